@@ -1,0 +1,277 @@
+"""ctypes binding of libbf_accel.so (include/bf_accel.h) -- plumbing for tests and bench.py.
+
+The product is the C-ABI library and the C++ host code on top of it
+(better_flow_amd/host/); this module only lets Python drive the same entry points.
+There is no CPU path here: if the library is missing, or no HIP device is present,
+construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libbf_accel.so")
+
+BF_OK, BF_SKIPPED = 0, 1
+BF_ERR_ARG, BF_ERR_HIP, BF_ERR_STATE, BF_ERR_NOCONV, BF_ERR_NODEVICE, BF_ERR_CAPACITY = (
+    -1, -2, -3, -4, -5, -6)
+
+
+class Model(C.Structure):
+    """bf_model == ObjectModel (object_model.h:10-13)."""
+    _fields_ = [
+        ("cx", C.c_double), ("cy", C.c_double), ("dx", C.c_double), ("dy", C.c_double),
+        ("rot", C.c_double), ("div", C.c_double), ("cnt", C.c_uint32), ("_pad", C.c_uint32),
+        ("total_dx", C.c_double), ("total_dy", C.c_double),
+        ("total_rot", C.c_double), ("total_div", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "_pad"}
+
+
+class Window(C.Structure):
+    _fields_ = [
+        ("scale", C.c_int32),
+        ("x_min", C.c_int32), ("y_min", C.c_int32), ("x_max", C.c_int32), ("y_max", C.c_int32),
+        ("metric_wsizex", C.c_int32), ("metric_wsizey", C.c_int32),
+        ("scale_img_x", C.c_int32), ("scale_img_y", C.c_int32), ("_pad", C.c_int32),
+        ("x_shift", C.c_double), ("y_shift", C.c_double),
+    ]
+
+
+class RunOpts(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int32), ("min_events", C.c_int32), ("res_x", C.c_int32),
+        ("res_y", C.c_int32), ("hard_iter_cap", C.c_int32), ("poll_interval", C.c_int32),
+        ("trace_cap", C.c_int32), ("want_uv", C.c_int32),
+    ]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [
+        ("rc", C.c_int32), ("iterations", C.c_int32),
+        ("x_divider", C.c_float), ("y_divider", C.c_float),
+        ("rot_divider", C.c_float), ("div_divider", C.c_float),
+        ("launches", C.c_int32), ("polls", C.c_int32),
+    ]
+
+
+class TraceRec(C.Structure):
+    _fields_ = [
+        ("model", Model),
+        ("x_divider", C.c_float), ("y_divider", C.c_float),
+        ("rot_divider", C.c_float), ("div_divider", C.c_float),
+        ("iteration", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("warp_scatter_ms", C.c_double), ("warp_scatter_launches", C.c_uint64),
+        ("stencil_ms", C.c_double), ("stencil_launches", C.c_uint64),
+        ("update_ms", C.c_double), ("update_launches", C.c_uint64),
+        ("other_ms", C.c_double), ("other_launches", C.c_uint64),
+        ("warp_scatter_events", C.c_uint64),
+    ]
+
+
+# every symbol include/bf_accel.h declares
+EXPORTS = [
+    "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
+    "bf_run_opts_default", "bf_set_option", "bf_upload_events", "bf_upload_events_device",
+    "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
+    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_get_trace",
+    "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
+    "bf_copy_bandwidth",
+]
+
+_lib = None
+
+
+class BfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bf_accel error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libbf_accel.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libbf_accel.so is missing (%s): build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C better_flow_amd/csrc`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.bf_last_error.restype = C.c_char_p
+        L.bf_version.restype = C.c_char_p
+        L.bf_create.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                C.POINTER(C.c_void_p)]
+        L.bf_destroy.argtypes = [C.c_void_p]
+        L.bf_destroy.restype = None
+        L.bf_last_error.argtypes = [C.c_void_p]
+        L.bf_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.bf_upload_events.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64]
+        L.bf_upload_events_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int64]
+        L.bf_set_cloud.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Window)]
+        L.bf_project_4param_reinit.argtypes = [C.c_void_p] + [C.c_double] * 6
+        L.bf_get_time_img.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bf_sobel.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.bf_fast_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Model)]
+        L.bf_writeout_events.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.bf_compute_uv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bf_set_model.argtypes = [C.c_void_p, C.POINTER(Model)]
+        L.bf_run.argtypes = [C.c_void_p, C.POINTER(RunOpts), C.POINTER(Model), C.POINTER(RunInfo)]
+        L.bf_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.bf_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+        L.bf_profile_reset.argtypes = [C.c_void_p]
+        L.bf_profile_get.argtypes = [C.c_void_p, C.POINTER(Profile)]
+        L.bf_synchronize.argtypes = [C.c_void_p]
+        L.bf_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+        L.bf_run_opts_default.argtypes = [C.POINTER(RunOpts)]
+        L.bf_device_count.argtypes = [C.POINTER(C.c_int32)]
+        _lib = L
+    return _lib
+
+
+def device_count():
+    n = C.c_int32(0)
+    load().bf_device_count(C.byref(n))
+    return n.value
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Accel:
+    """One bf_ctx: the AccelLib-equivalent plus the fused OptimizerRolling::run."""
+
+    def __init__(self, device=0, max_events=1 << 20, max_rows=1024, max_cols=1280, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.bf_create(device, max_events, max_rows, max_cols, stream, C.byref(h))
+        if rc != BF_OK:
+            raise BfError(rc, "bf_create failed (no HIP device?)" if rc == BF_ERR_NODEVICE
+                          else "bf_create failed")
+        self.h = h
+        self.n = 0
+        self.window = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, ok=(BF_OK,)):
+        if rc not in ok:
+            raise BfError(rc, self.L.bf_last_error(self.h).decode())
+        return rc
+
+    def set_option(self, key, value):
+        self._chk(self.L.bf_set_option(self.h, key.encode(), int(value)))
+
+    def upload_events(self, fr_x, fr_y, t_ns, noise=None):
+        fr_x = np.ascontiguousarray(fr_x, dtype=np.int32)
+        fr_y = np.ascontiguousarray(fr_y, dtype=np.int32)
+        t_ns = np.ascontiguousarray(t_ns, dtype=np.int32)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, dtype=np.uint8)
+        self.n = len(fr_x)
+        self._chk(self.L.bf_upload_events(self.h, _ptr(fr_x), _ptr(fr_y), _ptr(t_ns), _ptr(noise),
+                                          self.n))
+
+    def upload_events_device(self, d_fr_x, d_fr_y, d_t, n):
+        self.n = int(n)
+        self._chk(self.L.bf_upload_events_device(self.h, d_fr_x, d_fr_y, d_t, self.n))
+
+    def set_cloud(self, scale=3, res_x=180, res_y=240):
+        w = Window()
+        self._chk(self.L.bf_set_cloud(self.h, scale, res_x, res_y, C.byref(w)))
+        self.window = w
+        return w
+
+    def project_4param_reinit(self, dnx, dny, cx, cy, div, crl):
+        self._chk(self.L.bf_project_4param_reinit(self.h, dnx, dny, cx, cy, div, crl))
+
+    def get_time_img(self, want_time=True, want_count=True):
+        R, Cc = self.window.scale_img_x, self.window.scale_img_y
+        t = np.empty((R, Cc), dtype=np.float32) if want_time else None
+        c = np.empty((R, Cc), dtype=np.uint32) if want_count else None
+        self._chk(self.L.bf_get_time_img(self.h, _ptr(t), _ptr(c)))
+        return t, c
+
+    def sobel(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        gx = np.empty_like(img)
+        gy = np.empty_like(img)
+        self._chk(self.L.bf_sobel(self.h, _ptr(img), img.shape[0], img.shape[1], _ptr(gx), _ptr(gy)))
+        return gx, gy
+
+    def fast_model(self, img=None):
+        m = Model()
+        if img is None:
+            self._chk(self.L.bf_fast_model(self.h, None, 0, 0, C.byref(m)))
+        else:
+            img = np.ascontiguousarray(img, dtype=np.float32)
+            self._chk(self.L.bf_fast_model(self.h, _ptr(img), img.shape[0], img.shape[1], C.byref(m)))
+        return m
+
+    def writeout_events(self):
+        out = [np.empty(self.n) for _ in range(4)]
+        self._chk(self.L.bf_writeout_events(self.h, *[_ptr(a) for a in out]))
+        return tuple(out)   # pr_x, pr_y, nx, ny
+
+    def compute_uv(self):
+        u, v = np.empty(self.n), np.empty(self.n)
+        self._chk(self.L.bf_compute_uv(self.h, _ptr(u), _ptr(v)))
+        return u, v
+
+    def set_model(self, model):
+        self._chk(self.L.bf_set_model(self.h, C.byref(model)))
+
+    def default_opts(self):
+        o = RunOpts()
+        self.L.bf_run_opts_default(C.byref(o))
+        return o
+
+    def run(self, opts=None):
+        m, info = Model(), RunInfo()
+        rc = self.L.bf_run(self.h, C.byref(opts) if opts is not None else None, C.byref(m),
+                           C.byref(info))
+        self._chk(rc, ok=(BF_OK, BF_SKIPPED))
+        return rc, m, info
+
+    def get_trace(self, cap):
+        buf = (TraceRec * max(cap, 1))()
+        n = C.c_int32(0)
+        self._chk(self.L.bf_get_trace(self.h, buf, cap, C.byref(n)))
+        return list(buf)[: n.value]
+
+    def profile_enable(self, mode=1):
+        self._chk(self.L.bf_profile_enable(self.h, mode))
+
+    def profile_reset(self):
+        self._chk(self.L.bf_profile_reset(self.h))
+
+    def profile_get(self):
+        p = Profile()
+        self._chk(self.L.bf_profile_get(self.h, C.byref(p)))
+        return p
+
+    def synchronize(self):
+        self._chk(self.L.bf_synchronize(self.h))
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=5):
+        g = C.c_double(0)
+        self._chk(self.L.bf_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
+        return g.value

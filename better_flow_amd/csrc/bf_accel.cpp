@@ -1,0 +1,908 @@
+// bf_accel.cpp -- C-ABI (include/bf_accel.h) over the gfx950 kernels of bf_kernels.hip.
+//
+// Host-side counterpart of better-flow's AccelLib (accel_lib.h:14-616) plus the fused
+// OptimizerRolling::run (optimizer_rolling.h:48-125).  A bf_ctx owns every device buffer,
+// is reusable across slices and never allocates per slice.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "bf_device.h"
+#include "bf_kernels.h"
+
+using namespace bf;
+
+namespace {
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int cat;
+    long long nev;
+};
+
+}  // namespace
+
+struct bf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    long long cap_events = 0;   // padded
+    long long n = 0, n_pad = 0;
+    size_t cap_px = 0;
+    int cap_blocks = 0;
+
+    uint32_t* d_xy = nullptr;
+    int32_t* d_t = nullptr;
+    float2* d_p = nullptr;
+    uint8_t* d_noise = nullptr;
+    int32_t *d_in_x = nullptr, *d_in_y = nullptr, *d_in_t = nullptr;
+    double2 *d_nxny = nullptr, *d_uv = nullptr;
+    unsigned long long* d_plane[2] = {nullptr, nullptr};
+    uint32_t* d_cplane[2] = {nullptr, nullptr};
+    float *d_time = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_img = nullptr;
+    uint32_t* d_count = nullptr;
+    Partial* d_partials = nullptr;
+    DevState* d_state = nullptr;
+    SliceStats* d_stats = nullptr;
+    bf_trace_rec* d_trace = nullptr;
+    int trace_alloc = 0;
+    int trace_valid = 0;
+
+    DevState* h_state = nullptr;     // pinned, D2H target only
+    SliceStats* h_stats = nullptr;   // pinned, D2H target only
+
+    DevState hst;                    // authoritative host mirror outside bf_run
+    bf_window win;
+    bool uploaded = false, have_window = false;
+    bool has_noise = false, all_noise = false;
+    bool packed = true;
+    bool force_split = false;
+    bool degenerate = false;         // window with R <= 0 or C <= 0 (empty slice)
+    bool pending_warp = false;       // bf_set_model's warp not applied yet
+    bool n_valid = false;            // d_nxny holds the n of the last warp
+    int cur = 0;                     // plane buffer that is guaranteed all-zero
+    bool planes_unknown = true;      // both buffers must be cleared before use
+    int last_R = 0, last_C = 0;
+
+    int prof_mode = 0;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    bf_profile prof;
+
+    char err[512];
+};
+
+namespace {
+
+int fail(bf_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail((c), BF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+hipEvent_t get_event(bf_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Brackets one kernel launch with events when profiling is on.
+struct ProfScope {
+    bf_ctx* c;
+    ProfRec r;
+    bool on;
+    ProfScope(bf_ctx* c_, int cat, long long nev = 0) : c(c_), on(c_->prof_mode == 1) {
+        if (!on) return;
+        r.a = get_event(c);
+        r.b = get_event(c);
+        r.cat = cat;
+        r.nev = nev;
+        (void)hipEventRecord(r.a, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, c->stream);
+        c->prof_pending.push_back(r);
+    }
+};
+
+int prof_fold(bf_ctx* c) {
+    if (c->prof_pending.empty()) return BF_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof_pending) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        switch (r.cat) {
+            case 0: c->prof.warp_scatter_ms += ms; c->prof.warp_scatter_launches++;
+                    c->prof.warp_scatter_events += (uint64_t)r.nev; break;
+            case 1: c->prof.stencil_ms += ms; c->prof.stencil_launches++; break;
+            case 2: c->prof.update_ms += ms; c->prof.update_launches++; break;
+            default: c->prof.other_ms += ms; c->prof.other_launches++; break;
+        }
+        c->ev_pool.push_back(r.a);
+        c->ev_pool.push_back(r.b);
+    }
+    c->prof_pending.clear();
+    return BF_OK;
+}
+
+int bit_length(unsigned long long v) {
+    int b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+WarpParams identity_warp() {
+    WarpParams w;
+    w.dnx = w.dny = w.cx = w.cy = w.div = 0.0;
+    w.c = 1.0;
+    w.s = 0.0;
+    return w;
+}
+
+WarpScatterArgs ws_args(bf_ctx* c, int buf, int check_done) {
+    WarpScatterArgs a;
+    a.xy = c->d_xy; a.t = c->d_t; a.p = c->d_p;
+    a.noise = c->has_noise ? c->d_noise : nullptr;
+    a.nxny = c->d_nxny;
+    a.plane = c->d_plane[buf];
+    a.cplane = c->d_cplane[buf];
+    a.st = c->d_state;
+    a.n = c->n;
+    a.check_done = check_done;
+    a.packed = c->packed;
+    return a;
+}
+
+StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
+    StencilArgs a;
+    memset(&a, 0, sizeof(a));
+    a.st = c->d_state;
+    a.check_done = check_done;
+    a.R = c->win.scale_img_x; a.C = c->win.scale_img_y;
+    a.scale = c->win.scale;
+    a.tbits = c->hst.tbits;
+    a.tmin = c->hst.tmin;
+    a.plane = c->d_plane[buf];
+    a.cplane = c->d_cplane[buf];
+    a.zero_plane = c->d_plane[buf ^ 1];
+    a.zero_cplane = c->packed ? nullptr : c->d_cplane[buf ^ 1];
+    return a;
+}
+
+int ensure_cplanes(bf_ctx* c) {
+    if (c->d_cplane[0]) return BF_OK;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, hipMalloc(&c->d_cplane[i], c->cap_px * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->d_cplane[i], 0, c->cap_px * sizeof(uint32_t), c->stream));
+    }
+    return BF_OK;
+}
+
+int clear_planes(bf_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, hipMemsetAsync(c->d_plane[i], 0, c->cap_px * sizeof(unsigned long long), c->stream));
+        if (c->d_cplane[i])
+            HIP_TRY(c, hipMemsetAsync(c->d_cplane[i], 0, c->cap_px * sizeof(uint32_t), c->stream));
+    }
+    c->planes_unknown = false;
+    c->cur = 0;
+    return BF_OK;
+}
+
+// Apply the warp bf_set_model left pending (optimizer_rolling.h:294-298).
+int flush_pending(bf_ctx* c) {
+    if (!c->pending_warp) return BF_OK;
+    launch_set_state(c->d_state, c->hst, c->stream);
+    {
+        ProfScope ps(c, 3);
+        launch_warp_scatter(ws_args(c, c->cur, 0), true, false, true, c->stream);
+    }
+    c->pending_warp = false;
+    c->n_valid = true;
+    HIP_TRY(c, hipGetLastError());
+    return BF_OK;
+}
+
+int d2h_state(bf_ctx* c) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+int after_upload(bf_ctx* c, long long n) {
+    c->n = n;
+    c->uploaded = true;
+    c->have_window = false;
+    c->all_noise = false;
+    c->pending_warp = false;
+    c->n_valid = false;
+    return BF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bf_version(void) { return "bf_accel gfx950 r1"; }
+
+int bf_device_count(int32_t* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    return (e == hipSuccess && n > 0) ? BF_OK : BF_ERR_NODEVICE;
+}
+
+void bf_run_opts_default(bf_run_opts* o) {
+    if (!o) return;
+    o->max_iter = -1;       // OptimizerRolling(): max_itercount(-1)
+    o->min_events = 1000;   // optimizer_rolling.h:57
+    o->res_x = 180;         // common.h:39
+    o->res_y = 240;         // common.h:40
+    o->hard_iter_cap = 100000;
+    o->poll_interval = 8;
+    o->trace_cap = 0;
+    o->want_uv = 0;
+}
+
+int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_cols, void* hip_stream,
+              bf_ctx** out) {
+    if (!out || max_events <= 0 || max_rows <= 0 || max_cols <= 0) return BF_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BF_ERR_NODEVICE;
+    if (device < 0 || device >= ndev) return BF_ERR_ARG;
+    bf_ctx* c = new (std::nothrow) bf_ctx();
+    if (!c) return BF_ERR_HIP;
+    c->err[0] = 0;
+    memset(&c->hst, 0, sizeof(c->hst));
+    memset(&c->win, 0, sizeof(c->win));
+    memset(&c->prof, 0, sizeof(c->prof));
+    c->device = device;
+    int rc = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(device));
+        if (hip_stream) {
+            c->stream = (hipStream_t)hip_stream;
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        const long long gran = (long long)kThreads * kEvPerThread;
+        c->cap_events = ((long long)max_events + gran - 1) / gran * gran;
+        c->cap_px = (size_t)max_rows * (size_t)max_cols;
+        int gx, gy;
+        stencil_grid(max_rows, max_cols, &gx, &gy);
+        // a window with the same pixel count but another aspect ratio can need more tiles
+        c->cap_blocks = gx * gy * 2 + 64;
+        const size_t ne = (size_t)c->cap_events;
+        HIP_TRY(c, hipMalloc(&c->d_xy, ne * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_t, ne * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_p, ne * sizeof(float2)));
+        HIP_TRY(c, hipMalloc(&c->d_noise, ne));
+        HIP_TRY(c, hipMalloc(&c->d_in_x, ne * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_in_y, ne * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_in_t, ne * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_nxny, ne * sizeof(double2)));
+        HIP_TRY(c, hipMalloc(&c->d_uv, ne * sizeof(double2)));
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(c, hipMalloc(&c->d_plane[i], c->cap_px * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_time, c->cap_px * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&c->d_gx, c->cap_px * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&c->d_gy, c->cap_px * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&c->d_img, c->cap_px * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&c->d_count, c->cap_px * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_partials, (size_t)c->cap_blocks * sizeof(Partial)));
+        HIP_TRY(c, hipMalloc(&c->d_state, sizeof(DevState)));
+        HIP_TRY(c, hipMalloc(&c->d_stats, sizeof(SliceStats)));
+        HIP_TRY(c, hipHostMalloc(&c->h_state, sizeof(DevState), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(&c->h_stats, sizeof(SliceStats), hipHostMallocDefault));
+        HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
+        int r = clear_planes(c);
+        if (r != BF_OK) return r;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return BF_OK;
+    }();
+    if (rc != BF_OK) {
+        fprintf(stderr, "bf_create: %s\n", c->err);
+        bf_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return BF_OK;
+}
+
+void bf_destroy(bf_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    void* bufs[] = {c->d_xy, c->d_t, c->d_p, c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
+                    c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
+                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_state, c->d_stats,
+                    c->d_trace};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* bf_last_error(const bf_ctx* c) { return c ? c->err : "null ctx"; }
+
+int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return BF_ERR_ARG;
+    if (!strcmp(key, "force_split")) {
+        c->force_split = value != 0;
+        return BF_OK;
+    }
+    return fail(c, BF_ERR_ARG, "unknown option '%s'", key);
+}
+
+int bf_synchronize(bf_ctx* c) {
+    if (!c) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+// ---- slice set-up ---------------------------------------------------------------------
+
+static int stage_common(bf_ctx* c, const int32_t* dx, const int32_t* dy, const int32_t* dt, long long n) {
+    const long long gran = (long long)kThreads * kEvPerThread;
+    c->n_pad = (n + gran - 1) / gran * gran;
+    launch_init_stats(c->d_stats, c->stream);
+    {
+        ProfScope ps(c, 3);
+        launch_prepare(dx, dy, dt, c->d_xy, c->d_t, c->d_p, n, c->n_pad, c->d_stats, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return after_upload(c, n);
+}
+
+int bf_upload_events(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_ns,
+                     const uint8_t* noise, int64_t n) {
+    if (!c) return BF_ERR_ARG;
+    if (n < 0 || (n > 0 && (!fr_x || !fr_y || !t_ns))) return fail(c, BF_ERR_ARG, "bad event arrays");
+    if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nb = (size_t)n * sizeof(int32_t);
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_in_x, fr_x, nb, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_in_y, fr_y, nb, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_in_t, t_ns, nb, hipMemcpyHostToDevice, c->stream));
+    }
+    c->has_noise = false;
+    if (noise && n > 0) {
+        const long long gran = (long long)kThreads * kEvPerThread;
+        const long long n_pad = (n + gran - 1) / gran * gran;
+        HIP_TRY(c, hipMemsetAsync(c->d_noise, 0, (size_t)n_pad, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_noise, noise, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        c->has_noise = true;
+    }
+    int rc = stage_common(c, c->d_in_x, c->d_in_y, c->d_in_t, n);
+    if (rc != BF_OK) return rc;
+    // host arrays are only borrowed for the duration of the call
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+int bf_upload_events_device(bf_ctx* c, const int32_t* d_fr_x, const int32_t* d_fr_y, const int32_t* d_t_ns,
+                            int64_t n) {
+    if (!c) return BF_ERR_ARG;
+    if (n < 0 || (n > 0 && (!d_fr_x || !d_fr_y || !d_t_ns))) return fail(c, BF_ERR_ARG, "bad event arrays");
+    if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->has_noise = false;
+    return stage_common(c, d_fr_x, d_fr_y, d_t_ns, n);
+}
+
+int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_window* window_out) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_set_cloud before bf_upload_events");
+    if (scale < 1 || scale % 2 == 0 || scale / 2 > kMaxHalfScale)   // optimizer_rolling.h:274
+        return fail(c, BF_ERR_ARG, "scale must be odd and <= %d (got %d)", 2 * kMaxHalfScale + 1, scale);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(SliceStats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const SliceStats s = *c->h_stats;
+    bf_window w;
+    memset(&w, 0, sizeof(w));
+    w.scale = scale;
+    // optimizer_rolling.h:252-260: min seeded with RES, max with 0
+    w.x_min = res_x; w.y_min = res_y; w.x_max = 0; w.y_max = 0;
+    if (c->n > 0) {
+        if (s.xmin < 0 || s.ymin < 0 || s.xmax > 65535 || s.ymax > 65535)
+            return fail(c, BF_ERR_ARG, "event coordinates outside [0, 65535]");
+        if (s.xmax > w.x_max) w.x_max = s.xmax;
+        if (s.ymax > w.y_max) w.y_max = s.ymax;
+        if (s.xmin < w.x_min) w.x_min = s.xmin;
+        if (s.ymin < w.y_min) w.y_min = s.ymin;
+    }
+    w.metric_wsizex = scale * (w.x_max - w.x_min);   // :263
+    w.metric_wsizey = scale * (w.y_max - w.y_min);   // :264
+    w.scale_img_x = w.metric_wsizex + scale;         // :276
+    w.scale_img_y = w.metric_wsizey + scale;         // :277
+    // :279-282, both "/ 2" are integer divisions
+    w.x_shift = -double((w.x_max - w.x_min) / 2 + w.x_min) * double(scale) +
+                double(w.metric_wsizex) / 2.0 + scale / 2;
+    w.y_shift = -double((w.y_max - w.y_min) / 2 + w.y_min) * double(scale) +
+                double(w.metric_wsizey) / 2.0 + scale / 2;
+    if (w.scale_img_x <= 0 || w.scale_img_y <= 0) {
+        // e.g. an empty slice: x_min = RES_X > x_max = 0.  The reference carries on and run()
+        // returns 1 at the window guard (:49-55); no image operator is usable on it.
+        c->win = w;
+        c->have_window = true;
+        c->degenerate = true;
+        memset(&c->hst.model, 0, sizeof(c->hst.model));
+        c->pending_warp = false;
+        if (window_out) *window_out = w;
+        return BF_OK;
+    }
+    c->degenerate = false;
+    if ((size_t)w.scale_img_x * (size_t)w.scale_img_y > c->cap_px)
+        return fail(c, BF_ERR_CAPACITY, "window %d x %d exceeds the image capacity", w.scale_img_x, w.scale_img_y);
+    int gx, gy;
+    stencil_grid(w.scale_img_x, w.scale_img_y, &gx, &gy);
+    if (gx * gy > c->cap_blocks) return fail(c, BF_ERR_CAPACITY, "window needs %d tiles > %d", gx * gy, c->cap_blocks);
+
+    // Accumulator packing: count << tbits | sum(t - tmin).  Exact iff both fields can hold the
+    // whole slice (no pixel can collect more than all events / all time).
+    long long tmin = (c->n > 0) ? (long long)s.tmin : 0;
+    unsigned long long span_sum = (c->n > 0) ? (unsigned long long)(s.tsum - tmin * c->n) : 0ull;
+    int tbits = bit_length(span_sum);
+    if (tbits < 1) tbits = 1;
+    int cbits = bit_length((unsigned long long)c->n);
+    c->packed = !c->force_split && (tbits + cbits <= 64);
+    if (!c->packed) {
+        int rc = ensure_cplanes(c);
+        if (rc != BF_OK) return rc;
+        tbits = 64;
+    }
+
+    c->win = w;
+    c->have_window = true;
+    DevState& h = c->hst;
+    h.scale = scale;
+    h.R = w.scale_img_x; h.C = w.scale_img_y;
+    h.wsx = w.metric_wsizex; h.wsy = w.metric_wsizey;
+    h.x_sh = (int)w.x_shift;   // double -> int parameter conversion of accel_lib.h:147
+    h.y_sh = (int)w.y_shift;
+    h.tbits = tbits;
+    h.x_shift = w.x_shift; h.y_shift = w.y_shift;
+    h.tmin = tmin;
+    h.nblocks = gx * gy;
+    memset(&h.model, 0, sizeof(h.model));   // a fresh OptimizerRolling has a zero ObjectModel
+    h.wp = identity_warp();
+    h.it = 0; h.done = 0; h.rc = 0;
+    c->pending_warp = false;
+    c->all_noise = false;
+    // Event::reset for every event (set_cloud :260).  bf_upload_events already reset p.
+    HIP_TRY(c, hipMemsetAsync(c->d_p, 0, (size_t)c->n_pad * sizeof(float2), c->stream));
+    c->n_valid = false;
+    if (c->planes_unknown || w.scale_img_x != c->last_R || w.scale_img_y != c->last_C) {
+        int rc = clear_planes(c);
+        if (rc != BF_OK) return rc;
+    }
+    c->last_R = w.scale_img_x;
+    c->last_C = w.scale_img_y;
+    launch_set_state(c->d_state, c->hst, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    if (window_out) *window_out = w;
+    return BF_OK;
+}
+
+// ---- AccelLib operators ----------------------------------------------------------------
+
+int bf_project_4param_reinit(bf_ctx* c, double dnx_, double dny_, double cx, double cy, double div,
+                             double crl) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_project_4param_reinit before bf_set_cloud");
+    if (c->degenerate) return fail(c, BF_ERR_STATE, "bf_project_4param_reinit on a degenerate (empty) window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != BF_OK) return rc;
+    WarpParams& w = c->hst.wp;
+    w.dnx = dnx_; w.dny = dny_; w.cx = cx; w.cy = cy; w.div = div;
+    w.c = std::cos(crl);   // event.h:102-103 evaluates std::cos / std::sin on the host
+    w.s = std::sin(crl);
+    launch_set_state(c->d_state, c->hst, c->stream);
+    {
+        ProfScope ps(c, 0, c->n);
+        launch_warp_scatter(ws_args(c, c->cur, 0), true, false, true, c->stream);
+    }
+    c->n_valid = true;
+    HIP_TRY(c, hipGetLastError());
+    return BF_OK;
+}
+
+int bf_get_time_img(bf_ctx* c, float* time_out, uint32_t* count_out) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_get_time_img before bf_set_cloud");
+    if (c->degenerate) return fail(c, BF_ERR_STATE, "bf_get_time_img on a degenerate (empty) window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != BF_OK) return rc;
+    launch_set_state(c->d_state, c->hst, c->stream);
+    const int buf = c->cur;
+    if (!c->all_noise) {
+        ProfScope ps(c, 0, c->n);
+        launch_warp_scatter(ws_args(c, buf, 0), false, true, false, c->stream);
+    }
+    StencilArgs a = st_args(c, buf, 0);
+    a.time_out = c->d_time;
+    a.count_out = c->d_count;
+    {
+        ProfScope ps(c, 1);
+        launch_stencil(a, c->packed ? 0 : 1, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->cur = buf ^ 1;   // the stencil zeroed the other buffer; `buf` is cleared by the next pass
+    const size_t P = (size_t)c->win.scale_img_x * (size_t)c->win.scale_img_y;
+    if (time_out)
+        HIP_TRY(c, hipMemcpyAsync(time_out, c->d_time, P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (count_out)
+        HIP_TRY(c, hipMemcpyAsync(count_out, c->d_count, P * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+static int image_pass(bf_ctx* c, const float* d_src, int rows, int cols, bool grads, bool moments) {
+    StencilArgs a;
+    memset(&a, 0, sizeof(a));
+    a.st = c->d_state;
+    a.R = rows; a.C = cols; a.scale = 1;
+    a.time_in = d_src;
+    if (grads) { a.gx_out = c->d_gx; a.gy_out = c->d_gy; }
+    if (moments) a.partials = c->d_partials;
+    ProfScope ps(c, 1);
+    launch_stencil(a, 2, c->stream);
+    return BF_OK;
+}
+
+int bf_sobel(bf_ctx* c, const float* img, int32_t rows, int32_t cols, float* grad_x, float* grad_y) {
+    if (!c) return BF_ERR_ARG;
+    if (!img || !grad_x || !grad_y || rows <= 0 || cols <= 0) return fail(c, BF_ERR_ARG, "bad image");
+    const size_t P = (size_t)rows * (size_t)cols;
+    if (P > c->cap_px) return fail(c, BF_ERR_CAPACITY, "image %d x %d exceeds capacity", rows, cols);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img, img, P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    image_pass(c, c->d_img, rows, cols, true, false);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(grad_x, c->d_gx, P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(grad_y, c->d_gy, P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+int bf_fast_model(bf_ctx* c, const float* img, int32_t rows, int32_t cols, bf_model* model) {
+    if (!c) return BF_ERR_ARG;
+    if (!model) return fail(c, BF_ERR_ARG, "model is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float* src = c->d_time;
+    if (img) {
+        if (rows <= 0 || cols <= 0) return fail(c, BF_ERR_ARG, "bad image");
+        const size_t P = (size_t)rows * (size_t)cols;
+        if (P > c->cap_px) return fail(c, BF_ERR_CAPACITY, "image %d x %d exceeds capacity", rows, cols);
+        HIP_TRY(c, hipMemcpyAsync(c->d_img, img, P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        src = c->d_img;
+    } else {
+        if (!c->have_window) return fail(c, BF_ERR_STATE, "no resident time image");
+        rows = c->win.scale_img_x;
+        cols = c->win.scale_img_y;
+    }
+    int gx, gy;
+    stencil_grid(rows, cols, &gx, &gy);
+    if (gx * gy > c->cap_blocks) return fail(c, BF_ERR_CAPACITY, "image needs %d tiles", gx * gy);
+    image_pass(c, src, rows, cols, false, true);
+    DevState tmp = c->hst;
+    tmp.R = rows; tmp.C = cols;
+    launch_set_state(c->d_state, tmp, c->stream);
+    {
+        ProfScope ps(c, 2);
+        launch_update(c->d_state, c->d_partials, gx * gy, nullptr, 0, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    int rc = d2h_state(c);
+    if (rc != BF_OK) return rc;
+    const bf_model& m = c->h_state->model;
+    model->cx = m.cx; model->cy = m.cy;
+    model->dx = m.dx; model->dy = m.dy;
+    model->rot = m.rot; model->div = m.div;
+    model->cnt = m.cnt;
+    return BF_OK;
+}
+
+static int copy_pairs(bf_ctx* c, const double2* d_src, double* a, double* b) {
+    std::vector<double2> tmp((size_t)c->n);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), d_src, (size_t)c->n * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (long long i = 0; i < c->n; ++i) {
+        if (a) a[i] = tmp[(size_t)i].x;
+        if (b) b[i] = tmp[(size_t)i].y;
+    }
+    return BF_OK;
+}
+
+int bf_writeout_events(bf_ctx* c, double* pr_x, double* pr_y, double* nx, double* ny) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_writeout_events before bf_set_cloud");
+    if (c->degenerate) return fail(c, BF_ERR_STATE, "bf_writeout_events on a degenerate (empty) window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != BF_OK) return rc;
+    if (c->n == 0) return BF_OK;
+    if (pr_x || pr_y) {
+        {
+            ProfScope ps(c, 3);
+            launch_expand_pr(c->d_xy, c->d_p, c->d_uv, c->n, c->stream);
+        }
+        HIP_TRY(c, hipGetLastError());
+        rc = copy_pairs(c, c->d_uv, pr_x, pr_y);
+        if (rc != BF_OK) return rc;
+    }
+    if (nx || ny) {
+        if (!c->n_valid) {   // Event::reset leaves nx = ny = 0 (event.h:57)
+            for (long long i = 0; i < c->n; ++i) {
+                if (nx) nx[i] = 0.0;
+                if (ny) ny[i] = 0.0;
+            }
+        } else {
+            rc = copy_pairs(c, c->d_nxny, nx, ny);
+            if (rc != BF_OK) return rc;
+        }
+    }
+    return BF_OK;
+}
+
+int bf_compute_uv(bf_ctx* c, double* u, double* v) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_compute_uv before bf_set_cloud");
+    if (c->degenerate) return fail(c, BF_ERR_STATE, "bf_compute_uv on a degenerate (empty) window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != BF_OK) return rc;
+    if (c->n == 0) return BF_OK;
+    if (!c->n_valid) {
+        for (long long i = 0; i < c->n; ++i) {
+            if (u) u[i] = 0.0;
+            if (v) v[i] = 0.0;
+        }
+        return BF_OK;
+    }
+    {
+        ProfScope ps(c, 3);
+        launch_compute_uv(c->d_nxny, c->d_uv, c->n, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return copy_pairs(c, c->d_uv, u, v);
+}
+
+// ---- fused optimizer ---------------------------------------------------------------------
+
+int bf_set_model(bf_ctx* c, const bf_model* model) {
+    if (!c || !model) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_set_model before bf_set_cloud");
+    if (c->degenerate) {   // nothing to warp; get_model() still returns what was set
+        c->hst.model = *model;
+        return BF_OK;
+    }
+    // optimizer_rolling.h:289-299: model <- m; warp(-total_dx, -total_dy, cx, cy, total_div, -total_rot)
+    c->hst.model = *model;
+    WarpParams& w = c->hst.wp;
+    w.dnx = -model->total_dx; w.dny = -model->total_dy;
+    w.cx = model->cx; w.cy = model->cy;
+    w.div = model->total_div;
+    w.c = std::cos(-model->total_rot);
+    w.s = std::sin(-model->total_rot);
+    c->pending_warp = true;
+    return BF_OK;
+}
+
+int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_info* info) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_run before bf_set_cloud");
+    bf_run_opts o;
+    if (opts_in) o = *opts_in; else bf_run_opts_default(&o);
+    if (o.poll_interval < 1) o.poll_interval = 1;
+    bf_run_info inf;
+    memset(&inf, 0, sizeof(inf));
+    inf.x_divider = inf.y_divider = 1.0f;
+    inf.rot_divider = inf.div_divider = 10000.0f;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bf_window& w = c->win;
+
+    // optimizer_rolling.h:49-55 (integer arithmetic) and :57-58
+    if ((w.scale_img_x < w.scale * o.res_x / 15) && (w.scale_img_y < w.scale * o.res_y / 15)) {
+        c->all_noise = true;   // "for (auto &e : *events) e.noise = true;"
+        inf.rc = BF_SKIPPED;
+    } else if (c->n < (long long)o.min_events) {
+        inf.rc = BF_SKIPPED;
+    }
+    if (inf.rc == BF_SKIPPED) {
+        if (model_out) *model_out = c->hst.model;
+        if (info) *info = inf;
+        return BF_SKIPPED;
+    }
+
+    if (o.trace_cap > c->trace_alloc) {
+        if (c->d_trace) HIP_TRY(c, hipFree(c->d_trace));
+        c->d_trace = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_trace, (size_t)o.trace_cap * sizeof(bf_trace_rec)));
+        c->trace_alloc = o.trace_cap;
+    }
+    DevState& h = c->hst;
+    h.x_div = h.y_div = 1.0f;            // :61
+    h.rot_div = h.div_div = 10000.0f;    // :62-63
+    h.old_dx = h.old_dy = h.old_rot = h.old_div = 0.f;
+    h.it = 0; h.done = 0; h.rc = 0;
+    h.max_iter = o.max_iter;
+    h.hard_cap = o.hard_iter_cap;
+    h.trace_cap = o.trace_cap;
+    if (!c->pending_warp) h.wp = identity_warp();
+    launch_set_state(c->d_state, h, c->stream);
+
+    const int b0 = c->cur;
+    int buf = b0;
+    bool first = true;
+    const bool first_warp = c->pending_warp;
+    c->pending_warp = false;
+    bf_trace_rec* trace = o.trace_cap > 0 ? c->d_trace : nullptr;
+    int launched_iters = 0;
+    for (;;) {
+        for (int k = 0; k < o.poll_interval; ++k) {
+            {
+                ProfScope ps(c, 0, c->n);
+                launch_warp_scatter(ws_args(c, buf, 1), first ? first_warp : true, true, false, c->stream);
+            }
+            {
+                StencilArgs a = st_args(c, buf, 1);
+                a.partials = c->d_partials;
+                ProfScope ps(c, 1);
+                launch_stencil(a, c->packed ? 0 : 1, c->stream);
+            }
+            {
+                ProfScope ps(c, 2);
+                launch_update(c->d_state, c->d_partials, h.nblocks, trace, 1, c->stream);
+            }
+            first = false;
+            buf ^= 1;
+            ++launched_iters;
+            inf.launches += 3;
+        }
+        HIP_TRY(c, hipGetLastError());
+        int rc = d2h_state(c);
+        if (rc != BF_OK) return rc;
+        inf.polls++;
+        if (c->h_state->done) break;
+        if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 8) + o.poll_interval)
+            return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
+    }
+    // final warp: the last project_4param_reinit of iteration_step (:340-344), kept so that
+    // pr / nx / ny describe the converged model; n is written for compute_uv / writeout.
+    {
+        ProfScope ps(c, 0, c->n);
+        launch_warp_scatter(ws_args(c, buf, 0), true, false, true, c->stream);
+    }
+    inf.launches++;
+    c->n_valid = true;
+    if (o.want_uv) {
+        ProfScope ps(c, 3);
+        launch_compute_uv(c->d_nxny, c->d_uv, c->n, c->stream);
+        inf.launches++;
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (o.want_uv) HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    const DevState& d = *c->h_state;
+    h.model = d.model; h.wp = d.wp;
+    h.x_div = d.x_div; h.y_div = d.y_div; h.rot_div = d.rot_div; h.div_div = d.div_div;
+    h.it = d.it; h.done = d.done; h.rc = d.rc;
+    // iterations executed alternate buffers starting at b0; the stencil of the last one
+    // zeroed the buffer that the next pass will scatter into.
+    c->cur = b0 ^ (d.it & 1);
+    c->trace_valid = d.it < o.trace_cap ? d.it : o.trace_cap;
+    inf.rc = d.rc;
+    inf.iterations = d.it;
+    inf.x_divider = d.x_div; inf.y_divider = d.y_div;
+    inf.rot_divider = d.rot_div; inf.div_divider = d.div_div;
+    if (model_out) *model_out = d.model;
+    if (info) *info = inf;
+    if (d.rc < 0) return fail(c, d.rc, "iteration cap (%d) reached without convergence", o.hard_iter_cap);
+    return d.rc;
+}
+
+int bf_get_trace(bf_ctx* c, bf_trace_rec* out, int32_t cap, int32_t* written) {
+    if (!c || !out || cap < 0) return BF_ERR_ARG;
+    int n = c->trace_valid < cap ? c->trace_valid : cap;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_trace, (size_t)n * sizeof(bf_trace_rec), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (written) *written = n;
+    return BF_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------
+
+int bf_profile_enable(bf_ctx* c, int32_t mode) {
+    if (!c || mode < 0 || mode > 1) return BF_ERR_ARG;
+    int rc = prof_fold(c);
+    c->prof_mode = mode;
+    return rc;
+}
+
+int bf_profile_reset(bf_ctx* c) {
+    if (!c) return BF_ERR_ARG;
+    int rc = prof_fold(c);
+    memset(&c->prof, 0, sizeof(c->prof));
+    return rc;
+}
+
+int bf_profile_get(bf_ctx* c, bf_profile* out) {
+    if (!c || !out) return BF_ERR_ARG;
+    int rc = prof_fold(c);
+    *out = c->prof;
+    return rc;
+}
+
+int bf_copy_bandwidth(bf_ctx* c, int64_t bytes, int32_t reps, double* gbps_out) {
+    if (!c || !gbps_out || bytes < 4096 || reps < 1) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    bytes &= ~(int64_t)15;
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(c, hipMalloc(&a, (size_t)bytes));
+    HIP_TRY(c, hipMalloc(&b, (size_t)bytes));
+    HIP_TRY(c, hipMemsetAsync(a, 1, (size_t)bytes, c->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    launch_copy(a, b, bytes, c->stream);   // warm-up
+    double best = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        launch_copy(a, b, bytes, c->stream);
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+        const double g = 2.0 * (double)bytes / ((double)ms * 1e-3) / 1e9;
+        if (g > best) best = g;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *gbps_out = best;
+    return BF_OK;
+}
+
+}  // extern "C"

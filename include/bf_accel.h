@@ -1,0 +1,218 @@
+/*
+ * bf_accel.h -- C-ABI of the MI355X (gfx950) motion-compensation path.
+ *
+ * This is the drop-in boundary for better-flow's `class AccelLib`
+ * (better_flow_core/include/better_flow/accel_lib.h:14-616) as it is consumed by
+ * `OptimizerRolling` (optimizer_rolling.h:19,269,294,308,322,327,340) plus the fused
+ * on-device form of `OptimizerRolling::run` (optimizer_rolling.h:48-125,305-347).
+ * Every entry point cites the reference interface it replaces.  All arguments are
+ * plain pointers / sizes / PODs; outputs are caller-allocated; nothing throws.
+ *
+ * Conventions (same as the reference): fr_x is the sensor ROW, fr_y the COLUMN
+ * (bf_motion_compensator.cpp:192,200); t is nanoseconds relative to the slice start
+ * (Event::set_local_time, event.h:61-63) and must fit int32 (the reference's own
+ * device layout, accel_lib.h:83-85); images are row-major R x C with
+ * R = metric_wsizex + scale, C = metric_wsizey + scale.
+ *
+ * Return values: 0 = BF_OK, 1 = BF_SKIPPED (run() skipped by a guard,
+ * optimizer_rolling.h:54,58 -- the reference's own "return 1"), < 0 = error.
+ * There is NO CPU fallback: without a usable HIP device bf_create fails with
+ * BF_ERR_NODEVICE and every other call fails with BF_ERR_ARG on a NULL ctx.
+ *
+ * Threading: one bf_ctx per (host thread, GPU).  A ctx is reusable across slices
+ * (no per-slice allocation), is not thread-safe, and owns all of its device memory,
+ * pinned staging and its HIP stream.
+ */
+#ifndef BF_ACCEL_H
+#define BF_ACCEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_OK 0
+#define BF_SKIPPED 1
+#define BF_ERR_ARG (-1)
+#define BF_ERR_HIP (-2)
+#define BF_ERR_STATE (-3)
+#define BF_ERR_NOCONV (-4)   /* hard iteration cap hit (the reference would spin) */
+#define BF_ERR_NODEVICE (-5)
+#define BF_ERR_CAPACITY (-6)
+
+typedef struct bf_ctx bf_ctx;
+
+/* ObjectModel, object_model.h:10-13. */
+typedef struct bf_model {
+    double cx, cy, dx, dy, rot, div;
+    uint32_t cnt;
+    uint32_t _pad;
+    double total_dx, total_dy, total_rot, total_div;
+} bf_model;
+
+/* Window geometry of OptimizerRolling::set_cloud / set_scale,
+ * optimizer_rolling.h:248-283 (members :22-31). */
+typedef struct bf_window {
+    int32_t scale;
+    int32_t x_min, y_min, x_max, y_max;
+    int32_t metric_wsizex, metric_wsizey;
+    int32_t scale_img_x, scale_img_y;   /* R, C */
+    int32_t _pad;
+    double x_shift, y_shift;
+} bf_window;
+
+/* Options of the fused run; defaults (bf_run_opts_default) are the reference's. */
+typedef struct bf_run_opts {
+    int32_t max_iter;        /* OptimizerRolling::set_maxiter, :236-238; <= 0: unlimited */
+    int32_t min_events;      /* literal 1000 at optimizer_rolling.h:57                  */
+    int32_t res_x, res_y;    /* RES_X / RES_Y of the window guard, :49 (common.h:39-40) */
+    int32_t hard_iter_cap;   /* not in the reference: give up with BF_ERR_NOCONV        */
+    int32_t poll_interval;   /* iterations enqueued between host polls of `done`        */
+    int32_t trace_cap;       /* per-iteration records kept for bf_get_trace (0 = none)  */
+    int32_t want_uv;         /* 1: also compute per-event (u,v) (Event::compute_uv)     */
+} bf_run_opts;
+
+/* What run() leaves behind besides the model (optimizer_rolling.h:36,59). */
+typedef struct bf_run_info {
+    int32_t rc;              /* 0 optimised, 1 skipped, <0 error                        */
+    int32_t iterations;      /* itercount                                               */
+    float x_divider, y_divider, rot_divider, div_divider;
+    int32_t launches;        /* kernel launches enqueued (diagnostic)                   */
+    int32_t polls;           /* host polls of the done flag (diagnostic)                */
+} bf_run_info;
+
+/* One record per iteration_step (trajectory tests). */
+typedef struct bf_trace_rec {
+    bf_model model;
+    float x_divider, y_divider, rot_divider, div_divider;
+    int32_t iteration;
+    int32_t _pad;
+} bf_trace_rec;
+
+/* Accumulated per-kernel GPU time, measured with hipEvents on the ctx stream. */
+typedef struct bf_profile {
+    double warp_scatter_ms;  uint64_t warp_scatter_launches;
+    double stencil_ms;       uint64_t stencil_launches;
+    double update_ms;        uint64_t update_launches;
+    double other_ms;         uint64_t other_launches;
+    uint64_t warp_scatter_events;   /* sum over launches of events processed */
+} bf_profile;
+
+/* ---- life cycle -------------------------------------------------------------- */
+
+/* Number of visible HIP devices (0 and BF_ERR_NODEVICE if the runtime has none). */
+int bf_device_count(int32_t *count);
+
+/* AccelLib::AccelLib (accel_lib.h:44-55) + the allocations of init_gpu (:86-92,
+ * :127-144).  Capacity is fixed at creation: up to max_events events and images of
+ * up to max_rows x max_cols pixels (R x C).  hip_stream: a hipStream_t to run on, or
+ * NULL to let the ctx create (and own) a non-blocking stream. */
+int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_cols,
+              void *hip_stream, bf_ctx **out);
+
+/* AccelLib::~AccelLib / clear_buffers (accel_lib.h:57-69). */
+void bf_destroy(bf_ctx *ctx);
+
+/* Text of the last error on this ctx ("" if none).  Never NULL. */
+const char *bf_last_error(const bf_ctx *ctx);
+
+/* Library / build identification, e.g. "bf_accel gfx950 r1". */
+const char *bf_version(void);
+
+void bf_run_opts_default(bf_run_opts *opts);
+
+/* Tuning / test knobs that have no counterpart in the reference.  Keys:
+ *   "force_split"  1: keep the event-count and time-sum accumulators in separate planes
+ *                  even when they fit one packed 64-bit word (takes effect at the next
+ *                  bf_set_cloud). */
+int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
+
+/* ---- slice set-up -------------------------------------------------------------- */
+
+/* AccelLib::init_gpu (accel_lib.h:71-115): stage one slice on the device.  Host
+ * arrays are borrowed for the duration of the call.  noise may be NULL (no event
+ * is noise, the state DVS_flow hands over).  Also resets the per-event warp state
+ * (Event::reset, event.h:54-59: pr <- fr, n <- 0). */
+int bf_upload_events(bf_ctx *ctx, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns,
+                     const uint8_t *noise, int64_t n);
+
+/* Same, but the three arrays are DEVICE pointers (slice already resident in HBM). */
+int bf_upload_events_device(bf_ctx *ctx, const int32_t *d_fr_x, const int32_t *d_fr_y,
+                            const int32_t *d_t_ns, int64_t n);
+
+/* OptimizerRolling::set_cloud + set_scale (optimizer_rolling.h:248-283): bounding
+ * box over fr (device reduction), window geometry, Event::reset for every event.
+ * res_x / res_y seed x_min / y_min (:252).  scale must be odd (:274). */
+int bf_set_cloud(bf_ctx *ctx, int32_t scale, int32_t res_x, int32_t res_y, bf_window *window_out);
+
+/* ---- AccelLib operators -------------------------------------------------------- */
+
+/* AccelLib::project_4param_reinit (accel_lib.h:263-267; Event::project_4param_reinit,
+ * event.h:99-110; apply_project, event.h:164-168).  cos/sin of crl are evaluated on
+ * the host with libm, as the reference does. */
+int bf_project_4param_reinit(bf_ctx *ctx, double dnx_, double dny_, double cx, double cy,
+                             double div, double crl);
+
+/* AccelLib::get_time_img (accel_lib.h:211-217 -> get_time_img_cpu :147-178) for the
+ * current window; x_sh / y_sh are (int)x_shift, (int)y_shift as at :147.  time_out
+ * (R*C floats) and count_out (R*C uint32, the event-count image the reference keeps
+ * local at :149) may each be NULL.  The time image stays resident for bf_fast_model. */
+int bf_get_time_img(bf_ctx *ctx, float *time_out, uint32_t *count_out);
+
+/* AccelLib::Sobel / Sobel_cpu (accel_lib.h:400-432,513-543) on a host image. */
+int bf_sobel(bf_ctx *ctx, const float *img, int32_t rows, int32_t cols, float *grad_x,
+             float *grad_y);
+
+/* AccelLib::fast_model (accel_lib.h:337-341) = ObjectModel::update
+ * (object_model.h:31-34; object_model.cpp:4-39,103-126).  img == NULL: use the time
+ * image left on the device by the last bf_get_time_img.  Sets cx, cy, dx, dy, rot,
+ * div, cnt of *model; totals are left untouched. */
+int bf_fast_model(bf_ctx *ctx, const float *img, int32_t rows, int32_t cols, bf_model *model);
+
+/* AccelLib::writeout_events (accel_lib.h:310-329): copy per-event state back.  Any
+ * pointer may be NULL.  Arrays hold n doubles in upload order. */
+int bf_writeout_events(bf_ctx *ctx, double *pr_x, double *pr_y, double *nx, double *ny);
+
+/* Event::compute_uv (event.h:135-142) for every event, from the current nx, ny. */
+int bf_compute_uv(bf_ctx *ctx, double *u, double *v);
+
+/* ---- fused optimizer ----------------------------------------------------------- */
+
+/* OptimizerRolling::set_model (optimizer_rolling.h:289-299): warm start ("STM",
+ * dvs_flow.h:218-219).  model->cx, cy are SENSOR coordinates (:345-346). */
+int bf_set_model(bf_ctx *ctx, const bf_model *model);
+
+/* OptimizerRolling::run (optimizer_rolling.h:48-125) with iteration_step (:305-347)
+ * executed entirely on the device: per iteration a warp+scatter kernel, a
+ * stencil+moments kernel and a scalar update kernel, no host round trip except a
+ * poll of the `done` word every opts->poll_interval iterations.  The starting model is
+ * the zero ObjectModel of a fresh optimizer (after bf_set_cloud) or what bf_set_model
+ * was given; model_out receives get_model() (:285-287).  opts == NULL: defaults.
+ * Returns info->rc. */
+int bf_run(bf_ctx *ctx, const bf_run_opts *opts, bf_model *model_out, bf_run_info *info);
+
+/* Records of the last bf_run (opts->trace_cap > 0).  Returns the number written. */
+int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
+
+/* ---- measurement ---------------------------------------------------------------- */
+
+/* Per-kernel hipEvent timing.  mode 0: off (default).  mode 1: bracket every kernel
+ * launch with events on the ctx stream; totals are read with bf_profile_get, which
+ * synchronises the stream. */
+int bf_profile_enable(bf_ctx *ctx, int32_t mode);
+int bf_profile_reset(bf_ctx *ctx);
+int bf_profile_get(bf_ctx *ctx, bf_profile *out);
+
+/* Block until everything enqueued on the ctx stream has finished. */
+int bf_synchronize(bf_ctx *ctx);
+
+/* Streaming-copy bandwidth probe on this device: copies `bytes` bytes `reps` times
+ * with a float4 kernel and returns the best GB/s (read + write counted).  Used by
+ * bench.py to report the measured HBM ceiling next to the 8 TB/s nominal peak. */
+int bf_copy_bandwidth(bf_ctx *ctx, int64_t bytes, int32_t reps, double *gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BF_ACCEL_H */

@@ -1,0 +1,365 @@
+/*
+ * bf_oracle.c -- CPU restatement of better-flow's motion-compensation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY -- see bf_oracle.h.  PARITY UNPINNED: the reference
+ * cannot be built in this image (needs OpenCV + TBB headers) and ships no tests or
+ * golden vectors, so every function below is a restatement of the cited reference
+ * lines, not something validated against the reference's own output.
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off (oracle/Makefile).  The reference is
+ * built for baseline x86-64 without FMA (better_flow_core/CMakeLists.txt:4,10), so no
+ * operation here may be contracted; every mixed float/double expression is written
+ * with the conversions C++ performs implicitly in the reference made explicit.
+ */
+#include "bf_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BFO_NZ 127.0 /* common.h:60, Event::nz is double (event.h:16) */
+
+/* `int x = <double expr>;` on x86-64 is cvttsd2si: truncation toward zero, and the
+ * "integer indefinite" value INT_MIN for NaN or out-of-range inputs.  Out-of-range
+ * conversion is UB in C, so the x86 behaviour the reference binary has is spelled
+ * out here (it only matters for NaN / absurd models; such events are then rejected
+ * by the bounds test at accel_lib.h:157). */
+static int32_t trunc_to_int_x86(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+    return (int32_t)v;
+}
+
+void bfo_model_init(bfo_model *m) { /* object_model.h:15-17 */
+    memset(m, 0, sizeof(*m));
+}
+
+/* Event::set_local_time, event.h:61-63:
+ *   t = (timestamp > t_) ? timestamp - t_ : -sll(t_ - timestamp);               */
+void bfo_set_local_time(const uint64_t *timestamp, int64_t n, uint64_t t0, int64_t *t_out) {
+    for (int64_t i = 0; i < n; ++i)
+        t_out[i] = (timestamp[i] > t0) ? (int64_t)(timestamp[i] - t0)
+                                       : -(int64_t)(t0 - timestamp[i]);
+}
+
+/* OptimizerRolling::set_cloud + set_scale, optimizer_rolling.h:248-283, and
+ * Event::reset, event.h:54-59 (pr <- fr, n <- 0). */
+void bfo_set_cloud(bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, bfo_window *w) {
+    w->scale = scale;
+    w->x_min = res_x; w->y_min = res_y;            /* :252 */
+    w->x_max = 0;     w->y_max = 0;                /* :253 */
+    for (int64_t i = 0; i < ev->n; ++i) {          /* :255-261 */
+        int32_t fx = ev->fr_x[i], fy = ev->fr_y[i];
+        if (fx > w->x_max) w->x_max = fx;
+        if (fy > w->y_max) w->y_max = fy;
+        if (fx < w->x_min) w->x_min = fx;
+        if (fy < w->y_min) w->y_min = fy;
+        ev->pr_x[i] = (double)fx;                  /* reset(), event.h:55-57 */
+        ev->pr_y[i] = (double)fy;
+        ev->nx[i] = 0.0;
+        ev->ny[i] = 0.0;
+    }
+    w->metric_wsizex = scale * (w->x_max - w->x_min);   /* :263 */
+    w->metric_wsizey = scale * (w->y_max - w->y_min);   /* :264 */
+    /* set_scale, :272-283.  (x_max - x_min) / 2 and scale / 2 are INTEGER divisions. */
+    w->scale_img_x = w->metric_wsizex + scale;
+    w->scale_img_y = w->metric_wsizey + scale;
+    w->x_shift = -(double)((w->x_max - w->x_min) / 2 + w->x_min) * (double)scale
+                 + (double)w->metric_wsizex / 2.0 + (double)(scale / 2);
+    w->y_shift = -(double)((w->y_max - w->y_min) / 2 + w->y_min) * (double)scale
+                 + (double)w->metric_wsizey / 2.0 + (double)(scale / 2);
+}
+
+/* AccelLib::project_4param_reinit (accel_lib.h:263-267) applying
+ * Event::project_4param_reinit (event.h:99-110) and Event::apply_project
+ * (event.h:164-168) to every event, noise or not. */
+void bfo_project_4param_reinit(bfo_cloud *ev, double dnx_, double dny_, double cx, double cy,
+                               double div, double crl) {
+    for (int64_t i = 0; i < ev->n; ++i) {
+        /* event.h:100  cv::Point2d r(pr_x - cx, pr_y - cy);  -- the PREVIOUS pr */
+        double rx = ev->pr_x[i] - cx;
+        double ry = ev->pr_y[i] - cy;
+        /* event.h:102-103 */
+        double qx = cos(crl) * rx - sin(crl) * ry;
+        double qy = sin(crl) * rx + cos(crl) * ry;
+        /* event.h:105  dn = - r_ * div + (r_ - r)  (unary minus, then * double, then +) */
+        double dnx = (-qx) * div + (qx - rx);
+        double dny = (-qy) * div + (qy - ry);
+        /* event.h:107-108 */
+        double nx = dnx + dnx_;
+        double ny = dny + dny_;
+        ev->nx[i] = nx;
+        ev->ny[i] = ny;
+        /* event.h:164-165  float kx = float(nx) / nz;   (nz is double 127) */
+        float kx = (float)((double)(float)nx / BFO_NZ);
+        float ky = (float)((double)(float)ny / BFO_NZ);
+        /* event.h:167-168  pr_x = float(fr_x) - kx * float(t) / 10000.0;
+         * float*float is a float product; the divide and subtract are double. */
+        float ft = (float)ev->t[i];
+        float px = kx * ft;
+        float py = ky * ft;
+        ev->pr_x[i] = (double)(float)ev->fr_x[i] - (double)px / 10000.0;
+        ev->pr_y[i] = (double)(float)ev->fr_y[i] - (double)py / 10000.0;
+    }
+}
+
+/* AccelLib::get_time_img_cpu, accel_lib.h:147-178.  Two zeroed float planes of
+ * (w+scale) x (h+scale); per non-noise event an s x s splat of t/1e9 and of 1;
+ * then avg /= cnt where cnt >= 1.  The reference returns only avg; cnt (the
+ * "event-count image") is exposed here because north_star pins it bit-exact. */
+void bfo_get_time_img(const bfo_cloud *ev, int32_t w, int32_t h, int32_t scale, int32_t x_sh,
+                      int32_t y_sh, float *time_img, float *cnt_img) {
+    const int32_t R = w + scale, C = h + scale;
+    const size_t P = (size_t)R * (size_t)C;
+    float *cnt = cnt_img ? cnt_img : (float *)malloc(P * sizeof(float));
+    memset(time_img, 0, P * sizeof(float));        /* :148 */
+    memset(cnt, 0, P * sizeof(float));             /* :149 */
+
+    for (int64_t i = 0; i < ev->n; ++i) {          /* :151 container order */
+        if (ev->noise && ev->noise[i]) continue;   /* :152 */
+        /* :154-155  int x = e.pr_x * scale + x_sh;  (double * int + int -> double -> int) */
+        int32_t x = trunc_to_int_x86(ev->pr_x[i] * (double)scale + (double)x_sh);
+        int32_t y = trunc_to_int_x86(ev->pr_y[i] * (double)scale + (double)y_sh);
+        /* :157-158 */
+        if ((x >= w + scale / 2) || (x < scale / 2) || (y >= h + scale / 2) || (y < scale / 2))
+            continue;
+        for (int32_t jx = x - scale / 2; jx <= x + scale / 2; ++jx) {       /* :160 */
+            for (int32_t jy = y - scale / 2; jy <= y + scale / 2; ++jy) {   /* :161 */
+                size_t k = (size_t)jx * (size_t)C + (size_t)jy;
+                /* :162  float += double  ==  (float)((double)avg + double(t)/1e9) */
+                time_img[k] = (float)((double)time_img[k] + (double)ev->t[i] / 1000000000.0);
+                cnt[k] = cnt[k] + 1.0f;                                     /* :163 */
+            }
+        }
+    }
+    for (int32_t jx = 0; jx < R; ++jx) {           /* :168-175 (tbb rows; disjoint) */
+        for (int32_t jy = 0; jy < C; ++jy) {
+            size_t k = (size_t)jx * (size_t)C + (size_t)jy;
+            if (cnt[k] < 1.0f) continue;
+            time_img[k] = time_img[k] / cnt[k];
+        }
+    }
+    if (!cnt_img) free(cnt);
+}
+
+/* ObjectModel::center_of_mass, object_model.cpp:103-126.  `p[j] > 0.000001`
+ * compares a float against a double literal. */
+void bfo_center_of_mass(const float *img, int32_t rows, int32_t cols, bfo_model *m) {
+    m->cx = 0; m->cy = 0; m->cnt = 0;
+    for (int32_t i = 0; i < rows; ++i) {
+        const float *p = img + (size_t)i * (size_t)cols;
+        for (int32_t j = 0; j < cols; ++j) {
+            if ((double)p[j] > 0.000001) {
+                m->cx += (double)i;
+                m->cy += (double)j;
+                m->cnt++;
+            }
+        }
+    }
+    /* assert(cnt > 0) is compiled out (-DNDEBUG); cnt == 0 gives 0/0 = NaN. */
+    m->cx /= (double)m->cnt;
+    m->cy /= (double)m->cnt;
+}
+
+/* AccelLib::sobel_point, accel_lib.h:545-615, for the pixel at (row, col).
+ * The reference calls sobel_point(img, j = col, i = row, ...) (:536) and reads
+ * img.at<float>(l + row - 1, k + col - 1) with k outer, l inner, idx = 3k + l
+ * (:594-604).  mask_* / *_norm (:548-591) are computed but never used. */
+static int sobel_point(const float *img, int32_t cols, int32_t row, int32_t col, float *dx,
+                       float *dy) {
+    static const int sharr_x[9] = {3, 0, -3, 10, 0, -10, 3, 0, -3};   /* :546 */
+    static const int sharr_y[9] = {3, 10, 3, 0, 0, 0, -3, -10, -3};   /* :547 */
+    int idx = 0;
+    float ax = 0.0f, ay = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        for (int l = 0; l < 3; ++l) {
+            float val = img[(size_t)(l + row - 1) * (size_t)cols + (size_t)(k + col - 1)];
+            if ((double)val <= 0.000001) return 0;                    /* :599 */
+            ax = ax + val * (float)sharr_x[idx];                      /* :601 */
+            ay = ay + val * (float)sharr_y[idx];                      /* :602 */
+            idx++;
+        }
+    }
+    *dx = ax;
+    *dy = ay;
+    return 1;
+}
+
+/* AccelLib::Sobel_cpu, accel_lib.h:513-543: zero planes; interior pixels with a
+ * valid centre get the gated 3x3 Scharr response. */
+void bfo_sobel(const float *img, int32_t rows, int32_t cols, float *grad_x, float *grad_y) {
+    const size_t P = (size_t)rows * (size_t)cols;
+    memset(grad_x, 0, P * sizeof(float));          /* :522 */
+    memset(grad_y, 0, P * sizeof(float));          /* :523 */
+    for (int32_t i = 1; i < rows - 1; ++i) {       /* :528 */
+        const float *p = img + (size_t)i * (size_t)cols;
+        for (int32_t j = 1; j < cols - 1; ++j) {   /* :533 */
+            if ((double)p[j] <= 0.000001) continue;   /* :534 */
+            float dx = 0, dy = 0;
+            if (sobel_point(img, cols, i, j, &dx, &dy)) {
+                grad_x[(size_t)i * (size_t)cols + (size_t)j] = dx;
+                grad_y[(size_t)i * (size_t)cols + (size_t)j] = dy;
+            }
+        }
+    }
+}
+
+/* ObjectModel::compute(cv::Mat&), object_model.cpp:4-39.  cross / ddot are
+ * cv::Point2d::cross = x*pt.y - y*pt.x and ddot = x*pt.x + y*pt.y in double. */
+void bfo_model_compute(const float *img, int32_t rows, int32_t cols, bfo_model *m,
+                       float *grad_x, float *grad_y) {
+    const size_t P = (size_t)rows * (size_t)cols;
+    float *gx = grad_x ? grad_x : (float *)malloc(P * sizeof(float));
+    float *gy = grad_y ? grad_y : (float *)malloc(P * sizeof(float));
+    bfo_sobel(img, rows, cols, gx, gy);            /* :6 */
+    m->dx = 0; m->dy = 0; m->rot = 0; m->div = 0; m->cnt = 0;   /* :8-12 */
+    for (int32_t i = 0; i < rows; ++i) {           /* :17 */
+        const float *px = gx + (size_t)i * (size_t)cols;
+        const float *py = gy + (size_t)i * (size_t)cols;
+        const float *p = img + (size_t)i * (size_t)cols;
+        for (int32_t j = 0; j < cols; ++j) {
+            if ((double)p[j] > 0.000001) {         /* :22 */
+                double rx = (double)i - m->cx;     /* :23 */
+                double ry = (double)j - m->cy;
+                double gxd = (double)px[j];        /* :24 */
+                double gyd = (double)py[j];
+                m->dx += gxd;                      /* :26 */
+                m->dy += gyd;                      /* :27 */
+                m->rot += rx * gyd - ry * gxd;     /* :28 r.cross(g) */
+                m->div += rx * gxd + ry * gyd;     /* :29 r.ddot(g)  */
+                m->cnt++;
+            }
+        }
+    }
+    m->rot /= (double)m->cnt;                      /* :35-38 */
+    m->div /= (double)m->cnt;
+    m->dx /= (double)m->cnt;
+    m->dy /= (double)m->cnt;
+    if (!grad_x) free(gx);
+    if (!grad_y) free(gy);
+}
+
+/* AccelLib::fast_model CPU branch (accel_lib.h:337-341) -> ObjectModel::update
+ * (object_model.h:31-34): center_of_mass then compute. */
+void bfo_fast_model(const float *img, int32_t rows, int32_t cols, bfo_model *m) {
+    bfo_center_of_mass(img, rows, cols, m);
+    bfo_model_compute(img, rows, cols, m, NULL, NULL);
+}
+
+/* OptimizerRolling::iteration_step, optimizer_rolling.h:305-347. */
+void bfo_iteration_step(bfo_cloud *ev, const bfo_window *w, bfo_model *m, const bfo_loop *lp,
+                        float *scratch) {
+    const int32_t R = w->scale_img_x, C = w->scale_img_y;
+    const size_t P = (size_t)R * (size_t)C;
+    float *buf = scratch ? scratch : (float *)malloc(4 * P * sizeof(float));
+    float *time_img = buf, *cnt = buf + P, *gx = buf + 2 * P, *gy = buf + 3 * P;
+
+    /* :322-324  the double shifts are passed to `int x_sh, int y_sh` parameters:
+     * implicit double -> int conversion truncates toward zero (accel_lib.h:147). */
+    bfo_get_time_img(ev, w->metric_wsizex, w->metric_wsizey, w->scale,
+                     trunc_to_int_x86(w->x_shift), trunc_to_int_x86(w->y_shift), time_img, cnt);
+    /* :327 fast_model -> update */
+    bfo_center_of_mass(time_img, R, C, m);
+    bfo_model_compute(time_img, R, C, m, gx, gy);
+    /* :328 update_accumulators(rot_divider, div_divider, x_divider, y_divider),
+     * object_model.h:48-53 (double / float -> double) */
+    m->total_rot += m->rot / (double)lp->rot_divider;
+    m->total_div += m->div / (double)lp->div_divider;
+    m->total_dx += m->dx / (double)lp->x_divider;
+    m->total_dy += m->dy / (double)lp->y_divider;
+    /* :330-331  image -> sensor coordinates with the DOUBLE shift */
+    double cx = (m->cx - w->x_shift) / (double)w->scale;
+    double cy = (m->cy - w->y_shift) / (double)w->scale;
+    /* :340-344 */
+    bfo_project_4param_reinit(ev, -m->total_dx, -m->total_dy, cx, cy, m->total_div,
+                              -m->total_rot);
+    m->cx = cx;                                    /* :345-346 */
+    m->cy = cy;
+    if (!scratch) free(buf);
+}
+
+/* OptimizerRolling::set_model, optimizer_rolling.h:289-299 (warm start, "STM"). */
+void bfo_set_model(bfo_cloud *ev, bfo_model *m, const bfo_model *last) {
+    *m = *last;
+    bfo_project_4param_reinit(ev, -m->total_dx, -m->total_dy, m->cx, m->cy, m->total_div,
+                              -m->total_rot);
+}
+
+/* OptimizerRolling::run, optimizer_rolling.h:48-125. */
+int bfo_run(bfo_cloud *ev, const bfo_window *w, bfo_model *m, int32_t max_itercount,
+            int32_t res_x, int32_t res_y, int32_t min_events, int64_t hard_iter_cap,
+            bfo_loop *loop_out, bfo_trace_rec *trace, int64_t trace_cap) {
+    bfo_loop lp;
+    lp.x_divider = lp.y_divider = 1.0f;
+    lp.rot_divider = lp.div_divider = 10000.0f;
+    lp.itercount = 0;
+    if (loop_out) *loop_out = lp;
+    /* :49-55  integer arithmetic scale * RES / 15 */
+    if ((w->scale_img_x < w->scale * res_x / 15) && (w->scale_img_y < w->scale * res_y / 15)) {
+        if (ev->noise)
+            for (int64_t i = 0; i < ev->n; ++i) ev->noise[i] = 1;
+        return 1;
+    }
+    if (ev->n < (int64_t)min_events) return 1;     /* :57-58 */
+
+    const size_t P = (size_t)w->scale_img_x * (size_t)w->scale_img_y;
+    float *scratch = (float *)malloc(4 * P * sizeof(float));
+    int rc = 0;
+
+    bfo_iteration_step(ev, w, m, &lp, scratch);    /* :73 */
+    lp.itercount++;
+    if (trace && lp.itercount <= trace_cap) {
+        trace[lp.itercount - 1].model = *m;
+        trace[lp.itercount - 1].loop = lp;
+    }
+    while (lp.x_divider < 32 * 10 || lp.y_divider < 32 * 10 || lp.rot_divider < 32 * 1000 ||
+           lp.div_divider < 32 * 1000) {           /* :76-79 */
+        /* :81-84  double / float -> double */
+        if (fabs(m->dx / (double)lp.x_divider) < 1e-5 &&
+            fabs(m->dy / (double)lp.y_divider) < 1e-5 &&
+            fabs(m->rot / (double)lp.rot_divider) < 1e-4 &&
+            fabs(m->div / (double)lp.div_divider) < 1e-1)
+            break;
+        float old_dx = (float)m->dx;               /* :86-89 */
+        float old_dy = (float)m->dy;
+        float old_rot = (float)m->rot;
+        float old_div = (float)m->div;
+
+        bfo_iteration_step(ev, w, m, &lp, scratch);   /* :91 */
+        lp.itercount++;
+        if (max_itercount > 0 && (int)lp.itercount > max_itercount) {   /* :94-96 */
+            if (trace && lp.itercount <= trace_cap) {
+                trace[lp.itercount - 1].model = *m;
+                trace[lp.itercount - 1].loop = lp;
+            }
+            break;
+        }
+        /* :98-101  double * float -> double; float dividers *= 2 */
+        if (m->dx * (double)old_dx < 0) lp.x_divider *= 2;
+        if (m->dy * (double)old_dy < 0) lp.y_divider *= 2;
+        if (m->rot * (double)old_rot < 0) lp.rot_divider *= 2;
+        if (m->div * (double)old_div < 0) lp.div_divider *= 2;
+        if (trace && lp.itercount <= trace_cap) {
+            trace[lp.itercount - 1].model = *m;
+            trace[lp.itercount - 1].loop = lp;
+        }
+        if (hard_iter_cap > 0 && lp.itercount >= hard_iter_cap) {
+            rc = -2;                               /* not in the reference: it would spin */
+            break;
+        }
+    }
+    free(scratch);
+    if (loop_out) *loop_out = lp;
+    return rc;                                     /* :124 */
+}
+
+/* Event::compute_uv, event.h:135-142.  1000000000 / (T_DIVIDER * 10000) is the
+ * INTEGER 100000 (common.h:64), nz / 100000 the double 0.00127. */
+void bfo_compute_uv(const double *nx, const double *ny, int64_t n, double *u, double *v) {
+    for (int64_t i = 0; i < n; ++i) {
+        double xy_len = hypot(nx[i], ny[i]);
+        double speed = xy_len / (BFO_NZ / (double)(1000000000 / (1 * 10000)));
+        u[i] = (xy_len == 0) ? 0 : speed * nx[i] / xy_len;
+        v[i] = (xy_len == 0) ? 0 : speed * ny[i] / xy_len;
+    }
+}

@@ -1,0 +1,128 @@
+/*
+ * bf_oracle.h -- CPU restatement of better-flow's motion-compensation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * there only as the checker / the timed CPU baseline.  The product path
+ * (better_flow_amd/) never links, imports or falls back to this code.
+ *
+ * PARITY UNPINNED.  The reference has no tests, golden vectors or fixtures
+ *  and it cannot be compiled in this image: every header on the
+ * path includes OpenCV (common.h:17-19) and accel_lib.h includes TBB (accel_lib.h:7-8);
+ * neither is installed, and building it against stand-in headers is not allowed.
+ * This file is therefore a line-by-line restatement of the reference arithmetic,
+ * each function citing the reference lines it follows, checked by review and by
+ * analytic / known-answer properties -- not by outputs of the reference itself.
+ *
+ * All paths below are relative to /root/reference/better_flow_core/ :
+ *   event.h            = include/better_flow/event.h
+ *   accel_lib.h        = include/better_flow/accel_lib.h
+ *   optimizer_rolling.h= include/better_flow/optimizer_rolling.h
+ *   object_model.h/.cpp= include/better_flow/object_model.h, src/object_model.cpp
+ *
+ * Conventions: fr_x is the ROW, fr_y the COLUMN (bf_motion_compensator.cpp:192,200
+ * swaps the file's x/y).  Images are row-major R x C float, R = wsx + scale.
+ */
+#ifndef BF_ORACLE_H
+#define BF_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Event cloud, structure-of-arrays view of the live fields of `class Event`
+ * (event.h:9-24).  All arrays have length n and are owned by the caller. */
+typedef struct {
+    int64_t n;
+    const int32_t *fr_x;   /* row    (uint fr_x, event.h:9)  */
+    const int32_t *fr_y;   /* column (uint fr_y, event.h:9)  */
+    const int64_t *t;      /* ns relative to slice start (sll t, event.h:10,61-63) */
+    uint8_t *noise;        /* bool noise (event.h:12) */
+    double *pr_x, *pr_y;   /* projected position (event.h:15) */
+    double *nx, *ny;       /* direction vector (event.h:16); nz == 127 (common.h:60) */
+} bfo_cloud;
+
+/* Window geometry computed by OptimizerRolling::set_cloud / set_scale
+ * (optimizer_rolling.h:248-283). */
+typedef struct {
+    int32_t scale;
+    int32_t x_min, y_min, x_max, y_max;
+    int32_t metric_wsizex, metric_wsizey;   /* scale * (max - min)           */
+    int32_t scale_img_x, scale_img_y;       /* R, C = metric_wsize + scale   */
+    double x_shift, y_shift;
+} bfo_window;
+
+/* ObjectModel (object_model.h:10-13). */
+typedef struct {
+    double cx, cy, dx, dy, rot, div;
+    uint32_t cnt;
+    double total_dx, total_dy, total_rot, total_div;
+} bfo_model;
+
+/* Loop state of OptimizerRolling::run (optimizer_rolling.h:36,61-63). */
+typedef struct {
+    float x_divider, y_divider, rot_divider, div_divider;
+    int64_t itercount;
+} bfo_loop;
+
+/* One record per iteration_step, for trajectory comparisons. */
+typedef struct {
+    bfo_model model;       /* after update_accumulators, cx/cy in sensor coords */
+    bfo_loop loop;         /* dividers AFTER the sign-flip update of this pass  */
+} bfo_trace_rec;
+
+void bfo_model_init(bfo_model *m);
+
+/* event.h:61-63 */
+void bfo_set_local_time(const uint64_t *timestamp, int64_t n, uint64_t t0, int64_t *t_out);
+
+/* optimizer_rolling.h:248-283 (+ Event::reset, event.h:54-59).  res_x/res_y are the
+ * compile-time RES_X/RES_Y (common.h:39-40) made runtime. */
+void bfo_set_cloud(bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, bfo_window *w);
+
+/* accel_lib.h:263-267 -> event.h:99-110,164-168 */
+void bfo_project_4param_reinit(bfo_cloud *ev, double dnx_, double dny_, double cx, double cy,
+                               double div, double crl);
+
+/* accel_lib.h:147-178.  time_img and cnt_img are (w+scale) x (h+scale) floats.
+ * cnt_img may be NULL.  x_sh / y_sh are the int-truncated shifts. */
+void bfo_get_time_img(const bfo_cloud *ev, int32_t w, int32_t h, int32_t scale, int32_t x_sh,
+                      int32_t y_sh, float *time_img, float *cnt_img);
+
+/* object_model.cpp:103-126 */
+void bfo_center_of_mass(const float *img, int32_t rows, int32_t cols, bfo_model *m);
+
+/* accel_lib.h:513-615 */
+void bfo_sobel(const float *img, int32_t rows, int32_t cols, float *grad_x, float *grad_y);
+
+/* object_model.cpp:4-39 (grad planes are scratch of size rows*cols, may be NULL) */
+void bfo_model_compute(const float *img, int32_t rows, int32_t cols, bfo_model *m,
+                       float *grad_x, float *grad_y);
+
+/* accel_lib.h:337-341 (CPU branch) -> object_model.h:31-34 */
+void bfo_fast_model(const float *img, int32_t rows, int32_t cols, bfo_model *m);
+
+/* optimizer_rolling.h:305-347 ; scratch = 4 planes of R*C floats or NULL */
+void bfo_iteration_step(bfo_cloud *ev, const bfo_window *w, bfo_model *m, const bfo_loop *lp,
+                        float *scratch);
+
+/* optimizer_rolling.h:289-299 */
+void bfo_set_model(bfo_cloud *ev, bfo_model *m, const bfo_model *last);
+
+/* optimizer_rolling.h:48-125.  Returns 0 (optimised), 1 (skipped by a guard), or
+ * -2 when hard_iter_cap (>0) was hit (the reference would spin forever, e.g. on a
+ * NaN model).  min_events is the reference's literal 1000 (:57) made runtime.
+ * trace (may be NULL) receives up to trace_cap records. */
+int bfo_run(bfo_cloud *ev, const bfo_window *w, bfo_model *m, int32_t max_itercount,
+            int32_t res_x, int32_t res_y, int32_t min_events, int64_t hard_iter_cap,
+            bfo_loop *loop_out, bfo_trace_rec *trace, int64_t trace_cap);
+
+/* event.h:135-142 */
+void bfo_compute_uv(const double *nx, const double *ny, int64_t n, double *u, double *v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

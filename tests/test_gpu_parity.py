@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bars: window / warp state / event-count image / Scharr planes bit-exact;
+time image <= 1e-6 relative (the reference's own f32 accumulation-order noise) and
+bit-exact where a single event hit the pixel; moments <= 1e-9 relative; converged
+(u, v) <= 1e-4 relative or 0.02 px/s, iteration count within +-1.
+"""
+import numpy as np
+import pytest
+
+from better_flow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = [  # dnx, dny, cx, cy, div, crl
+    (0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+    (0.35, -0.7, 0.0, 0.0, 0.0, 0.0),
+    (0.2, 0.4, 88.5, 121.25, 3.0e-4, -2.0e-4),
+    (-0.15, 0.05, 90.0, 119.0, -1.0e-3, 1.5e-3),
+]
+
+
+def small_slice(n=20000, H=180, W=240, seed=7, dur=0.05):
+    return synth.make_slice(n, H, W, dur, seed=seed)
+
+
+def make_pair(oracle_lib, accel_mod, sl, scale, split=False, noise=None):
+    H, W = sl["height"], sl["width"]
+    oc = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    if noise is not None:
+        oc.noise[:] = noise
+    ow = oc.set_cloud(scale, H, W)
+    acc = accel_mod.Accel(max_events=max(len(sl["t"]), 1024), max_rows=scale * H + scale,
+                          max_cols=scale * W + scale)
+    acc.set_option("force_split", 1 if split else 0)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"], noise)
+    gw = acc.set_cloud(scale, H, W)
+    return oc, ow, acc, gw
+
+
+@pytest.mark.parametrize("scale", [1, 3, 5])
+def test_window_matches(oracle_lib, accel_mod, scale):
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, scale)
+    for k in ("scale", "x_min", "y_min", "x_max", "y_max", "metric_wsizex", "metric_wsizey",
+              "scale_img_x", "scale_img_y", "x_shift", "y_shift"):
+        assert getattr(ow, k) == getattr(gw, k), k
+    acc.close()
+
+
+def test_warp_state_bit_exact(oracle_lib, accel_mod):
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+    pr_x, pr_y, nx, ny = acc.writeout_events()     # after reset: pr == fr, n == 0
+    assert np.array_equal(pr_x, oc.pr_x) and np.array_equal(pr_y, oc.pr_y)
+    assert not nx.any() and not ny.any()
+    for prm in PARAMS:                              # chained: each warp reads the previous pr
+        oc.project_4param_reinit(*prm)
+        acc.project_4param_reinit(*prm)
+        pr_x, pr_y, nx, ny = acc.writeout_events()
+        assert np.array_equal(pr_x, oc.pr_x)
+        assert np.array_equal(pr_y, oc.pr_y)
+        assert np.array_equal(nx, oc.nx)
+        assert np.array_equal(ny, oc.ny)
+    u, v = acc.compute_uv()
+    ou, ov = oc.compute_uv()
+    np.testing.assert_allclose(u, ou, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(v, ov, rtol=1e-14, atol=0)
+    acc.close()
+
+
+@pytest.mark.parametrize("scale,split", [(1, False), (3, False), (3, True), (5, False)])
+def test_count_and_time_image(oracle_lib, accel_mod, scale, split):
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, scale, split=split)
+    for prm in PARAMS:
+        oc.project_4param_reinit(*prm)
+        acc.project_4param_reinit(*prm)
+        otime, ocnt = oc.get_time_img(ow)
+        gtime, gcnt = acc.get_time_img()
+        assert np.array_equal(gcnt, ocnt.astype(np.uint32)), "event-count image must be bit-exact"
+        assert gcnt.sum() > 0
+        one = ocnt == 1.0
+        assert np.array_equal(gtime[one], otime[one]), "single-event pixels must be bit-exact"
+        np.testing.assert_allclose(gtime, otime, rtol=1e-6, atol=0)
+    acc.close()
+
+
+def test_time_image_idempotent_and_deterministic(oracle_lib, accel_mod):
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+    acc.project_4param_reinit(*PARAMS[2])
+    t1, c1 = acc.get_time_img()
+    t2, c2 = acc.get_time_img()
+    assert np.array_equal(t1, t2) and np.array_equal(c1, c2)
+    acc.close()
+
+
+def test_noise_mask(oracle_lib, accel_mod):
+    sl = small_slice()
+    noise = (np.arange(len(sl["t"])) % 3 == 0).astype(np.uint8)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3, noise=noise)
+    oc.project_4param_reinit(*PARAMS[1])
+    acc.project_4param_reinit(*PARAMS[1])
+    otime, ocnt = oc.get_time_img(ow)
+    gtime, gcnt = acc.get_time_img()
+    assert np.array_equal(gcnt, ocnt.astype(np.uint32))
+    np.testing.assert_allclose(gtime, otime, rtol=1e-6, atol=0)
+    acc.close()
+
+
+def test_sobel_bit_exact(oracle_lib, accel_mod):
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+    oc.project_4param_reinit(*PARAMS[1])
+    otime, _ = oc.get_time_img(ow)
+    rng = np.random.default_rng(3)
+    dense = rng.uniform(2e-6, 0.05, size=(97, 211)).astype(np.float32)
+    holes = dense.copy()
+    holes[rng.uniform(size=holes.shape) < 0.1] = 0.0
+    holes[5, 5] = 1e-6            # exactly on the validity threshold (invalid: not > 1e-6)
+    holes[6, 9] = np.float32(1.0000001e-6)
+    for img in (otime, dense, holes, np.zeros((3, 3), np.float32), dense[:2, :5], dense[:1, :1]):
+        ogx, ogy = oracle_lib.sobel(img)
+        ggx, ggy = acc.sobel(img)
+        assert np.array_equal(ggx, ogx)
+        assert np.array_equal(ggy, ogy)
+    acc.close()
+
+
+def test_fast_model(oracle_lib, accel_mod):
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+    oc.project_4param_reinit(*PARAMS[2])
+    acc.project_4param_reinit(*PARAMS[2])
+    otime, _ = oc.get_time_img(ow)
+    acc.get_time_img()
+    om = oracle_lib.fast_model(otime)
+    for gm in (acc.fast_model(otime), acc.fast_model()):   # host image, then the resident one
+        assert gm.cnt == om.cnt
+        assert gm.cx == om.cx and gm.cy == om.cy           # integer sums: exact
+        for k in ("dx", "dy", "rot", "div"):
+            a, b = getattr(gm, k), getattr(om, k)
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-12) + 1e-15, (k, a, b)
+    acc.close()
+
+
+def _flow_close(u, ou):
+    tol = np.maximum(1e-4 * np.abs(ou), 0.02)
+    return np.all(np.abs(u - ou) <= tol)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_run_cold_200k(oracle_lib, accel_mod, split):
+    H, W = 260, 346
+    sl = synth.make_slice(200000, H, W, 0.030, seed=1)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3, split=split)
+    om = oracle_lib.Model()
+    orc, oloop, otrace = oc.run(ow, om, res_x=H, res_y=W, trace_cap=64)
+    opts = acc.default_opts()
+    opts.res_x, opts.res_y, opts.trace_cap = H, W, 64
+    grc, gm, info = acc.run(opts)
+    assert grc == orc == 0
+    assert abs(info.iterations - oloop.itercount) <= 1, (info.iterations, oloop.itercount)
+    gtrace = acc.get_trace(64)
+    # first iterations: same trajectory to rounding (only the time image differs, by 1e-7)
+    for k in range(min(16, len(gtrace), len(otrace))):
+        g, o = gtrace[k].model, otrace[k].model
+        assert g.cnt == o.cnt, k
+        for f in ("dx", "dy", "total_dx", "total_dy"):
+            assert abs(getattr(g, f) - getattr(o, f)) <= 2e-5 * max(abs(getattr(o, f)), 1e-3), (k, f)
+    u, v = acc.compute_uv()
+    ou, ov = oc.compute_uv()
+    assert _flow_close(u, ou) and _flow_close(v, ov)
+    # known answer: the injected flow is recovered
+    vr, vc = sl["velocity"]
+    assert abs(u.mean() - vr) < 0.01 * abs(vr) and abs(v.mean() - vc) < 0.01 * abs(vc)
+    # a second run on the same ctx / slice is bit-identical (deterministic integer scatter)
+    acc.set_cloud(3, H, W)
+    grc2, gm2, info2 = acc.run(opts)
+    assert info2.iterations == info.iterations
+    assert gm2.as_dict() == gm.as_dict()
+    acc.close()
+
+
+def test_run_warm_start(oracle_lib, accel_mod):
+    H, W = 260, 346
+    a = synth.make_slice(100000, H, W, 0.030, seed=11)
+    b = synth.make_slice(100000, H, W, 0.030, seed=12)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, a, 3)
+    om = oracle_lib.Model()
+    oc.run(ow, om, res_x=H, res_y=W)
+    opts = acc.default_opts()
+    opts.res_x, opts.res_y = H, W
+    _, gm, info_a = acc.run(opts)
+    # slice b warm-started from slice a's model ("STM", dvs_flow.h:218-219)
+    oc2 = oracle_lib.Cloud(b["fr_x"], b["fr_y"], b["t"])
+    ow2 = oc2.set_cloud(3, H, W)
+    om2 = oc2.set_model(om)
+    orc, oloop, _ = oc2.run(ow2, om2, res_x=H, res_y=W)
+    acc.upload_events(b["fr_x"], b["fr_y"], b["t"])
+    acc.set_cloud(3, H, W)
+    acc.set_model(gm)
+    grc, gm2, info_b = acc.run(opts)
+    assert grc == orc == 0
+    assert abs(info_b.iterations - oloop.itercount) <= 1
+    assert info_b.iterations < info_a.iterations        # warm start converges faster
+    u, v = acc.compute_uv()
+    ou, ov = oc2.compute_uv()
+    assert _flow_close(u, ou) and _flow_close(v, ov)
+    acc.close()
+
+
+def test_run_max_iter(oracle_lib, accel_mod):
+    H, W = 180, 240
+    sl = small_slice(30000, H, W, seed=5)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+    om = oracle_lib.Model()
+    orc, oloop, _ = oc.run(ow, om, max_iter=10, res_x=H, res_y=W)
+    opts = acc.default_opts()
+    opts.max_iter = 10
+    grc, gm, info = acc.run(opts)
+    assert info.iterations == oloop.itercount == 11      # "itercount > max" breaks after 11 steps
+    for f in ("total_dx", "total_dy", "total_rot", "total_div"):
+        assert abs(getattr(gm, f) - getattr(om, f)) <= 1e-5 * max(abs(getattr(om, f)), 1e-6), f
+    acc.close()
+
+
+def test_guards_and_edges(oracle_lib, accel_mod):
+    H, W = 180, 240
+    # fewer than 1000 events: run() returns 1 (optimizer_rolling.h:57-58)
+    sl = small_slice(600, H, W, seed=9)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+    om = oracle_lib.Model()
+    assert oc.run(ow, om, res_x=H, res_y=W)[0] == 1
+    rc, gm, info = acc.run()
+    assert rc == accel_mod.BF_SKIPPED and info.iterations == 0
+    u, v = acc.compute_uv()
+    assert not u.any() and not v.any()
+    # window too small: every event becomes noise (optimizer_rolling.h:49-55)
+    tiny = {"fr_x": np.full(2000, 50, np.int32) + (np.arange(2000) % 3).astype(np.int32),
+            "fr_y": np.full(2000, 60, np.int32) + (np.arange(2000) % 4).astype(np.int32),
+            "t": np.arange(2000, dtype=np.int64) * 1000, "height": H, "width": W}
+    acc.upload_events(tiny["fr_x"], tiny["fr_y"], tiny["t"])
+    acc.set_cloud(3, H, W)
+    rc, _, _ = acc.run()
+    assert rc == accel_mod.BF_SKIPPED
+    _, cnt = acc.get_time_img()
+    assert cnt.sum() == 0
+    # empty slice
+    acc.upload_events(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    w = acc.set_cloud(3, H, W)
+    assert (w.x_min, w.x_max, w.y_min, w.y_max) == (H, 0, W, 0)
+    acc.close()
+    # capacity errors are reported, not ignored
+    small = accel_mod.Accel(max_events=1024, max_rows=64, max_cols=64)
+    with pytest.raises(accel_mod.BfError):
+        small.upload_events(np.zeros(5000, np.int32), np.zeros(5000, np.int32), np.zeros(5000, np.int32))
+    small.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    with pytest.raises(accel_mod.BfError):
+        small.set_cloud(3, H, W)
+    small.close()

@@ -80,11 +80,11 @@ class Profile(C.Structure):
 # every symbol include/bf_accel.h declares
 EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
-    "bf_run_opts_default", "bf_set_option", "bf_upload_events", "bf_upload_events_device",
+    "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_upload_events", "bf_upload_events_device",
     "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
     "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
-    "bf_copy_bandwidth",
+    "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
 ]
 
 _lib = None
@@ -133,6 +133,9 @@ def load():
         L.bf_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
         L.bf_run_opts_default.argtypes = [C.POINTER(RunOpts)]
         L.bf_device_count.argtypes = [C.POINTER(C.c_int32)]
+        L.bf_device_malloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.bf_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.bf_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -270,6 +273,18 @@ class Accel:
 
     def synchronize(self):
         self._chk(self.L.bf_synchronize(self.h))
+
+    def to_device(self, arr):
+        """Copy a numpy array into a fresh device buffer; returns the device pointer."""
+        arr = np.ascontiguousarray(arr)
+        d = C.c_void_p()
+        self._chk(self.L.bf_device_malloc(self.h, max(arr.nbytes, 16), C.byref(d)))
+        if arr.nbytes:
+            self._chk(self.L.bf_memcpy_h2d(self.h, d, _ptr(arr), arr.nbytes))
+        return d
+
+    def device_free(self, d):
+        self._chk(self.L.bf_device_free(self.h, d))
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=5):
         g = C.c_double(0)

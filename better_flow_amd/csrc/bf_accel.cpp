@@ -259,6 +259,14 @@ int bf_device_count(int32_t* count) {
     return (e == hipSuccess && n > 0) ? BF_OK : BF_ERR_NODEVICE;
 }
 
+int bf_abi_struct_sizes(int32_t* out, int32_t n) {
+    const int32_t sz[6] = {(int32_t)sizeof(bf_model),    (int32_t)sizeof(bf_window),
+                           (int32_t)sizeof(bf_run_opts), (int32_t)sizeof(bf_run_info),
+                           (int32_t)sizeof(bf_trace_rec), (int32_t)sizeof(bf_profile)};
+    for (int i = 0; out && i < n && i < 6; ++i) out[i] = sz[i];
+    return 6;
+}
+
 void bf_run_opts_default(bf_run_opts* o) {
     if (!o) return;
     o->max_iter = -1;       // OptimizerRolling(): max_itercount(-1)
@@ -848,6 +856,29 @@ int bf_get_trace(bf_ctx* c, bf_trace_rec* out, int32_t cap, int32_t* written) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (written) *written = n;
+    return BF_OK;
+}
+
+// ---- raw device buffers -----------------------------------------------------------------------
+
+int bf_device_malloc(bf_ctx* c, int64_t bytes, void** out) {
+    if (!c || !out || bytes <= 0) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(out, (size_t)bytes));
+    return BF_OK;
+}
+
+int bf_device_free(bf_ctx* c, void* ptr) {
+    if (!c) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (ptr) HIP_TRY(c, hipFree(ptr));
+    return BF_OK;
+}
+
+int bf_memcpy_h2d(bf_ctx* c, void* dst, const void* src, int64_t bytes) {
+    if (!c || !dst || !src || bytes < 0) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
     return BF_OK;
 }
 

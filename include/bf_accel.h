@@ -122,6 +122,11 @@ const char *bf_version(void);
 
 void bf_run_opts_default(bf_run_opts *opts);
 
+/* sizeof() of bf_model, bf_window, bf_run_opts, bf_run_info, bf_trace_rec, bf_profile (in
+ * that order) as this library was compiled -- lets a foreign-language binding verify its
+ * struct layouts.  Writes min(n, 6) entries; returns 6. */
+int bf_abi_struct_sizes(int32_t *out, int32_t n);
+
 /* Tuning / test knobs that have no counterpart in the reference.  Keys:
  *   "force_split"  1: keep the event-count and time-sum accumulators in separate planes
  *                  even when they fit one packed 64-bit word (takes effect at the next
@@ -194,6 +199,14 @@ int bf_run(bf_ctx *ctx, const bf_run_opts *opts, bf_model *model_out, bf_run_inf
 
 /* Records of the last bf_run (opts->trace_cap > 0).  Returns the number written. */
 int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
+
+/* ---- raw device buffers ----------------------------------------------------------- */
+
+/* For callers that keep slices resident in HBM (bench.py, the streaming front end) and
+ * hand them over with bf_upload_events_device.  bf_memcpy_h2d is synchronous. */
+int bf_device_malloc(bf_ctx *ctx, int64_t bytes, void **out);
+int bf_device_free(bf_ctx *ctx, void *ptr);
+int bf_memcpy_h2d(bf_ctx *ctx, void *dst, const void *src, int64_t bytes);
 
 /* ---- measurement ---------------------------------------------------------------- */
 

@@ -1,0 +1,189 @@
+"""CPU tests of the oracle (oracle/bf_oracle.c): cross-check against an independent numpy
+restatement, analytic known answers, and the committed golden vectors.
+
+The reference itself cannot be built here (OpenCV + TBB missing) and has no tests, so
+these pins are the oracle's own -- "parity unpinned" (oracle/bf_oracle.h)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import np_ref
+from better_flow_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+PARAMS = [
+    (0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+    (0.35, -0.7, 0.0, 0.0, 0.0, 0.0),
+    (0.2, 0.4, 20.5, 31.25, 3.0e-4, -2.0e-4),
+    (-0.15, 0.05, 22.0, 29.0, -1.0e-3, 1.5e-3),
+]
+
+
+def tiny_slice(n=1500, H=48, W=64, seed=4):
+    return synth.make_slice(n, H, W, 0.04, seed=seed, velocity=(-120.0, 260.0))
+
+
+def test_window_hand_computed(oracle_lib):
+    # rows 10..20, cols 5..8, scale 3: wsx = 30, wsy = 9, R = 33, C = 12
+    c = oracle_lib.Cloud([10, 20, 15], [5, 8, 6], [0, 1, 2])
+    w = c.set_cloud(3, 180, 240)
+    assert (w.x_min, w.x_max, w.y_min, w.y_max) == (10, 20, 5, 8)
+    assert (w.metric_wsizex, w.metric_wsizey, w.scale_img_x, w.scale_img_y) == (30, 9, 33, 12)
+    # x_shift = -((20-10)/2 + 10)*3 + 30/2 + 1 = -45 + 15 + 1 ; y: -((3)/2 + 5)*3 + 4.5 + 1
+    assert w.x_shift == -29.0 and w.y_shift == -12.5
+    assert np.array_equal(c.pr_x, [10.0, 20.0, 15.0]) and not c.nx.any()
+    # empty cloud: min stays at RES, max at 0 (optimizer_rolling.h:252-253)
+    e = oracle_lib.Cloud([], [], [])
+    we = e.set_cloud(3, 180, 240)
+    assert (we.x_min, we.x_max, we.y_min, we.y_max) == (180, 0, 240, 0)
+
+
+def test_set_local_time(oracle_lib):
+    ts = np.array([100, 50, 75, 2**40], dtype=np.uint64)
+    assert list(oracle_lib.set_local_time(ts, 75)) == [25, -25, 0, 2**40 - 75]
+
+
+@pytest.mark.parametrize("scale", [1, 3, 5])
+def test_oracle_matches_numpy_restatement(oracle_lib, scale):
+    sl = tiny_slice()
+    H, W = sl["height"], sl["width"]
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    w = c.set_cloud(scale, H, W)
+    nw = np_ref.window(sl["fr_x"], sl["fr_y"], scale, H, W)
+    assert (w.x_min, w.x_max, w.y_min, w.y_max) == (nw["x_min"], nw["x_max"], nw["y_min"], nw["y_max"])
+    assert (w.scale_img_x, w.scale_img_y, w.x_shift, w.y_shift) == (nw["R"], nw["C"], nw["x_shift"], nw["y_shift"])
+    pr_x, pr_y = c.pr_x.copy(), c.pr_y.copy()
+    for prm in PARAMS:
+        c.project_4param_reinit(*prm)
+        pr_x, pr_y, nx, ny = np_ref.warp(sl["fr_x"], sl["fr_y"], sl["t"], pr_x, pr_y, *prm)
+        assert np.array_equal(pr_x, c.pr_x) and np.array_equal(pr_y, c.pr_y)
+        assert np.array_equal(nx, c.nx) and np.array_equal(ny, c.ny)
+        timg, cimg = c.get_time_img(w)
+        ntime, ncnt = np_ref.time_img(pr_x, pr_y, sl["t"], nw, scale)
+        assert np.array_equal(cimg, ncnt) and np.array_equal(timg, ntime)
+    gx, gy = oracle_lib.sobel(timg)
+    ngx, ngy = np_ref.scharr(timg)
+    assert np.array_equal(gx, ngx) and np.array_equal(gy, ngy)
+    m = oracle_lib.fast_model(timg)
+    nm = np_ref.model(timg)
+    assert m.cnt == nm["cnt"] and m.cx == nm["cx"] and m.cy == nm["cy"]
+    for k in ("dx", "dy", "rot", "div"):
+        assert getattr(m, k) == nm[k], k
+
+
+def test_warp_analytic(oracle_lib):
+    """Pure translation: pr = fr - (n/127) * t / 1e4 and flow u = n * 1e5 / 127 px/s."""
+    c = oracle_lib.Cloud([100, 50], [30, 200], [10_000_000, 20_000_000])
+    c.set_cloud(3, 180, 240)
+    c.project_4param_reinit(1.27, -2.54, 0, 0, 0, 0)
+    np.testing.assert_allclose(c.pr_x, [100 - 0.01 * 1000, 50 - 0.01 * 2000], rtol=1e-6)
+    np.testing.assert_allclose(c.pr_y, [30 + 0.02 * 1000, 200 + 0.02 * 2000], rtol=1e-6)
+    u, v = c.compute_uv()
+    np.testing.assert_allclose(u, 1000.0, rtol=1e-12)
+    np.testing.assert_allclose(v, -2000.0, rtol=1e-12)
+    # zero parameters are the identity on the reset state
+    c.set_cloud(3, 180, 240)
+    c.project_4param_reinit(0, 0, 0, 0, 0, 0)
+    assert np.array_equal(c.pr_x, [100.0, 50.0]) and not c.nx.any()
+
+
+def test_count_image_properties(oracle_lib):
+    sl = tiny_slice(3000)
+    H, W = sl["height"], sl["width"]
+    for scale in (1, 3):
+        c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+        w = c.set_cloud(scale, H, W)
+        timg, cimg = c.get_time_img(w)
+        # zero warp: an event is kept iff hs <= fr*s + (int)shift < wsize + hs (accel_lib.h:154-158)
+        hs = scale // 2
+        X = sl["fr_x"] * scale + int(w.x_shift)
+        Y = sl["fr_y"] * scale + int(w.y_shift)
+        keep = (X >= hs) & (X < w.metric_wsizex + hs) & (Y >= hs) & (Y < w.metric_wsizey + hs)
+        assert 0.9 * len(X) < keep.sum() < len(X)      # the bbox-max row / column is always lost
+        assert not keep[(sl["fr_x"] == w.x_max) | (sl["fr_y"] == w.y_max)].any()
+        assert cimg.sum() == keep.sum() * scale * scale
+        assert np.all(cimg == np.round(cimg))
+        assert timg.max() <= sl["t"].max() / 1e9 * (1 + 1e-6) and timg.min() >= 0
+        # noise events are skipped (accel_lib.h:152)
+        c.noise[::2] = 1
+        _, chalf = c.get_time_img(w)
+        assert chalf.sum() == keep[1::2].sum() * scale * scale
+
+
+def test_scharr_orientation_and_gating(oracle_lib):
+    # time increasing along rows: grad_x = -(d/d row) * 32 * pitch, grad_y = 0
+    i = np.arange(12, dtype=np.float32)[:, None]
+    img = (0.001 + 0.0005 * i) * np.ones((1, 9), np.float32)
+    gx, gy = oracle_lib.sobel(img)
+    np.testing.assert_allclose(gx[1:-1, 1:-1], -2 * 0.0005 * 16, rtol=1e-4)
+    assert np.all(np.abs(gy[1:-1, 1:-1]) < 1e-8)
+    assert not gx[0].any() and not gx[-1].any() and not gx[:, 0].any() and not gx[:, -1].any()
+    # one invalid tap gates all nine neighbours' gradients to zero
+    img2 = img.copy()
+    img2[5, 4] = 0.0
+    gx2, _ = oracle_lib.sobel(img2)
+    assert not gx2[4:7, 3:6].any() and gx2[3, 4] != 0
+
+
+def test_known_answer_flow_recovery(oracle_lib):
+    H, W = 180, 240
+    sl = synth.make_slice(20000, H, W, 0.05, seed=3)
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    w = c.set_cloud(3, H, W)
+    m = oracle_lib.Model()
+    rc, loop, _ = c.run(w, m)
+    assert rc == 0 and 10 < loop.itercount < 2000
+    u, v = c.compute_uv()
+    vr, vc = sl["velocity"]
+    assert abs(u.mean() - vr) < 0.02 * abs(vr) and abs(v.mean() - vc) < 0.02 * abs(vc)
+
+
+def test_guards(oracle_lib):
+    sl = tiny_slice(600)
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    w = c.set_cloud(3, 48, 64)
+    assert c.run(w, oracle_lib.Model(), res_x=48, res_y=64)[0] == 1       # < 1000 events
+    sl = tiny_slice(2000)
+    c = oracle_lib.Cloud(sl["fr_x"] % 3 + 20, sl["fr_y"] % 4 + 20, sl["t"])
+    w = c.set_cloud(3, 180, 240)
+    assert c.run(w, oracle_lib.Model())[0] == 1 and c.noise.all()           # window too small
+
+
+def test_max_iter_semantics(oracle_lib):
+    sl = synth.make_slice(5000, 90, 120, 0.05, seed=8)
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    w = c.set_cloud(3, 90, 120)
+    rc, loop, tr = c.run(w, oracle_lib.Model(), max_iter=10, res_x=90, res_y=120, trace_cap=32)
+    assert rc == 0 and loop.itercount == 11 and len(tr) == 11   # breaks when itercount > max
+
+
+def test_golden_vectors(oracle_lib):
+    """Committed vectors (tests/golden/make_golden.py): the oracle must keep reproducing them."""
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))
+    z = np.load(os.path.join(GOLD, man["file"]))
+    H, W, s = man["height"], man["width"], man["scale"]
+    c = oracle_lib.Cloud(z["fr_x"], z["fr_y"], z["t"])
+    w = c.set_cloud(s, H, W)
+    assert [w.x_min, w.x_max, w.y_min, w.y_max, w.scale_img_x, w.scale_img_y] == man["window"]
+    for k, prm in enumerate(man["warps"]):
+        c.project_4param_reinit(*prm)
+        timg, cimg = c.get_time_img(w)
+        assert np.array_equal(c.pr_x, z["pr_x_%d" % k]) and np.array_equal(c.nx, z["nx_%d" % k])
+        assert np.array_equal(cimg.astype(np.uint16), z["cnt_%d" % k])
+        assert np.array_equal(timg, z["time_%d" % k])
+    gx, gy = oracle_lib.sobel(timg)
+    assert np.array_equal(gx, z["gx"]) and np.array_equal(gy, z["gy"])
+    m = oracle_lib.fast_model(timg)
+    assert [m.cx, m.cy, m.dx, m.dy, m.rot, m.div, m.cnt] == man["model"]
+    c2 = oracle_lib.Cloud(z["fr_x"], z["fr_y"], z["t"])
+    w2 = c2.set_cloud(s, H, W)
+    m2 = oracle_lib.Model()
+    rc, loop, tr = c2.run(w2, m2, res_x=H, res_y=W, trace_cap=4096)
+    assert loop.itercount == man["iterations"]
+    got = np.array([[r.model.total_dx, r.model.total_dy, r.model.total_rot, r.model.total_div,
+                     r.loop.x_divider, r.loop.y_divider, r.loop.rot_divider, r.loop.div_divider]
+                    for r in tr])
+    assert np.array_equal(got, z["trajectory"])

@@ -55,6 +55,7 @@ class RunInfo(C.Structure):
         ("x_divider", C.c_float), ("y_divider", C.c_float),
         ("rot_divider", C.c_float), ("div_divider", C.c_float),
         ("launches", C.c_int32), ("polls", C.c_int32),
+        ("rebins", C.c_int32), ("overflow_events", C.c_int32),
     ]
 
 

@@ -39,10 +39,26 @@ struct bf_ctx {
     size_t cap_px = 0;
     int cap_blocks = 0;
 
-    uint32_t* d_xy = nullptr;
-    int32_t* d_t = nullptr;
-    float2* d_p = nullptr;
+    // two event sets: the tile-binned mode ping-pongs between them on every re-bin
+    struct EvSet { uint32_t* xy = nullptr; int32_t* t = nullptr; float2* p = nullptr; uint32_t* perm = nullptr; };
+    EvSet set[2];
+    int cs = 0;                      // set holding the live events
+    bool has_perm = false;           // set[cs] is permuted; perm[] gives the upload index
     uint8_t* d_noise = nullptr;
+    // tile-binned scatter
+    bool opt_binned = true;
+    bool opt_bin_predict = true;
+    int opt_bin_tile = 32, opt_bin_margin = 8, opt_bin_threads = 256;
+    bool use_binned = false;         // decided per slice in bf_set_cloud
+    BinGrid grid;
+    uint16_t* d_binid = nullptr;
+    uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
+    unsigned long long* d_hist_ts = nullptr;
+    uint32_t* d_armed = nullptr;
+    unsigned long long* d_slabs = nullptr;
+    int bins_alloc = 0;
+    size_t slabs_alloc = 0;
+    bool bin_setup_done = false;
     int32_t *d_in_x = nullptr, *d_in_y = nullptr, *d_in_t = nullptr;
     double2 *d_nxny = nullptr, *d_uv = nullptr;
     unsigned long long* d_plane[2] = {nullptr, nullptr};
@@ -50,13 +66,15 @@ struct bf_ctx {
     float *d_time = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_img = nullptr;
     uint32_t* d_count = nullptr;
     Partial* d_partials = nullptr;
+    unsigned int* d_ticket = nullptr;
     DevState* d_state = nullptr;
     SliceStats* d_stats = nullptr;
     bf_trace_rec* d_trace = nullptr;
     int trace_alloc = 0;
     int trace_valid = 0;
 
-    DevState* h_state = nullptr;     // pinned, D2H target only
+    DevState* h_state = nullptr;     // pinned, D2H target only: 2 slots (pipelined polling)
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
     SliceStats* h_stats = nullptr;   // pinned, D2H target only
 
     DevState hst;                    // authoritative host mirror outside bf_run
@@ -167,9 +185,11 @@ WarpParams identity_warp() {
 
 WarpScatterArgs ws_args(bf_ctx* c, int buf, int check_done) {
     WarpScatterArgs a;
-    a.xy = c->d_xy; a.t = c->d_t; a.p = c->d_p;
+    const bf_ctx::EvSet& e = c->set[c->cs];
+    a.xy = e.xy; a.t = e.t; a.p = e.p;
     a.noise = c->has_noise ? c->d_noise : nullptr;
     a.nxny = c->d_nxny;
+    a.perm = c->has_perm ? e.perm : nullptr;
     a.plane = c->d_plane[buf];
     a.cplane = c->d_cplane[buf];
     a.st = c->d_state;
@@ -186,14 +206,20 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.check_done = check_done;
     a.R = c->win.scale_img_x; a.C = c->win.scale_img_y;
     a.scale = c->win.scale;
-    a.tbits = c->hst.tbits;
-    a.tmin = c->hst.tmin;
+    a.tbits = c->hst.hot.tbits;
+    a.tmin = c->hst.hot.tmin;
     a.plane = c->d_plane[buf];
     a.cplane = c->d_cplane[buf];
     a.zero_plane = c->d_plane[buf ^ 1];
-    a.zero_cplane = c->packed ? nullptr : c->d_cplane[buf ^ 1];
+    a.zero_cplane = (c->packed && !c->use_binned) ? nullptr : c->d_cplane[buf ^ 1];
+    a.slabs = c->d_slabs;
+    a.g = c->grid;
+    a.cur = buf;
     return a;
 }
+
+// which k_stencil instantiation reads the scatter result of the current mode
+int stencil_src(const bf_ctx* c, bool binned_pass) { return binned_pass ? 3 : (c->packed ? 0 : 1); }
 
 int ensure_cplanes(bf_ctx* c) {
     if (c->d_cplane[0]) return BF_OK;
@@ -212,6 +238,63 @@ int clear_planes(bf_ctx* c) {
     }
     c->planes_unknown = false;
     c->cur = 0;
+    c->hst.hot.ovf_cnt[0] = c->hst.hot.ovf_cnt[1] = 0;
+    return BF_OK;
+}
+
+int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
+    if (!c->bin_setup_done) {
+        if (bin_kernel_setup() != 0) return fail(c, BF_ERR_HIP, "cannot raise the dynamic LDS limit");
+        c->bin_setup_done = true;
+    }
+    if (!c->d_binid) {
+        HIP_TRY(c, hipMalloc(&c->d_binid, (size_t)c->cap_events * sizeof(uint16_t)));
+        HIP_TRY(c, hipMalloc(&c->d_armed, 64));
+        HIP_TRY(c, hipMemsetAsync(c->d_armed, 0, 64, c->stream));
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(c, hipMalloc(&c->set[i].perm, (size_t)c->cap_events * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[1].xy, (size_t)c->cap_events * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[1].t, (size_t)c->cap_events * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[1].p, (size_t)c->cap_events * sizeof(float2)));
+    }
+    if (g.nbins > c->bins_alloc) {
+        void* old[] = {c->d_hist_cnt, c->d_hist_ts, c->d_bin_start, c->d_cursor};
+        for (void* o : old) if (o) HIP_TRY(c, hipFree(o));
+        c->d_hist_cnt = nullptr; c->d_hist_ts = nullptr; c->d_bin_start = nullptr; c->d_cursor = nullptr;
+        const size_t nb = (size_t)g.nbins + 1;
+        HIP_TRY(c, hipMalloc(&c->d_hist_cnt, nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_hist_ts, nb * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_bin_start, nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_cursor, nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->d_hist_cnt, 0, nb * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_hist_ts, 0, nb * sizeof(unsigned long long), c->stream));
+        c->bins_alloc = g.nbins;
+    }
+    const size_t need = (size_t)g.nbins * (size_t)g.L * (size_t)g.L;
+    if (need > c->slabs_alloc) {
+        if (c->d_slabs) HIP_TRY(c, hipFree(c->d_slabs));
+        c->d_slabs = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_slabs, need * sizeof(unsigned long long)));
+        c->slabs_alloc = need;
+    }
+    return BF_OK;
+}
+
+EvSets ev_sets(const bf_ctx* c) {
+    EvSets e;
+    for (int i = 0; i < 2; ++i) {
+        e.s[i].xy = c->set[i].xy; e.s[i].t = c->set[i].t; e.s[i].p = c->set[i].p; e.s[i].perm = c->set[i].perm;
+    }
+    return e;
+}
+
+// Device-conditional counting sort of the live events by the image tile of their current
+// target (runs only when hot.need_rebin is set); no host synchronisation.
+int enqueue_rebin(bf_ctx* c, bool has_perm_at_start) {
+    ProfScope ps(c, 3);
+    launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, c->d_state, c->grid, c->d_binid, c->d_hist_cnt,
+                 c->d_hist_ts, c->d_bin_start, c->d_cursor, c->d_armed, c->stream);
+    HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
 
@@ -309,9 +392,9 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         // a window with the same pixel count but another aspect ratio can need more tiles
         c->cap_blocks = gx * gy * 2 + 64;
         const size_t ne = (size_t)c->cap_events;
-        HIP_TRY(c, hipMalloc(&c->d_xy, ne * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_t, ne * sizeof(int32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_p, ne * sizeof(float2)));
+        HIP_TRY(c, hipMalloc(&c->set[0].xy, ne * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[0].t, ne * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[0].p, ne * sizeof(float2)));
         HIP_TRY(c, hipMalloc(&c->d_noise, ne));
         HIP_TRY(c, hipMalloc(&c->d_in_x, ne * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->d_in_y, ne * sizeof(int32_t)));
@@ -327,9 +410,12 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMalloc(&c->d_count, c->cap_px * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_partials, (size_t)c->cap_blocks * sizeof(Partial)));
         HIP_TRY(c, hipMalloc(&c->d_state, sizeof(DevState)));
-        HIP_TRY(c, hipMalloc(&c->d_stats, sizeof(SliceStats)));
-        HIP_TRY(c, hipHostMalloc(&c->h_state, sizeof(DevState), hipHostMallocDefault));
-        HIP_TRY(c, hipHostMalloc(&c->h_stats, sizeof(SliceStats), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc(&c->d_ticket, 16 * 64 * sizeof(unsigned int)));   // 1 + 32 counters, 64 B apart
+        HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, 16 * 64 * sizeof(unsigned int), c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_stats, kPrepBlocks * sizeof(SliceStats)));
+        HIP_TRY(c, hipHostMalloc(&c->h_state, 2 * sizeof(DevState), hipHostMallocDefault));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
         int r = clear_planes(c);
         if (r != BF_OK) return r;
@@ -351,9 +437,12 @@ void bf_destroy(bf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    void* bufs[] = {c->d_xy, c->d_t, c->d_p, c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
+    for (int i = 0; i < 2; ++i) if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
+    void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
+                    c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_hist_ts, c->d_bin_start,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
-                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_state, c->d_stats,
+                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
                     c->d_trace};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -371,6 +460,30 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->force_split = value != 0;
         return BF_OK;
     }
+    if (!strcmp(key, "binned")) {
+        c->opt_binned = value != 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_tile")) {
+        if (value != 16 && value != 32 && value != 64 && value != 128)
+            return fail(c, BF_ERR_ARG, "bin_tile must be 16, 32, 64 or 128");
+        c->opt_bin_tile = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_predict")) {
+        c->opt_bin_predict = value != 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_threads")) {
+        if (value != 256 && value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "bin_threads must be 256, 512 or 1024");
+        c->opt_bin_threads = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_margin")) {
+        if (value < 2 || value > 64 || value % 2) return fail(c, BF_ERR_ARG, "bin_margin must be even, in [2, 64]");
+        c->opt_bin_margin = (int)value;
+        return BF_OK;
+    }
     return fail(c, BF_ERR_ARG, "unknown option '%s'", key);
 }
 
@@ -386,10 +499,12 @@ int bf_synchronize(bf_ctx* c) {
 static int stage_common(bf_ctx* c, const int32_t* dx, const int32_t* dy, const int32_t* dt, long long n) {
     const long long gran = (long long)kThreads * kEvPerThread;
     c->n_pad = (n + gran - 1) / gran * gran;
-    launch_init_stats(c->d_stats, c->stream);
     {
         ProfScope ps(c, 3);
-        launch_prepare(dx, dy, dt, c->d_xy, c->d_t, c->d_p, n, c->n_pad, c->d_stats, c->stream);
+        launch_prepare(dx, dy, dt, c->set[0].xy, c->set[0].t, c->set[0].p, n, c->n_pad, c->d_stats,
+                       c->stream);
+        c->cs = 0;
+        c->has_perm = false;
     }
     HIP_TRY(c, hipGetLastError());
     return after_upload(c, n);
@@ -438,9 +553,20 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     if (scale < 1 || scale % 2 == 0 || scale / 2 > kMaxHalfScale)   // optimizer_rolling.h:274
         return fail(c, BF_ERR_ARG, "scale must be odd and <= %d (got %d)", 2 * kMaxHalfScale + 1, scale);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(SliceStats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->d_stats, kPrepBlocks * sizeof(SliceStats), hipMemcpyDeviceToHost,
+                              c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const SliceStats s = *c->h_stats;
+    SliceStats s = c->h_stats[0];   // fold the per-work-group records of k_prepare
+    for (int k = 1; k < kPrepBlocks; ++k) {
+        const SliceStats& q = c->h_stats[k];
+        if (q.xmin < s.xmin) s.xmin = q.xmin;
+        if (q.xmax > s.xmax) s.xmax = q.xmax;
+        if (q.ymin < s.ymin) s.ymin = q.ymin;
+        if (q.ymax > s.ymax) s.ymax = q.ymax;
+        if (q.tmin < s.tmin) s.tmin = q.tmin;
+        if (q.tmax > s.tmax) s.tmax = q.tmax;
+        s.tsum += q.tsum;
+    }
     bf_window w;
     memset(&w, 0, sizeof(w));
     w.scale = scale;
@@ -498,23 +624,52 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     c->win = w;
     c->have_window = true;
     DevState& h = c->hst;
-    h.scale = scale;
-    h.R = w.scale_img_x; h.C = w.scale_img_y;
-    h.wsx = w.metric_wsizex; h.wsy = w.metric_wsizey;
-    h.x_sh = (int)w.x_shift;   // double -> int parameter conversion of accel_lib.h:147
-    h.y_sh = (int)w.y_shift;
-    h.tbits = tbits;
+    h.hot.scale = scale;
+    h.hot.R = w.scale_img_x; h.hot.C = w.scale_img_y;
+    h.hot.wsx = w.metric_wsizex; h.hot.wsy = w.metric_wsizey;
+    h.hot.x_sh = (int)w.x_shift;   // double -> int parameter conversion of accel_lib.h:147
+    h.hot.y_sh = (int)w.y_shift;
+    h.hot.tbits = tbits;
     h.x_shift = w.x_shift; h.y_shift = w.y_shift;
-    h.tmin = tmin;
+    h.hot.tmin = tmin;
     h.nblocks = gx * gy;
     memset(&h.model, 0, sizeof(h.model));   // a fresh OptimizerRolling has a zero ObjectModel
-    h.wp = identity_warp();
-    h.it = 0; h.done = 0; h.rc = 0;
+    h.hot.wp = identity_warp();
+    h.hot.it = 0; h.hot.done = 0; h.rc = 0;
     c->pending_warp = false;
     c->all_noise = false;
     // Event::reset for every event (set_cloud :260).  bf_upload_events already reset p.
-    HIP_TRY(c, hipMemsetAsync(c->d_p, 0, (size_t)c->n_pad * sizeof(float2), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->set[c->cs].p, 0, (size_t)c->n_pad * sizeof(float2), c->stream));
     c->n_valid = false;
+    // Tile-binned scatter: usable when the packed accumulator can hold the whole slice (then
+    // it can hold any bin), there is no noise mask, and the bin grid fits the kernels' LDS.
+    {
+        BinGrid g;
+        g.TS = c->opt_bin_tile;
+        g.D = c->opt_bin_margin > g.TS / 2 ? g.TS / 2 : c->opt_bin_margin;   // <= 2 x 2 bins per pixel
+        g.L = g.TS + 2 * g.D;
+        g.lg = 0;
+        while ((1 << g.lg) < g.TS) ++g.lg;
+        g.pad = 0;
+        g.nbr = (w.scale_img_x + g.TS - 1) / g.TS;
+        g.nbc = (w.scale_img_y + g.TS - 1) / g.TS;
+        g.nbins = g.nbr * g.nbc;
+        c->use_binned = c->opt_binned && c->packed && !c->has_noise && c->n > 0 && g.nbins <= 4096 &&
+                        (size_t)g.L * g.L * 8 <= 160 * 1024;
+        if (c->use_binned) {
+            int rc = ensure_cplanes(c);
+            if (rc == BF_OK) rc = ensure_bin_buffers(c, g);
+            if (rc != BF_OK) return rc;
+            c->grid = g;
+        }
+        h.hot.binned = c->use_binned ? 1 : 0;
+        h.n_events = (uint32_t)c->n;
+        h.hot.bin_tbits = tbits; h.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
+        h.hot.flip = 0;
+        h.t_abs_max = (c->n > 0) ? std::fmax(std::fabs((double)s.tmin), std::fabs((double)s.tmax)) : 0.0;
+        h.r_max = std::hypot((double)(w.x_max - w.x_min), (double)(w.y_max - w.y_min)) + 64.0;
+        h.drift_limit = c->opt_bin_predict ? 0.6 * (double)c->grid.D : 1e300;
+    }
     if (c->planes_unknown || w.scale_img_x != c->last_R || w.scale_img_y != c->last_C) {
         int rc = clear_planes(c);
         if (rc != BF_OK) return rc;
@@ -537,7 +692,7 @@ int bf_project_4param_reinit(bf_ctx* c, double dnx_, double dny_, double cx, dou
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = flush_pending(c);
     if (rc != BF_OK) return rc;
-    WarpParams& w = c->hst.wp;
+    WarpParams& w = c->hst.hot.wp;
     w.dnx = dnx_; w.dny = dny_; w.cx = cx; w.cy = cy; w.div = div;
     w.c = std::cos(crl);   // event.h:102-103 evaluates std::cos / std::sin on the host
     w.s = std::sin(crl);
@@ -567,12 +722,15 @@ int bf_get_time_img(bf_ctx* c, float* time_out, uint32_t* count_out) {
     StencilArgs a = st_args(c, buf, 0);
     a.time_out = c->d_time;
     a.count_out = c->d_count;
+    a.zero_cplane = c->d_cplane[buf ^ 1];   // may be NULL (never allocated): nothing to clear
     {
         ProfScope ps(c, 1);
-        launch_stencil(a, c->packed ? 0 : 1, c->stream);
+        launch_stencil(a, stencil_src(c, false), c->stream);
     }
     HIP_TRY(c, hipGetLastError());
     c->cur = buf ^ 1;   // the stencil zeroed the other buffer; `buf` is cleared by the next pass
+    c->hst.hot.ovf_cnt[buf] = 1;
+    c->hst.hot.ovf_cnt[buf ^ 1] = 0;
     const size_t P = (size_t)c->win.scale_img_x * (size_t)c->win.scale_img_y;
     if (time_out)
         HIP_TRY(c, hipMemcpyAsync(time_out, c->d_time, P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -631,11 +789,11 @@ int bf_fast_model(bf_ctx* c, const float* img, int32_t rows, int32_t cols, bf_mo
     if (gx * gy > c->cap_blocks) return fail(c, BF_ERR_CAPACITY, "image needs %d tiles", gx * gy);
     image_pass(c, src, rows, cols, false, true);
     DevState tmp = c->hst;
-    tmp.R = rows; tmp.C = cols;
+    tmp.hot.R = rows; tmp.hot.C = cols;
     launch_set_state(c->d_state, tmp, c->stream);
     {
         ProfScope ps(c, 2);
-        launch_update(c->d_state, c->d_partials, gx * gy, nullptr, 0, c->stream);
+        launch_update(c->d_state, c->d_partials, gx * gy, nullptr, 0, 0, c->stream);
     }
     HIP_TRY(c, hipGetLastError());
     int rc = d2h_state(c);
@@ -670,7 +828,8 @@ int bf_writeout_events(bf_ctx* c, double* pr_x, double* pr_y, double* nx, double
     if (pr_x || pr_y) {
         {
             ProfScope ps(c, 3);
-            launch_expand_pr(c->d_xy, c->d_p, c->d_uv, c->n, c->stream);
+            launch_expand_pr(c->set[c->cs].xy, c->set[c->cs].p, c->has_perm ? c->set[c->cs].perm : nullptr,
+                             c->d_uv, c->n, c->stream);
         }
         HIP_TRY(c, hipGetLastError());
         rc = copy_pairs(c, c->d_uv, pr_x, pr_y);
@@ -724,7 +883,7 @@ int bf_set_model(bf_ctx* c, const bf_model* model) {
     }
     // optimizer_rolling.h:289-299: model <- m; warp(-total_dx, -total_dy, cx, cy, total_div, -total_rot)
     c->hst.model = *model;
-    WarpParams& w = c->hst.wp;
+    WarpParams& w = c->hst.hot.wp;
     w.dnx = -model->total_dx; w.dny = -model->total_dy;
     w.cx = model->cx; w.cy = model->cy;
     w.div = model->total_div;
@@ -766,52 +925,93 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         HIP_TRY(c, hipMalloc(&c->d_trace, (size_t)o.trace_cap * sizeof(bf_trace_rec)));
         c->trace_alloc = o.trace_cap;
     }
+    const bool binned = c->use_binned;
     DevState& h = c->hst;
+    // Tile-binned mode sorts the events by the tile of their CURRENT target, so a warm-start
+    // warp (bf_set_model) is applied before the sort rather than inside the first iteration.
+    bool first_warp = c->pending_warp;
+    if (binned && c->pending_warp) {
+        launch_set_state(c->d_state, h, c->stream);
+        ProfScope ps(c, 0, c->n);
+        launch_warp_scatter(ws_args(c, c->cur, 0), true, false, false, c->stream);
+        first_warp = false;
+        inf.launches++;
+    }
+    c->pending_warp = false;
     h.x_div = h.y_div = 1.0f;            // :61
     h.rot_div = h.div_div = 10000.0f;    // :62-63
     h.old_dx = h.old_dy = h.old_rot = h.old_div = 0.f;
-    h.it = 0; h.done = 0; h.rc = 0;
+    h.hot.it = 0; h.hot.done = 0; h.rc = 0;
     h.max_iter = o.max_iter;
     h.hard_cap = o.hard_iter_cap;
     h.trace_cap = o.trace_cap;
-    if (!c->pending_warp) h.wp = identity_warp();
+    h.hot.binned = binned ? 1 : 0;
+    h.hot.need_rebin = binned ? 1 : 0;   // the first enqueued re-bin builds the bins
+    h.hot.rebins = 0; h.ovf_total = 0;
+    h.hot.cs = c->cs; h.hot.flip = 0;
+    if (!first_warp) h.hot.wp = identity_warp();
+    h.ref_wp = h.hot.wp;
     launch_set_state(c->d_state, h, c->stream);
+    const bool perm_at_start = c->has_perm;
 
     const int b0 = c->cur;
     int buf = b0;
     bool first = true;
-    const bool first_warp = c->pending_warp;
-    c->pending_warp = false;
     bf_trace_rec* trace = o.trace_cap > 0 ? c->d_trace : nullptr;
     int launched_iters = 0;
-    for (;;) {
+    // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
+    // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
+    // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
+    DevState fin;
+    for (int batch = 0;; ++batch) {
+        if (binned) {   // runs only if the update asked for it (and always before iteration 1)
+            int rc = enqueue_rebin(c, perm_at_start);
+            if (rc != BF_OK) return rc;
+            inf.launches += 4;
+        }
         for (int k = 0; k < o.poll_interval; ++k) {
-            {
+            const bool warp = first ? first_warp : true;
+            if (binned) {
                 ProfScope ps(c, 0, c->n);
-                launch_warp_scatter(ws_args(c, buf, 1), first ? first_warp : true, true, false, c->stream);
+                launch_bin_warp_scatter(ev_sets(c), c->d_bin_start, c->d_slabs, c->d_plane[buf],
+                                        c->d_cplane[buf], c->d_state, c->grid, buf, warp, 1, c->opt_bin_threads, c->stream);
+            } else {
+                ProfScope ps(c, 0, c->n);
+                launch_warp_scatter(ws_args(c, buf, 1), warp, true, false, c->stream);
             }
-            {
+            {   // stencil + moments; its last work-group reduces and runs the model / loop update
                 StencilArgs a = st_args(c, buf, 1);
                 a.partials = c->d_partials;
+                a.ticket = c->d_ticket;
+                a.st_rw = c->d_state;
+                a.trace = trace;
+                a.update_mode = 1;
                 ProfScope ps(c, 1);
-                launch_stencil(a, c->packed ? 0 : 1, c->stream);
-            }
-            {
-                ProfScope ps(c, 2);
-                launch_update(c->d_state, c->d_partials, h.nblocks, trace, 1, c->stream);
+                launch_stencil(a, stencil_src(c, binned), c->stream);
             }
             first = false;
             buf ^= 1;
             ++launched_iters;
-            inf.launches += 3;
+            inf.launches += 2;
         }
         HIP_TRY(c, hipGetLastError());
-        int rc = d2h_state(c);
-        if (rc != BF_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(c->poll_ev[batch & 1], c->stream));
+        if (batch == 0) continue;
+        HIP_TRY(c, hipEventSynchronize(c->poll_ev[(batch - 1) & 1]));
         inf.polls++;
-        if (c->h_state->done) break;
-        if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 8) + o.poll_interval)
+        const DevState& snap = c->h_state[(batch - 1) & 1];
+        if (snap.hot.done) {
+            fin = snap;
+            break;
+        }
+        if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
             return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
+    }
+    if (binned) {   // the device chose which set holds the (tile-sorted) events
+        c->cs = fin.hot.cs;
+        c->has_perm = true;
     }
     // final warp: the last project_4param_reinit of iteration_step (:340-344), kept so that
     // pr / nx / ny describe the converged model; n is written for compute_uv / writeout.
@@ -829,18 +1029,19 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     HIP_TRY(c, hipGetLastError());
     if (o.want_uv) HIP_TRY(c, hipStreamSynchronize(c->stream));
 
-    const DevState& d = *c->h_state;
-    h.model = d.model; h.wp = d.wp;
-    h.x_div = d.x_div; h.y_div = d.y_div; h.rot_div = d.rot_div; h.div_div = d.div_div;
-    h.it = d.it; h.done = d.done; h.rc = d.rc;
-    // iterations executed alternate buffers starting at b0; the stencil of the last one
-    // zeroed the buffer that the next pass will scatter into.
-    c->cur = b0 ^ (d.it & 1);
-    c->trace_valid = d.it < o.trace_cap ? d.it : o.trace_cap;
+    const DevState d = fin;
+    h = d;   // model, dividers, warp parameters, plane-buffer dirtiness
+
+    // iterations executed alternate buffers starting at b0; the next scatter goes to the
+    // buffer the last stencil left clean.
+    c->cur = b0 ^ (d.hot.it & 1);
+    c->trace_valid = d.hot.it < o.trace_cap ? d.hot.it : o.trace_cap;
     inf.rc = d.rc;
-    inf.iterations = d.it;
+    inf.iterations = d.hot.it;
     inf.x_divider = d.x_div; inf.y_divider = d.y_div;
     inf.rot_divider = d.rot_div; inf.div_divider = d.div_div;
+    inf.rebins = d.hot.rebins;
+    inf.overflow_events = (int32_t)(d.ovf_total > 0x7fffffffu ? 0x7fffffffu : d.ovf_total);
     if (model_out) *model_out = d.model;
     if (info) *info = inf;
     if (d.rc < 0) return fail(c, d.rc, "iteration cap (%d) reached without convergence", o.hard_iter_cap);

@@ -1,0 +1,438 @@
+// bf_binned.hip -- tile-binned form of the warp+scatter kernel (K1) for gfx950.
+//
+// Why: one random 64-bit global atomic per event costs ~48 us per 1M events on MI355X no
+// matter how small the footprint is (scripts/micro/atomics.hip: random 48 us, coalesced 9 us,
+// LDS-accumulate + dense store flush 9-14 us).  So the scatter is made local:
+//
+//   * events are counting-sorted by the image tile (TS x TS scaled pixels) their CURRENT
+//     target falls into (k_bin_count / k_bin_scan / k_bin_scatter, once per slice and again
+//     only when the model has drifted by more than the margin D);
+//   * k_bin_warp_scatter: one work-group per bin.  It owns an LDS tile of (TS+2D)^2 packed
+//     64-bit accumulators placed over its image tile, warps its events (coalesced loads of
+//     xy / t / p), adds them with LDS atomics, and writes the tile with plain 16-byte stores
+//     to its private slab -- no global atomics, nothing to zero, deterministic;
+//   * an event that lands outside its bin's LDS tile (drift > D) takes an exact overflow
+//     path (global atomics into the double-buffered overflow planes) and is counted; the
+//     update kernel raises `need_rebin` when that count is large;
+//   * the stencil kernel (k_stencil<3>, bf_kernels.hip) sums the <= 9 slabs that overlap
+//     each pixel while it loads its LDS tile.
+//
+// All accumulators are integers (count << tbits | sum(t - tmin)), so the result is exactly
+// the reference's s x s splat (accel_lib.h:147-166) whatever the event order.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "bf_device.h"
+#include "bf_device_fns.h"
+#include "bf_kernels.h"
+
+namespace bf {
+
+
+// Image tile of the current target of one event (clamped into the grid: events whose target
+// is outside the image are rejected by the scatter but still need a home bin).
+__device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs, const BinGrid& g) {
+    const double pr_x = pr_from_p(xy & 0xffffu, p.x);
+    const double pr_y = pr_from_p(xy >> 16, p.y);
+    int X = trunc_x86(pr_x * (double)hs.scale + (double)hs.x_sh);
+    int Y = trunc_x86(pr_y * (double)hs.scale + (double)hs.y_sh);
+    X = min(max(X, 0), hs.R - 1);
+    Y = min(max(Y, 0), hs.C - 1);
+    return (X >> g.lg) * g.nbc + (Y >> g.lg);
+}
+
+// The re-bin kernels are enqueued by the host at a fixed cadence and run only when the update
+// asked for it (hot.need_rebin): no host round trip sits between "drifted" and "re-sorted".
+//
+// R1: per-bin event count and sum(t - tmin); remembers each event's bin.
+__global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n,
+                                                        const DevState* __restrict__ st, BinGrid g,
+                                                        uint16_t* __restrict__ binid,
+                                                        uint32_t* __restrict__ hist_cnt,
+                                                        unsigned long long* __restrict__ hist_ts) {
+    const HotState hs = st->hot;
+    if (!hs.need_rebin || hs.done) return;
+    const EvSetPtrs e = sets.s[hs.cs ^ hs.flip];
+    extern __shared__ unsigned long long s_mem[];
+    unsigned long long* s_ts = s_mem;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mem + g.nbins);
+    for (int i = threadIdx.x; i < g.nbins; i += kThreads) { s_ts[i] = 0; s_cnt[i] = 0; }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (long long)gridDim.x * kThreads) {
+        const int b = bin_of(e.xy[i], e.p[i], hs, g);
+        binid[i] = (uint16_t)b;
+        atomicAdd(&s_cnt[b], 1u);
+        atomicAdd(&s_ts[b], (unsigned long long)((long long)e.t[i] - hs.tmin));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.nbins; i += kThreads) {
+        if (s_cnt[i]) {
+            atomicAdd(&hist_cnt[i], s_cnt[i]);
+            atomicAdd(&hist_ts[i], s_ts[i]);
+        }
+    }
+}
+
+// R2: exclusive scan of the counts -> bin_start; accumulator packing for this binning:
+// tbits = bits(max_b sum_b(t - tmin)), and it is usable iff tbits + bits(max_b count_b) <= 64.
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_cnt,
+                                                   unsigned long long* __restrict__ hist_ts, int nbins,
+                                                   uint32_t* __restrict__ bin_start,
+                                                   uint32_t* __restrict__ cursor, DevState* st,
+                                                   uint32_t* __restrict__ armed) {
+    if (!st->hot.need_rebin || st->hot.done) return;
+    __shared__ uint32_t s_sum[1024];
+    __shared__ uint32_t s_maxc[1024];
+    __shared__ unsigned long long s_maxt[1024];
+    const int tid = threadIdx.x;
+    const int per = (nbins + 1023) / 1024;
+    uint32_t local = 0, maxc = 0;
+    unsigned long long maxt = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < nbins) {
+            local += hist_cnt[b];
+            maxc = max(maxc, hist_cnt[b]);
+            maxt = max(maxt, hist_ts[b]);
+        }
+    }
+    s_sum[tid] = local; s_maxc[tid] = maxc; s_maxt[tid] = maxt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        uint32_t v = (tid >= off) ? s_sum[tid - off] : 0u;
+        uint32_t mc = (tid >= off) ? s_maxc[tid - off] : 0u;
+        unsigned long long mt = (tid >= off) ? s_maxt[tid - off] : 0ull;
+        __syncthreads();
+        s_sum[tid] += v;
+        s_maxc[tid] = max(s_maxc[tid], mc);
+        s_maxt[tid] = max(s_maxt[tid], mt);
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - local;   // exclusive prefix of this thread's first bin
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < nbins) {
+            bin_start[b] = run;
+            run += hist_cnt[b];
+            cursor[b] = 0;
+            hist_cnt[b] = 0;   // ready for the next re-bin
+            hist_ts[b] = 0;
+        }
+    }
+    if (tid == 1023) {
+        bin_start[nbins] = s_sum[1023];
+        int tbits = 1, cbits = 0;
+        for (unsigned long long v = s_maxt[1023]; v; v >>= 1) ++tbits;
+        for (uint32_t v = s_maxc[1023]; v; v >>= 1) ++cbits;
+        tbits -= 1;
+        if (tbits < 1) tbits = 1;
+        st->hot.bin_tbits = tbits;
+        st->bin_ok = (tbits + cbits <= 64) ? 1 : 0;
+        st->hot.need_rebin = 0;
+        st->hot.flip = 1;            // k_bin_scatter (next kernel) moves the events to set cs^1
+        st->hot.rebins += 1;
+        st->ref_wp = st->hot.wp;     // drift is measured from the model the bins were built for
+        *armed = 1;
+    }
+}
+
+// R3: move every event to its bin's range (order inside a bin is irrelevant: integer sums).
+// Runs right after k_bin_scan set hot.flip; `armed` (written by the scan) guards a second
+// launch before the update has committed the flip.
+__global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_perm,
+                                                          const uint16_t* __restrict__ binid, long long n,
+                                                          const uint32_t* __restrict__ bin_start,
+                                                          uint32_t* __restrict__ cursor, int nbins,
+                                                          const DevState* __restrict__ st,
+                                                          const uint32_t* __restrict__ armed) {
+    if (!*armed) return;
+    const int cs = st->hot.cs;
+    const EvSetPtrs src = sets.s[cs], dst = sets.s[cs ^ 1];
+    const bool perm_in = has_perm || st->hot.rebins > 1;
+    extern __shared__ uint32_t s_u32[];
+    uint32_t* s_cnt = s_u32;
+    uint32_t* s_base = s_u32 + nbins;
+    for (int i = threadIdx.x; i < nbins; i += kThreads) s_cnt[i] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * kThreads * 4;
+    uint32_t rank[4];
+    int bin[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * kThreads + threadIdx.x;
+        bin[k] = -1;
+        if (i < n) {
+            bin[k] = binid[i];
+            rank[k] = atomicAdd(&s_cnt[bin[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += kThreads)
+        if (s_cnt[i]) s_base[i] = bin_start[i] + atomicAdd(&cursor[i], s_cnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * kThreads + threadIdx.x;
+        if (bin[k] >= 0) {
+            const uint32_t o = s_base[bin[k]] + rank[k];
+            dst.xy[o] = src.xy[i];
+            dst.t[o] = src.t[i];
+            dst.p[o] = src.p[i];
+            dst.perm[o] = perm_in ? src.perm[i] : (uint32_t)i;
+        }
+    }
+}
+
+// R4: disarm the scatter once it has run (single thread).
+__global__ void k_bin_disarm(uint32_t* armed) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *armed = 0;
+}
+
+// K1 (binned): warp + LDS scatter + slab flush, one work-group per bin.
+template <bool WARP, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
+    EvSets sets, const uint32_t* __restrict__ bin_start, unsigned long long* __restrict__ slabs,
+    unsigned long long* __restrict__ ovf_plane, uint32_t* __restrict__ ovf_cplane, DevState* st,
+    BinGrid g, int cur, int check_done) {
+    extern __shared__ unsigned long long s_tile[];
+    const int L = g.L, LL = g.L * g.L;
+    const int b = blockIdx.x;
+    // everything the block needs from global memory is requested up front, in one burst
+    const uint32_t beg = bin_start[b], end = bin_start[b + 1];
+    const HotState hs = st->hot;
+    const int X0 = (b / g.nbc) * g.TS - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
+    {   // zero the LDS tile, 16 bytes per lane (overlaps the scalar loads above)
+        ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
+        for (int i = threadIdx.x; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
+    }
+    if (check_done && hs.done) return;
+    const EvSetPtrs ev = sets.s[hs.cs ^ hs.flip];
+    const uint32_t* __restrict__ xy = ev.xy;
+    const int32_t* __restrict__ t = ev.t;
+    float2* __restrict__ p = ev.p;
+    const WarpParams& wp = hs.wp;
+    const int s = hs.scale, x_sh = hs.x_sh, y_sh = hs.y_sh, hsc = hs.scale / 2;
+    const int wsx = hs.wsx, wsy = hs.wsy, C = hs.C, tbits = hs.bin_tbits;
+    const long long tmin = hs.tmin;
+    uint32_t n_ovf = 0;
+    __syncthreads();
+    constexpr int U = 4;   // events in flight per thread: all loads of a pass are issued first
+    for (uint32_t base = beg; base < end; base += THREADS * U) {
+        uint32_t vxy[U];
+        int32_t vt[U];
+        float2 vp[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t i = base + k * THREADS + threadIdx.x;
+            const bool live = i < end;
+            vxy[k] = live ? xy[i] : 0u;
+            vt[k] = live ? t[i] : 0;
+            vp[k] = live ? p[i] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t i = base + k * THREADS + threadIdx.x;
+            if (i >= end) continue;
+            const uint32_t v = vxy[k];
+            const int32_t ti = vt[k];
+            float2 q = vp[k];
+            const uint32_t fx = v & 0xffffu, fy = v >> 16;
+            double pr_x = pr_from_p(fx, q.x);
+            double pr_y = pr_from_p(fy, q.y);
+            if (WARP) {   // event.h:100-108,164-168 -- same arithmetic as k_warp_scatter
+                const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
+                const double qx = wp.c * rx - wp.s * ry;
+                const double qy = wp.s * rx + wp.c * ry;
+                const double nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
+                const double ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
+                const float kx = div_127((float)nx);
+                const float ky = div_127((float)ny);
+                const float ft = (float)ti;
+                q.x = kx * ft;
+                q.y = ky * ft;
+                p[i] = q;
+                pr_x = pr_from_p(fx, q.x);
+                pr_y = pr_from_p(fy, q.y);
+            }
+            const int X = trunc_x86(pr_x * (double)s + (double)x_sh);   // accel_lib.h:154-158
+            const int Y = trunc_x86(pr_y * (double)s + (double)y_sh);
+            if (!((X >= wsx + hsc) || (X < hsc) || (Y >= wsy + hsc) || (Y < hsc))) {
+                const unsigned long long dt = (unsigned long long)((long long)ti - tmin);
+                const int lx = X - X0, ly = Y - Y0;
+                if (lx >= 0 && lx < L && ly >= 0 && ly < L) {
+                    atomicAdd(&s_tile[lx * L + ly], (1ull << tbits) + dt);
+                } else {   // drifted out of this bin's tile: exact, slow path
+                    const size_t kk = (size_t)X * (size_t)C + (size_t)Y;
+                    atomicAdd(&ovf_plane[kk], dt);
+                    atomicAdd(&ovf_cplane[kk], 1u);
+                    ++n_ovf;
+                }
+            }
+        }
+    }
+    if (n_ovf) atomicAdd(&st->hot.ovf_cnt[cur], n_ovf);
+    __syncthreads();
+    {   // flush: the whole tile, plain 16-byte stores (nothing to zero, no atomics)
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_tile);
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(slabs + (size_t)b * (size_t)LL);
+        for (int i = threadIdx.x; i < LL / 2; i += THREADS) dst[i] = src[i];
+    }
+}
+
+// K3 (binned): merge the slabs covering each pixel, box-sum, normalise, then the shared tail.
+// HS = scale / 2 is a template parameter so that the tile geometry is constexpr (index
+// arithmetic by multiply-shift), TS is a power of two (shifts), D <= TS / 2 (a pixel is
+// covered by at most 2 x 2 bins) and every slab load of a thread is issued up front.
+template <int HS>
+__global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
+    const HotState hs = a.st->hot;   // one burst of scalar loads, then the branch
+    if (a.check_done && hs.done) return;
+    constexpr int TR = kTileR, TC = kTileC;
+    constexpr int H = HS + 1;
+    constexpr int PR = TR + 2 * H, PC = TC + 2 * H;
+    constexpr int TH = TR + 2, TW = TC + 2;
+    constexpr int NC = (PR * PC + kThreads - 1) / kThreads;
+    __shared__ unsigned long long s_ts[PR * PC];
+    __shared__ uint32_t s_cnt[PR * PC];
+    __shared__ float s_time[TH * TW];
+    __shared__ Sums s_red[kThreads / 64];
+    const int R = a.R, C = a.C;
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
+    const BinGrid g = a.g;
+    const int bt = hs.bin_tbits;
+    const unsigned long long bm = (1ull << bt) - 1ull;
+    // (static indices only: a runtime index would push the HotState copy into scratch memory)
+    const bool ovf = (a.cur ? hs.ovf_cnt[1] : hs.ovf_cnt[0]) != 0;
+    const size_t LL = (size_t)g.L * (size_t)g.L;
+
+    unsigned long long w[NC][4];
+    unsigned long long ov[NC];
+    uint32_t oc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int idx = tid + c * kThreads;
+        const int pr = idx / PC, pc = idx - pr * PC;
+        const int gr = r0 - H + pr, gc = c0 - H + pc;
+        const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
+        // bin (br, bc) holds rows [br*TS - D, br*TS + TS + D)
+        const int brl = max(gr - g.D, 0) >> g.lg, brh = min((gr + g.D) >> g.lg, g.nbr - 1);
+        const int bcl = max(gc - g.D, 0) >> g.lg, bch = min((gc + g.D) >> g.lg, g.nbc - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int br = (q & 2) ? brh : brl, bc = (q & 1) ? bch : bcl;
+            const bool use = in && (!(q & 2) || brh > brl) && (!(q & 1) || bch > bcl);
+            const int lx = gr - ((br << g.lg) - g.D), ly = gc - ((bc << g.lg) - g.D);
+            w[c][q] = use ? a.slabs[(size_t)(br * g.nbc + bc) * LL + (size_t)(lx * g.L + ly)] : 0ull;
+        }
+        ov[c] = (in && ovf) ? a.plane[(size_t)gr * C + gc] : 0ull;
+        oc[c] = (in && ovf) ? a.cplane[(size_t)gr * C + gc] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int idx = tid + c * kThreads;
+        if (idx < PR * PC) {
+            unsigned long long ts = ov[c];
+            uint32_t cn = oc[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ts += w[c][q] & bm;
+                cn += (uint32_t)(w[c][q] >> bt);
+            }
+            s_ts[idx] = ts;
+            s_cnt[idx] = cn;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TH * TW; idx += kThreads) {
+        const int tr = idx / TW, tc = idx - tr * TW;
+        const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
+        float tv = 0.f;
+        if (gr >= 0 && gr < R && gc >= 0 && gc < C) {
+            // s x s box sum == the s x s splat of accel_lib.h:160-165 on integer planes
+            unsigned long long acc = 0;
+            uint32_t cacc = 0;
+#pragma unroll
+            for (int da = 0; da <= 2 * HS; ++da)
+#pragma unroll
+                for (int db = 0; db <= 2 * HS; ++db) {
+                    acc += s_ts[(tr + da) * PC + (tc + db)];
+                    cacc += s_cnt[(tr + da) * PC + (tc + db)];
+                }
+            tv = time_from_sums(cacc, (long long)acc, a.tmin);
+            if (tr >= 1 && tr <= TR && tc >= 1 && tc <= TC) {
+                if (a.time_out) a.time_out[(size_t)gr * C + gc] = tv;
+                if (a.count_out) a.count_out[(size_t)gr * C + gc] = cacc;
+            }
+        }
+        s_time[idx] = tv;
+    }
+    __syncthreads();
+    const bool do_zero = a.zero_plane && (a.cur ? hs.ovf_cnt[0] : hs.ovf_cnt[1]) != 0;
+    stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
+}
+
+void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
+    switch (a.scale / 2) {
+        case 0: hipLaunchKernelGGL(k_stencil_binned<0>, grid, dim3(kThreads), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(k_stencil_binned<1>, grid, dim3(kThreads), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(k_stencil_binned<2>, grid, dim3(kThreads), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(k_stencil_binned<3>, grid, dim3(kThreads), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_stencil_binned<4>, grid, dim3(kThreads), 0, s, a); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
+                  uint16_t* binid, uint32_t* hist_cnt, unsigned long long* hist_ts, uint32_t* bin_start,
+                  uint32_t* cursor, uint32_t* armed, hipStream_t s) {
+    if (n <= 0) return;
+    long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 12, s, sets, n,
+                       st, g, binid, hist_cnt, hist_ts);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, hist_cnt, hist_ts, g.nbins, bin_start, cursor,
+                       st, armed);
+    const long long per = (long long)kThreads * 4;
+    hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + per - 1) / per)), dim3(kThreads),
+                       (size_t)g.nbins * 8, s, sets, has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);
+    hipLaunchKernelGGL(k_bin_disarm, dim3(1), dim3(64), 0, s, armed);
+}
+
+template <int THREADS>
+static void launch_bws(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane, uint32_t* ovf_cplane,
+                       DevState* st, const BinGrid& g, int cur, bool warp, int check_done, hipStream_t s) {
+    const size_t lds = (size_t)g.L * g.L * sizeof(unsigned long long);
+    if (warp)
+        hipLaunchKernelGGL((k_bin_warp_scatter<true, THREADS>), dim3(g.nbins), dim3(THREADS), lds, s, sets,
+                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done);
+    else
+        hipLaunchKernelGGL((k_bin_warp_scatter<false, THREADS>), dim3(g.nbins), dim3(THREADS), lds, s, sets,
+                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done);
+}
+
+void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane,
+                             uint32_t* ovf_cplane, DevState* st, const BinGrid& g, int cur, bool warp,
+                             int check_done, int threads, hipStream_t s) {
+    if (threads >= 1024) launch_bws<1024>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, s);
+    else if (threads >= 512) launch_bws<512>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, s);
+    else launch_bws<256>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, s);
+}
+
+template <bool W, int T>
+static hipError_t raise_lds() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<W, T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+int bin_kernel_setup() {
+    // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
+    hipError_t e[6] = {raise_lds<true, 256>(),  raise_lds<false, 256>(),  raise_lds<true, 512>(),
+                       raise_lds<false, 512>(), raise_lds<true, 1024>(), raise_lds<false, 1024>()};
+    for (hipError_t x : e)
+        if (x != hipSuccess) return -1;
+    return 0;
+}
+
+}  // namespace bf

@@ -12,6 +12,10 @@
 //   plane   2 x u64[R*C]  point-scatter accumulators, double buffered:
 //                    PACKED: count << tbits | sum(t - tmin)
 //                    SPLIT : u64 sum(t - tmin) in plane[], u32 count in cplane[]
+//                    (in the tile-binned mode they only take the rare overflow events)
+//   set[2]  two copies of (xy, t, p, perm): the tile-binned mode keeps events counting-
+//                    sorted by the image tile of their current target and ping-pongs on re-bin
+//   slabs   u64[nbins * L * L]  one private (TS+2D)^2 tile per bin, rewritten every iteration
 //   time    f32[R*C] time image (stand-alone operators only)
 //   gx, gy  f32[R*C] Scharr planes (stand-alone operators only)
 //   partial Partial[blocks]  per-work-group moment sums of the stencil kernel
@@ -44,18 +48,53 @@ struct Partial {
     double pad;
 };
 
-struct DevState {
-    // --- window (host-written at set_cloud) ---
+// Geometry of the tile-binned scatter (bf_binned.hip): image tiles of TS x TS scaled
+// pixels, LDS / slab tiles of L = TS + 2 D, nbr x nbc bins.
+struct BinGrid {
+    int32_t TS, D, L, nbr, nbc, nbins;
+    int32_t lg, pad;   // TS == 1 << lg; D <= TS / 2, so a pixel is covered by <= 2 x 2 bins
+};
+
+// Fields every kernel of the loop reads.  They are contiguous so that a kernel issues ONE
+// burst of scalar loads for them before it branches on `done` (each dependent scalar load
+// that misses L2 costs ~1-2 us on the iteration's critical path).
+struct HotState {
+    int32_t done, it, binned, bin_tbits;
+    uint32_t ovf_cnt[2];      // events that took the overflow path into plane buffer [i]
+    int32_t need_rebin, rebins;
+    int32_t cs, flip, pad0, pad1;   // live event set; flip = a re-bin moved the events to set cs^1
+                                    // (committed by the next update)
+    // window (host-written at set_cloud)
     int32_t scale, R, C, wsx, wsy, x_sh, y_sh, tbits;
-    double x_shift, y_shift;
     long long tmin;
+    WarpParams wp;
+};
+
+struct DevState {
+    HotState hot;
+    double x_shift, y_shift;
     // --- loop control (optimizer_rolling.h:36,59-63) ---
     float x_div, y_div, rot_div, div_div;
     float old_dx, old_dy, old_rot, old_div;
-    int32_t it, done, max_iter, hard_cap, rc, trace_cap, nblocks, pad0;
-    // --- model + warp parameters ---
+    int32_t max_iter, hard_cap, rc, trace_cap, nblocks, bin_ok;
+    uint32_t ovf_total, n_events;
+    // --- drift tracking of the tile-binned scatter: warp parameters at the last re-bin, and
+    //     the largest |t| (ns) and lever arm (sensor px) an event of this slice can have ---
+    WarpParams ref_wp;
+    double t_abs_max, r_max, drift_limit;
+    // --- model ---
     bf_model model;
-    WarpParams wp;
+};
+
+// The two event sets as kernel arguments; the live one is sets[hot.cs ^ hot.flip].
+struct EvSetPtrs {
+    uint32_t* xy;
+    int32_t* t;
+    float2* p;
+    uint32_t* perm;
+};
+struct EvSets {
+    EvSetPtrs s[2];
 };
 
 }  // namespace bf

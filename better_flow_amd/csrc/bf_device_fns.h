@@ -1,0 +1,378 @@
+// bf_device_fns.h -- device-side helpers shared by bf_kernels.hip and bf_binned.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "bf_device.h"
+#include "bf_kernels.h"
+#include <math.h>
+#include <math.h>
+
+namespace bf {
+
+// `int x = <double>` on x86-64 is cvttsd2si: NaN / out-of-range -> INT_MIN (then rejected by
+// the bounds test of accel_lib.h:157).  v_cvt_i32_f64 would saturate / give 0 instead.
+__device__ __forceinline__ int trunc_x86(double v) {
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN;
+}
+
+// f32 form of the reference's `p > 0.000001` (float against a double literal): 1e-6f is the
+// largest float below 1e-6, so (double)p > 1e-6  <=>  p > 1e-6f.
+__device__ __forceinline__ bool valid_px(float p) { return p > 1e-6f; }
+
+// Exact IEEE division by a constant in three FMA-class operations (Markstein):
+//   q0 = x * R,  r = fma(-q0, d, x),  q = fma(r, R, q0),  R = RN(1 / d).
+// The dividends here are always a float (converted to double for the f64 form), so the
+// identity with x / d was PROVEN EXHAUSTIVELY over all 2^32 floats by tests/exhaustive_div.c
+// (0 mismatches with the zero / infinity fix-up below).  Replaces ~15-instruction division
+// expansions: the warp+scatter kernel was f64-ALU-bound on them.
+__device__ __forceinline__ double div_10000(double x) {   // x == (double)(some float)
+    constexpr double R = 1.0 / 10000.0;
+    const double q0 = x * R;
+    const double r = fma(-q0, 10000.0, x);
+    const double q = fma(r, R, q0);
+    return (x == 0.0 || isinf(x)) ? q0 : q;
+}
+__device__ __forceinline__ float div_127(float x) {
+    constexpr float R = 1.0f / 127.0f;
+    const float q0 = x * R;
+    const float r = fmaf(-q0, 127.0f, x);
+    const float q = fmaf(r, R, q0);
+    return (x == 0.0f || isinf(x)) ? q0 : q;
+}
+
+// Previous / new projected position from the stored f32 product (event.h:167-168):
+//   pr = float(fr) - (kx * float(t)) / 10000.0      (f32 product, f64 divide and subtract)
+__device__ __forceinline__ double pr_from_p(uint32_t fr, float prod) {
+    return (double)(float)fr - div_10000((double)prod);
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+constexpr int kTicketGroups = 32;   // arrival counters of the fused reduction (64 B apart)
+
+struct Sums {
+    long long n, sci, scj;
+    double sgx, sgy, sigx, sigy, sjgx, sjgy;
+};
+
+__device__ __forceinline__ void sums_zero(Sums& s) {
+    s.n = s.sci = s.scj = 0;
+    s.sgx = s.sgy = s.sigx = s.sigy = s.sjgx = s.sjgy = 0.0;
+}
+__device__ __forceinline__ void sums_add(Sums& a, const Sums& b) {
+    a.n += b.n; a.sci += b.sci; a.scj += b.scj;
+    a.sgx += b.sgx; a.sgy += b.sgy;
+    a.sigx += b.sigx; a.sigy += b.sigy; a.sjgx += b.sjgx; a.sjgy += b.sjgy;
+}
+__device__ __forceinline__ void sums_wave_reduce(Sums& s) {
+    s.n = wave_sum(s.n); s.sci = wave_sum(s.sci); s.scj = wave_sum(s.scj);
+    s.sgx = wave_sum(s.sgx); s.sgy = wave_sum(s.sgy);
+    s.sigx = wave_sum(s.sigx); s.sigy = wave_sum(s.sigy);
+    s.sjgx = wave_sum(s.sjgx); s.sjgy = wave_sum(s.sjgy);
+}
+
+// Mean time of one pixel from its exact integer sums (accel_lib.h:162,172): the f32 sum of
+// seconds is the integer-ns sum rounded once, then the f32 divide by the count.
+__device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_biased, long long tmin) {
+    if (cnt == 0) return 0.f;
+    const long long ts = tsum_biased + (long long)cnt * tmin;
+    const float sum_s = (float)((double)ts / 1000000000.0);
+    return sum_s / (float)cnt;
+}
+
+// ObjectModel::update from the reduced sums (object_model.cpp:4-39,103-126) and, in mode 1,
+// ObjectModel::update_accumulators (object_model.h:48-53), the glue of iteration_step
+// (optimizer_rolling.h:328-346) and the loop control of run() (optimizer_rolling.h:61-101).
+// Runs on ONE thread (the reducer).  mode 0: model only (AccelLib::fast_model).
+__device__ __noinline__ void model_update(DevState* st, const Sums& t, bf_trace_rec* trace, int mode,
+                                          int cur) {
+    bf_model m = st->model;
+    const int R = st->hot.R, C = st->hot.C;
+    const double dn = (double)t.n;   // cnt == 0 -> 0/0 = NaN, as in the reference (assert off)
+    // object_model.cpp:103-126: cx = (sum of rows) / cnt, exact integer numerator
+    m.cx = (double)(t.sci + t.n * (long long)(R / 2)) / dn;
+    m.cy = (double)(t.scj + t.n * (long long)(C / 2)) / dn;
+    const double cxc = (double)t.sci / dn, cyc = (double)t.scj / dn;
+    // object_model.cpp:26-38 with r = (ci - cxc, cj - cyc)
+    m.dx = t.sgx / dn;
+    m.dy = t.sgy / dn;
+    m.rot = ((t.sigy - cxc * t.sgy) - (t.sjgx - cyc * t.sgx)) / dn;
+    m.div = ((t.sigx - cxc * t.sgx) + (t.sjgy - cyc * t.sgy)) / dn;
+    m.cnt = (uint32_t)t.n;
+    if (mode == 0) {
+        st->model = m;
+        return;
+    }
+    // object_model.h:48-53 via optimizer_rolling.h:328
+    m.total_rot += m.rot / (double)st->rot_div;
+    m.total_div += m.div / (double)st->div_div;
+    m.total_dx += m.dx / (double)st->x_div;
+    m.total_dy += m.dy / (double)st->y_div;
+    // optimizer_rolling.h:330-331,340-346
+    const double cxs = (m.cx - st->x_shift) / (double)st->hot.scale;
+    const double cys = (m.cy - st->y_shift) / (double)st->hot.scale;
+    WarpParams wp;
+    wp.dnx = -m.total_dx; wp.dny = -m.total_dy;
+    wp.cx = cxs; wp.cy = cys;
+    wp.div = m.total_div;
+    const double crl = -m.total_rot;
+    wp.c = cos(crl);
+    wp.s = sin(crl);
+    m.cx = cxs;
+    m.cy = cys;
+    st->hot.wp = wp;
+    st->model = m;
+
+    // plane-buffer bookkeeping: the stencil of this iteration cleared buffer cur^1 (v1 paths
+    // always, the tile-binned path when it was dirty); buffer `cur` is dirty iff something was
+    // scattered into it.  Many overflow events -> ask the host for a re-bin.
+    if (st->hot.binned) {
+        if (st->hot.flip) {   // a re-bin moved the events to the other set: commit
+            st->hot.cs ^= 1;
+            st->hot.flip = 0;
+        }
+        const uint32_t oc = st->hot.ovf_cnt[cur];
+        st->ovf_total += oc;
+        // Predictive re-bin: bound how far the new warp can have moved any event (scaled pixels)
+        // since the bins were built, and re-sort BEFORE events start leaving their LDS tiles.
+        //   n = dn(translation) + (div, rot) x lever arm;  displacement = scale * n / 127 * t / 1e4
+        const WarpParams& r = st->ref_wp;
+        const double dn = fabs(wp.dnx - r.dnx) + fabs(wp.dny - r.dny) +
+                          2.0 * st->r_max * (fabs(wp.div - r.div) + fabs(wp.s - r.s)) +
+                          (fabs(wp.div) + fabs(wp.s)) * (fabs(wp.cx - r.cx) + fabs(wp.cy - r.cy));
+        const double drift = (double)st->hot.scale * dn / 127.0 * st->t_abs_max / 10000.0;
+        if (drift > st->drift_limit) st->hot.need_rebin = 1;
+        // safety net: whatever the bound missed shows up as overflow events
+        if ((unsigned long long)oc * 64ull > (unsigned long long)st->n_events) st->hot.need_rebin = 1;
+    } else {
+        st->hot.ovf_cnt[cur] = 1;
+    }
+    st->hot.ovf_cnt[cur ^ 1] = 0;
+
+    // ---- run(), optimizer_rolling.h:73-101, as a state machine after each step ----
+    const int it = st->hot.it + 1;
+    st->hot.it = it;
+    float xd = st->x_div, yd = st->y_div, rd = st->rot_div, dd = st->div_div;
+    int done = 0, rc = 0;
+    if (it > 1) {
+        if (st->max_iter > 0 && it > st->max_iter) {   // :94-96 (before the sign flips)
+            done = 1;
+        } else {                                       // :98-101
+            if (m.dx * (double)st->old_dx < 0) xd *= 2;
+            if (m.dy * (double)st->old_dy < 0) yd *= 2;
+            if (m.rot * (double)st->old_rot < 0) rd *= 2;
+            if (m.div * (double)st->old_div < 0) dd *= 2;
+            st->x_div = xd; st->y_div = yd; st->rot_div = rd; st->div_div = dd;
+            if (st->hard_cap > 0 && it >= st->hard_cap) { done = 1; rc = BF_ERR_NOCONV; }
+        }
+    }
+    if (trace && it <= st->trace_cap) {
+        bf_trace_rec& r = trace[it - 1];
+        r.model = m;
+        r.x_divider = xd; r.y_divider = yd; r.rot_divider = rd; r.div_divider = dd;
+        r.iteration = it;
+    }
+    if (!done) {
+        if (!(xd < 32 * 10 || yd < 32 * 10 || rd < 32 * 1000 || dd < 32 * 1000)) {   // :76-79
+            done = 1;
+        } else if (fabs(m.dx / (double)xd) < 1e-5 && fabs(m.dy / (double)yd) < 1e-5 &&
+                   fabs(m.rot / (double)rd) < 1e-4 && fabs(m.div / (double)dd) < 1e-1) {   // :81-84
+            done = 1;
+        } else {                                                                         // :86-89
+            st->old_dx = (float)m.dx; st->old_dy = (float)m.dy;
+            st->old_rot = (float)m.rot; st->old_div = (float)m.div;
+        }
+    }
+    if (done) {
+        st->rc = rc;
+        st->hot.done = 1;
+    }
+}
+
+// Second half of the stencil kernels: given the time tile in LDS ((TR+2) x (TC+2), halo 1),
+// the gated 3x3 Scharr (accel_lib.h:513-615), the centre-of-mass and moment sums
+// (object_model.cpp:4-39,103-126), optional gradient output, clearing of the other plane
+// buffer, and the wave64-shuffle + LDS reduction into one Partial per work-group.
+template <int TR, int TC>
+__device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* s_time, Sums* s_red,
+                                             int r0, int c0, bool do_zero) {
+    constexpr int TW = TC + 2;
+    const int R = a.R, C = a.C;
+    const int tid = threadIdx.x;
+    Sums sm;
+    sums_zero(sm);
+    const int hR = R / 2, hC = C / 2;
+#pragma unroll
+    for (int k = 0; k < (TR * TC) / kThreads; ++k) {
+        const int pidx = tid + k * kThreads;
+        const int lr = pidx / TC, lc = pidx - lr * TC;
+        const int gr = r0 + lr, gc = c0 + lc;
+        if (gr < R && gc < C) {
+            const float* tp = &s_time[(lr + 1) * TW + (lc + 1)];
+            const float ctr = tp[0];
+            float gx = 0.f, gy = 0.f;
+            const bool v = valid_px(ctr);
+            if (v && gr >= 1 && gr < R - 1 && gc >= 1 && gc < C - 1) {
+                // accel_lib.h:594-604: k = column offset (outer), l = row offset (inner),
+                // idx = 3k + l; sharr_x = {3,0,-3,10,0,-10,3,0,-3},
+                // sharr_y = {3,10,3,0,0,0,-3,-10,-3}; any tap <= 1e-6 -> gradient stays 0.
+                const float t00 = tp[-TW - 1], t10 = tp[-1], t20 = tp[TW - 1];
+                const float t01 = tp[-TW], t21 = tp[TW];
+                const float t02 = tp[-TW + 1], t12 = tp[1], t22 = tp[TW + 1];
+                const bool all = valid_px(t00) && valid_px(t10) && valid_px(t20) &&
+                                 valid_px(t01) && valid_px(t21) && valid_px(t02) &&
+                                 valid_px(t12) && valid_px(t22);
+                if (all) {
+                    float dx = 0.f, dy = 0.f;
+                    // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
+                    dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
+                    dx = dx + t10 * 0.f;   dy = dy + t10 * 10.f;
+                    dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
+                    // k = 1 (column c)
+                    dx = dx + t01 * 10.f;  dy = dy + t01 * 0.f;
+                    dx = dx + ctr * 0.f;   dy = dy + ctr * 0.f;
+                    dx = dx + t21 * -10.f; dy = dy + t21 * 0.f;
+                    // k = 2 (column c+1)
+                    dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
+                    dx = dx + t12 * 0.f;   dy = dy + t12 * -10.f;
+                    dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
+                    gx = dx;
+                    gy = dy;
+                }
+            }
+            if (a.gx_out) {
+                a.gx_out[(size_t)gr * C + gc] = gx;
+                a.gy_out[(size_t)gr * C + gc] = gy;
+            }
+            if (v) {
+                // object_model.cpp:22-30 and :112-116 in one pass, centred coordinates
+                const int ci = gr - hR, cj = gc - hC;
+                sm.n += 1;
+                sm.sci += ci;
+                sm.scj += cj;
+                const double gxd = (double)gx, gyd = (double)gy;
+                sm.sgx += gxd;
+                sm.sgy += gyd;
+                sm.sigx += (double)ci * gxd;
+                sm.sigy += (double)ci * gyd;
+                sm.sjgx += (double)cj * gxd;
+                sm.sjgy += (double)cj * gyd;
+            }
+            if (do_zero) {
+                a.zero_plane[(size_t)gr * C + gc] = 0ull;
+                if (a.zero_cplane) a.zero_cplane[(size_t)gr * C + gc] = 0u;
+            }
+        }
+    }
+    if (a.partials) {
+        sums_wave_reduce(sm);
+        if ((tid & 63) == 0) s_red[tid >> 6] = sm;
+        __syncthreads();
+        const int nblk = gridDim.x * gridDim.y;
+        const int me = blockIdx.y * gridDim.x + blockIdx.x;
+        if (!a.ticket) {   // stand-alone pass: partials only, reduced by k_update
+            if (tid == 0) {
+                Sums t = s_red[0];
+                for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
+                Partial& o = a.partials[me];
+                o.n = t.n; o.sci = t.sci; o.scj = t.scj;
+                o.sgx = t.sgx; o.sgy = t.sgy;
+                o.sigx = t.sigx; o.sigy = t.sigy; o.sjgx = t.sjgx; o.sjgy = t.sjgy;
+            }
+            return;
+        }
+        // Fused reduction: every work-group publishes its partial, the LAST one to arrive reduces
+        // all of them in a fixed order and runs the model / loop update -- no separate kernel.
+        // Hand-off (cdna_hip_programming.md, Guideline 16): write-through (agent-scope atomic)
+        // stores of the payload, drained with s_waitcnt vmcnt(0), then a relaxed agent-scope
+        // ticket; the reducer reads the payload with agent-scope (L1-bypassing) loads.
+        __shared__ int s_last;
+        if (tid == 0) {
+            Sums t = s_red[0];
+            for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(&a.partials[me]);
+            const unsigned long long v[9] = {
+                (unsigned long long)t.n, (unsigned long long)t.sci, (unsigned long long)t.scj,
+                (unsigned long long)__double_as_longlong(t.sgx), (unsigned long long)__double_as_longlong(t.sgy),
+                (unsigned long long)__double_as_longlong(t.sigx), (unsigned long long)__double_as_longlong(t.sigy),
+                (unsigned long long)__double_as_longlong(t.sjgx), (unsigned long long)__double_as_longlong(t.sjgy)};
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                __hip_atomic_store(&o[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
+            // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
+            // lines and only the last arriver of each group takes the top-level ticket.
+            const int grp = me % kTicketGroups;
+            const int grp_size = nblk / kTicketGroups + (grp < nblk % kTicketGroups ? 1 : 0);
+            const int n_groups = nblk < kTicketGroups ? nblk : kTicketGroups;
+            int last = 0;
+            const unsigned int t1 = __hip_atomic_fetch_add(&a.ticket[16 * (1 + grp)], 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            if (t1 == (unsigned int)(grp_size - 1)) {
+                a.ticket[16 * (1 + grp)] = 0;   // re-armed for the next launch
+                const unsigned int t0 =
+                    __hip_atomic_fetch_add(&a.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (t0 == (unsigned int)(n_groups - 1)) ? 1 : 0;
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        Sums acc;
+        sums_zero(acc);
+        // fixed summation order (thread-strided, then the wave / LDS trees): bitwise repeatable
+        for (int base = 0; base < nblk; base += kThreads * 4) {
+            unsigned long long q[4][9];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k * kThreads + tid;
+                const unsigned long long* src =
+                    reinterpret_cast<const unsigned long long*>(&a.partials[i < nblk ? i : 0]);
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    q[k][j] = (i < nblk) ? __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc.n += (long long)q[k][0]; acc.sci += (long long)q[k][1]; acc.scj += (long long)q[k][2];
+                acc.sgx += __longlong_as_double((long long)q[k][3]);
+                acc.sgy += __longlong_as_double((long long)q[k][4]);
+                acc.sigx += __longlong_as_double((long long)q[k][5]);
+                acc.sigy += __longlong_as_double((long long)q[k][6]);
+                acc.sjgx += __longlong_as_double((long long)q[k][7]);
+                acc.sjgy += __longlong_as_double((long long)q[k][8]);
+            }
+        }
+        sums_wave_reduce(acc);
+        __syncthreads();   // s_red is reused
+        if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            Sums t = s_red[0];
+            for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
+            a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
+            model_update(a.st_rw, t, a.trace, a.update_mode, a.cur);
+        }
+    }
+}
+
+
+}  // namespace bf

@@ -8,7 +8,9 @@
 
 namespace bf {
 
-// min / max / sum statistics of one staged slice (k_prepare).
+constexpr int kPrepBlocks = 1024;   // work-groups of k_prepare == SliceStats records it writes
+
+// min / max / sum statistics of one staged slice (k_prepare), one record per work-group.
 struct SliceStats {
     int32_t xmin, xmax, ymin, ymax, tmin, tmax;
     long long tsum;
@@ -19,7 +21,8 @@ struct WarpScatterArgs {
     const int32_t* t;
     float2* p;
     const uint8_t* noise;          // may be NULL
-    double2* nxny;                 // written only by the final warp
+    double2* nxny;                 // written only by the final warp, at [perm[i]]
+    const uint32_t* perm;          // original index of slot i (NULL: identity)
     unsigned long long* plane;     // point-scatter accumulator (current buffer)
     uint32_t* cplane;              // SPLIT mode count plane (current buffer)
     const DevState* st;
@@ -43,10 +46,18 @@ struct StencilArgs {
     Partial* partials;                 // optional
     unsigned long long* zero_plane;    // optional: the OTHER plane buffer, zeroed here
     uint32_t* zero_cplane;
+    // fused reduction + model / loop update by the last work-group (NULL ticket: partials only)
+    unsigned int* ticket;
+    DevState* st_rw;
+    bf_trace_rec* trace;
+    int update_mode;                   // 1: full iteration_step / run() update, 0: model only
+    // SRC 3 (tile-binned): per-bin slabs + the overflow planes of buffer `cur`
+    const unsigned long long* slabs;
+    BinGrid g;
+    int cur;
 };
 
 void launch_set_state(DevState* st, const DevState& v, hipStream_t s);
-void launch_init_stats(SliceStats* st, hipStream_t s);
 void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool write_n,
                          hipStream_t s);
 void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_in, uint32_t* xy,
@@ -55,9 +66,22 @@ void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_i
 void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
 void launch_update(DevState* st, const Partial* partials, int nblocks, bf_trace_rec* trace, int mode,
-                   hipStream_t s);
+                   int cur, hipStream_t s);
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s);
-void launch_expand_pr(const uint32_t* xy, const float2* p, double2* pr, long long n, hipStream_t s);
+void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,
+                      hipStream_t s);
+
+// bf_binned.hip
+int bin_kernel_setup();
+void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
+void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
+                  uint16_t* binid, uint32_t* hist_cnt, unsigned long long* hist_ts, uint32_t* bin_start,
+                  uint32_t* cursor, uint32_t* armed, hipStream_t s);
+void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs,
+                             unsigned long long* ovf_plane, uint32_t* ovf_cplane, DevState* st,
+                             const BinGrid& g, int cur, bool warp, int check_done, int threads,
+                             hipStream_t s);
+
 void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 
 }  // namespace bf

@@ -80,6 +80,9 @@ typedef struct bf_run_info {
     float x_divider, y_divider, rot_divider, div_divider;
     int32_t launches;        /* kernel launches enqueued (diagnostic)                   */
     int32_t polls;           /* host polls of the done flag (diagnostic)                */
+    int32_t rebins;          /* counting sorts of the events by image tile (diagnostic)  */
+    int32_t overflow_events; /* events that left their bin's LDS tile, summed over the
+                                iterations; they take an exact global-atomic path          */
 } bf_run_info;
 
 /* One record per iteration_step (trajectory tests). */
@@ -127,10 +130,19 @@ void bf_run_opts_default(bf_run_opts *opts);
  * struct layouts.  Writes min(n, 6) entries; returns 6. */
 int bf_abi_struct_sizes(int32_t *out, int32_t n);
 
-/* Tuning / test knobs that have no counterpart in the reference.  Keys:
+/* Tuning / test knobs that have no counterpart in the reference (each takes effect at the
+ * next bf_set_cloud).  Keys:
  *   "force_split"  1: keep the event-count and time-sum accumulators in separate planes
- *                  even when they fit one packed 64-bit word (takes effect at the next
- *                  bf_set_cloud). */
+ *                  even when they fit one packed 64-bit word.
+ *   "binned"       1 (default): tile-binned LDS scatter inside bf_run; 0: one global
+ *                  atomic per event.  Results are identical.
+ *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 32).
+ *   "bin_margin"   LDS margin around a bin's tile (even, default 8); events drifting
+ *                  further take the exact overflow path and trigger a re-bin.
+ *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x margin
+ *                  (bounded analytically), i.e. before they overflow; 0: re-bin only on
+ *                  observed overflow.
+ *   "bin_threads"  work-group size of the binned warp+scatter kernel (256, 512, 1024). */
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 
 /* ---- slice set-up -------------------------------------------------------------- */

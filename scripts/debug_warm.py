@@ -1,5 +1,7 @@
 import sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, "tests")
 import numpy as np
 import oracle
 from better_flow_amd import accel, synth

@@ -1,6 +1,8 @@
 """Per-operator GPU timing through the C-ABI (hipEvent-bracketed launches)."""
 import sys
-sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from better_flow_amd import accel, synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000

@@ -1,6 +1,8 @@
 """Timing probe: one cold + one warm fused run on a synthetic slice (GPU box)."""
 import sys, time, json
-sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 from better_flow_amd import accel, synth
 
@@ -9,11 +11,15 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 260
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 346
 s = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 poll = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+binned = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+tile = int(sys.argv[7]) if len(sys.argv) > 7 else 32
+margin = int(sys.argv[8]) if len(sys.argv) > 8 else 8
 sl = synth.make_slice(N, H, W, 0.030, seed=1)
 sl2 = synth.make_slice(N, H, W, 0.030, seed=2)
 n = len(sl["t"])
 acc = accel.Accel(max_events=max(n, len(sl2["t"])), max_rows=s * H + s, max_cols=s * W + s)
-print("version", acc.L.bf_version().decode(), "events", n)
+acc.set_option("binned", binned); acc.set_option("bin_tile", tile); acc.set_option("bin_margin", margin)
+print("version", acc.L.bf_version().decode(), "events", n, "binned", binned, "tile", tile, "margin", margin)
 print("copy GB/s", acc.copy_bandwidth(1 << 30, 5))
 opts = acc.default_opts()
 opts.res_x, opts.res_y, opts.poll_interval, opts.want_uv = H, W, poll, 1
@@ -26,7 +32,7 @@ for rep in range(3):
     acc.synchronize()
     dt = time.perf_counter() - t0
     print("cold rep", rep, "rc", rc, "iters", info.iterations, "ms", dt * 1e3, "us/iter", dt * 1e6 / info.iterations,
-          "Mev/s", n / dt / 1e6, "polls", info.polls)
+          "Mev/s", n / dt / 1e6, "polls", info.polls, "rebins", info.rebins, "ovf", info.overflow_events)
     # warm: slice 2 from slice 1's model
     acc.upload_events(sl2["fr_x"], sl2["fr_y"], sl2["t"])
     acc.synchronize()
@@ -36,7 +42,7 @@ for rep in range(3):
     rc, m2, info2 = acc.run(opts)
     acc.synchronize()
     dt = time.perf_counter() - t0
-    print("warm rep", rep, "rc", rc, "iters", info2.iterations, "ms", dt * 1e3, "Mev/s", len(sl2["t"]) / dt / 1e6)
+    print("warm rep", rep, "rc", rc, "iters", info2.iterations, "ms", dt * 1e3, "Mev/s", len(sl2["t"]) / dt / 1e6, "rebins", info2.rebins, "ovf", info2.overflow_events)
 u, v = acc.compute_uv()
 print("flow", u.mean(), v.mean(), "truth", sl["velocity"])
 print("model", m.as_dict())

@@ -1,0 +1,55 @@
+/* Exhaustive proof (all 2^32 float bit patterns) that the 3-operation sequences used by the
+ * HIP kernels are bit-identical to the IEEE divisions of the reference:
+ *   (a)  (double)f / 10000.0        event.h:167-168   (f = the f32 product kx * float(t))
+ *   (b)  f / 127.0f                 event.h:164-165   (== (float)((double)f / 127.0), see kernels)
+ * Sequence:  q0 = x * R;  r = fma(-q0, d, x);  q = fma(r, R, q0),  R = RN(1 / d).
+ * Without the zero / infinity fix-up exactly three inputs differ (-0, +inf, -inf); with it none.
+ * Exit status 0 iff there is no mismatch.  Build: gcc -O2 -mfma -fopenmp -ffp-contract=off.  Test-only. */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+static inline double div10000(double x) {
+    const double R = 1.0 / 10000.0;
+    double q0 = x * R;
+    double r = fma(-q0, 10000.0, x);
+    double q = fma(r, R, q0);
+    return (x == 0.0 || isinf(x)) ? q0 : q;   /* -0 and +-inf: the residual step is not exact */
+}
+static inline float div127(float x) {
+    const float R = 1.0f / 127.0f;
+    float q0 = x * R;
+    float r = fmaf(-q0, 127.0f, x);
+    float q = fmaf(r, R, q0);
+    return (x == 0.0f || isinf(x)) ? q0 : q;
+}
+
+int main(void) {
+    unsigned long long bad_a = 0, bad_b = 0;
+    float max_bad_b = 0.f, min_bad_b = INFINITY, max_bad_a = 0.f;
+#pragma omp parallel for reduction(+ : bad_a, bad_b) reduction(max : max_bad_b, max_bad_a) reduction(min : min_bad_b)
+    for (long long hi = 0; hi < 65536; ++hi) {
+        for (uint32_t lo = 0; lo < 65536; ++lo) {
+            uint32_t bits = ((uint32_t)hi << 16) | lo;
+            float f;
+            memcpy(&f, &bits, 4);
+            if (isnan(f)) continue;
+            double x = (double)f;
+            double qa = x / 10000.0, ga = div10000(x);
+            if (memcmp(&qa, &ga, 8) != 0) {
+                bad_a++;
+                if (fabsf(f) > max_bad_a) max_bad_a = fabsf(f);
+            }
+            float qb = f / 127.0f, gb = div127(f);
+            if (memcmp(&qb, &gb, 4) != 0 && !(isnan(qb) && isnan(gb))) {
+                bad_b++;
+                if (fabsf(f) > max_bad_b) max_bad_b = fabsf(f);
+                if (fabsf(f) < min_bad_b) min_bad_b = fabsf(f);
+            }
+        }
+    }
+    printf("div10000 (f64): %llu mismatches (max |f| %.9g)\n", bad_a, (double)max_bad_a);
+    printf("div127   (f32): %llu mismatches (|f| in [%.9g, %.9g])\n", bad_b, (double)min_bad_b, (double)max_bad_b);
+    return (bad_a || bad_b) ? 1 : 0;
+}

@@ -311,3 +311,64 @@ def test_golden_vectors_gpu(accel_mod):
     u, v = acc.compute_uv()
     assert _flow_close(u, z["u"]) and _flow_close(v, z["v"])
     acc.close()
+
+
+def _run_mode(accel_mod, sl, H, W, scale, trace_cap=0, warm=None, **options):
+    acc = accel_mod.Accel(max_events=max(len(sl["t"]), 8192), max_rows=scale * H + scale,
+                          max_cols=scale * W + scale)
+    for k, v in options.items():
+        acc.set_option(k, v)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    acc.set_cloud(scale, H, W)
+    if warm is not None:
+        acc.set_model(warm)
+    opts = acc.default_opts()
+    opts.res_x, opts.res_y, opts.trace_cap, opts.want_uv = H, W, trace_cap, 1
+    rc, m, info = acc.run(opts)
+    tr = acc.get_trace(trace_cap) if trace_cap else []
+    out = acc.writeout_events() + acc.compute_uv()
+    tim, cnt = acc.get_time_img()
+    acc.close()
+    return rc, m, info, tr, out, tim, cnt
+
+
+@pytest.mark.parametrize("scale", [1, 3])
+def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
+    """The tile-binned LDS scatter and the one-global-atomic-per-event scatter accumulate the
+    same integers, so whole trajectories must agree bit for bit -- also when a tiny margin
+    forces the overflow path and several re-bins."""
+    H, W = 180, 240
+    sl = synth.make_slice(60000, H, W, 0.05, seed=17)
+    ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=0)
+    assert ref[2].rebins == 0
+    for opts in (dict(binned=1), dict(binned=1, bin_tile=32, bin_margin=2),
+                 dict(binned=1, bin_tile=16, bin_margin=4), dict(binned=1, bin_tile=128, bin_margin=6)):
+        got = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, **opts)
+        assert got[0] == ref[0] and got[2].iterations == ref[2].iterations, opts
+        assert got[2].rebins >= 1
+        assert got[1].as_dict() == ref[1].as_dict(), opts
+        for a, b in zip(got[3], ref[3]):
+            assert a.model.as_dict() == b.model.as_dict(), opts
+        for a, b in zip(got[4], ref[4]):          # pr_x, pr_y, nx, ny, u, v in upload order
+            assert np.array_equal(a, b), opts
+        assert np.array_equal(got[5], ref[5]) and np.array_equal(got[6], ref[6]), opts
+    # without the drift prediction the re-bin is triggered by observed overflow only: the exact
+    # global-atomic overflow path must give the same bits
+    tiny = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=1, bin_tile=32, bin_margin=2,
+                     bin_predict=0)
+    assert tiny[2].overflow_events > 0 and tiny[2].rebins > 1, "margin 2 must exercise overflow + re-bin"
+    assert tiny[1].as_dict() == ref[1].as_dict() and tiny[2].iterations == ref[2].iterations
+    for a, b in zip(tiny[4], ref[4]):
+        assert np.array_equal(a, b)
+
+
+def test_binned_warm_start_bit_identical(accel_mod):
+    H, W = 180, 240
+    a = synth.make_slice(40000, H, W, 0.05, seed=31)
+    b = synth.make_slice(40000, H, W, 0.05, seed=32)
+    cold = _run_mode(accel_mod, a, H, W, 3, binned=0)
+    w0 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=0)
+    w1 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=1)
+    assert w0[2].iterations == w1[2].iterations and w0[1].as_dict() == w1[1].as_dict()
+    for x, y in zip(w0[4], w1[4]):
+        assert np.array_equal(x, y)

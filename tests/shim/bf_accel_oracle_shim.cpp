@@ -1,0 +1,165 @@
+// TEST INFRASTRUCTURE ONLY -- never built or linked by the product.
+//
+// Implements the subset of the C-ABI (include/bf_accel.h) that the host front end
+// (better_flow_amd/host/) calls, on top of the CPU oracle (oracle/bf_oracle.c).  It exists so
+// that the slice manager / CLI plumbing (ring buffer, triggers, STM chain, accumulation,
+// de-duplication, text formats -- BASELINE config 1) can be exercised on a machine without a
+// GPU, and so that the GPU CLI's output has a CPU-side expectation to be compared with.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/bf_accel.h"
+#include "../../oracle/bf_oracle.h"
+
+struct bf_ctx {
+    std::vector<int32_t> fx, fy;
+    std::vector<int64_t> t;
+    std::vector<uint8_t> noise;
+    std::vector<double> pr_x, pr_y, nx, ny;
+    bfo_cloud cloud;
+    bfo_window win;
+    bfo_model model;
+    bool have_window = false;
+    std::vector<float> time_img;
+    char err[128] = "";
+    void bind() {
+        cloud.n = (int64_t)fx.size();
+        cloud.fr_x = fx.data(); cloud.fr_y = fy.data(); cloud.t = t.data(); cloud.noise = noise.data();
+        cloud.pr_x = pr_x.data(); cloud.pr_y = pr_y.data(); cloud.nx = nx.data(); cloud.ny = ny.data();
+    }
+};
+
+static void to_abi(const bfo_model &m, bf_model *o) {
+    o->cx = m.cx; o->cy = m.cy; o->dx = m.dx; o->dy = m.dy; o->rot = m.rot; o->div = m.div;
+    o->cnt = m.cnt; o->_pad = 0;
+    o->total_dx = m.total_dx; o->total_dy = m.total_dy; o->total_rot = m.total_rot; o->total_div = m.total_div;
+}
+static void from_abi(const bf_model &m, bfo_model *o) {
+    o->cx = m.cx; o->cy = m.cy; o->dx = m.dx; o->dy = m.dy; o->rot = m.rot; o->div = m.div;
+    o->cnt = m.cnt;
+    o->total_dx = m.total_dx; o->total_dy = m.total_dy; o->total_rot = m.total_rot; o->total_div = m.total_div;
+}
+
+extern "C" {
+
+const char *bf_version(void) { return "bf_accel ORACLE TEST SHIM (CPU) -- not the product"; }
+const char *bf_last_error(const bf_ctx *c) { return c ? c->err : "null ctx"; }
+
+void bf_run_opts_default(bf_run_opts *o) {
+    o->max_iter = -1; o->min_events = 1000; o->res_x = 180; o->res_y = 240;
+    o->hard_iter_cap = 100000; o->poll_interval = 8; o->trace_cap = 0; o->want_uv = 0;
+}
+
+int bf_create(int32_t, int64_t, int32_t, int32_t, void *, bf_ctx **out) {
+    *out = new bf_ctx();
+    return BF_OK;
+}
+void bf_destroy(bf_ctx *c) { delete c; }
+
+int bf_upload_events(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns,
+                     const uint8_t *noise, int64_t n) {
+    c->fx.assign(fr_x, fr_x + n);
+    c->fy.assign(fr_y, fr_y + n);
+    c->t.resize(n);
+    for (int64_t i = 0; i < n; ++i) c->t[i] = t_ns[i];
+    c->noise.assign(n, 0);
+    if (noise) c->noise.assign(noise, noise + n);
+    c->pr_x.assign(n, 0); c->pr_y.assign(n, 0); c->nx.assign(n, 0); c->ny.assign(n, 0);
+    c->bind();
+    c->have_window = false;
+    return BF_OK;
+}
+
+int bf_set_cloud(bf_ctx *c, int32_t scale, int32_t res_x, int32_t res_y, bf_window *w) {
+    c->bind();
+    bfo_set_cloud(&c->cloud, scale, res_x, res_y, &c->win);
+    bfo_model_init(&c->model);
+    c->have_window = true;
+    if (w) {
+        memset(w, 0, sizeof(*w));
+        w->scale = scale;
+        w->x_min = c->win.x_min; w->y_min = c->win.y_min; w->x_max = c->win.x_max; w->y_max = c->win.y_max;
+        w->metric_wsizex = c->win.metric_wsizex; w->metric_wsizey = c->win.metric_wsizey;
+        w->scale_img_x = c->win.scale_img_x; w->scale_img_y = c->win.scale_img_y;
+        w->x_shift = c->win.x_shift; w->y_shift = c->win.y_shift;
+    }
+    return BF_OK;
+}
+
+int bf_project_4param_reinit(bf_ctx *c, double a, double b, double cx, double cy, double div, double crl) {
+    bfo_project_4param_reinit(&c->cloud, a, b, cx, cy, div, crl);
+    return BF_OK;
+}
+
+int bf_get_time_img(bf_ctx *c, float *time_out, uint32_t *count_out) {
+    const size_t P = (size_t)c->win.scale_img_x * c->win.scale_img_y;
+    c->time_img.resize(P);
+    std::vector<float> cnt(P);
+    bfo_get_time_img(&c->cloud, c->win.metric_wsizex, c->win.metric_wsizey, c->win.scale, (int)c->win.x_shift,
+                     (int)c->win.y_shift, c->time_img.data(), cnt.data());
+    if (time_out) memcpy(time_out, c->time_img.data(), P * sizeof(float));
+    if (count_out)
+        for (size_t i = 0; i < P; ++i) count_out[i] = (uint32_t)cnt[i];
+    return BF_OK;
+}
+
+int bf_sobel(bf_ctx *, const float *img, int32_t rows, int32_t cols, float *gx, float *gy) {
+    bfo_sobel(img, rows, cols, gx, gy);
+    return BF_OK;
+}
+
+int bf_fast_model(bf_ctx *c, const float *img, int32_t rows, int32_t cols, bf_model *model) {
+    bfo_model m;
+    from_abi(*model, &m);
+    if (img) bfo_fast_model(img, rows, cols, &m);
+    else bfo_fast_model(c->time_img.data(), c->win.scale_img_x, c->win.scale_img_y, &m);
+    model->cx = m.cx; model->cy = m.cy; model->dx = m.dx; model->dy = m.dy;
+    model->rot = m.rot; model->div = m.div; model->cnt = m.cnt;
+    return BF_OK;
+}
+
+int bf_writeout_events(bf_ctx *c, double *pr_x, double *pr_y, double *nx, double *ny) {
+    const size_t n = c->fx.size();
+    if (pr_x) memcpy(pr_x, c->pr_x.data(), n * 8);
+    if (pr_y) memcpy(pr_y, c->pr_y.data(), n * 8);
+    if (nx) memcpy(nx, c->nx.data(), n * 8);
+    if (ny) memcpy(ny, c->ny.data(), n * 8);
+    return BF_OK;
+}
+
+int bf_compute_uv(bf_ctx *c, double *u, double *v) {
+    const size_t n = c->fx.size();
+    std::vector<double> uu(n), vv(n);
+    bfo_compute_uv(c->nx.data(), c->ny.data(), (int64_t)n, uu.data(), vv.data());
+    if (u) memcpy(u, uu.data(), n * 8);
+    if (v) memcpy(v, vv.data(), n * 8);
+    return BF_OK;
+}
+
+int bf_set_model(bf_ctx *c, const bf_model *model) {
+    bfo_model last;
+    from_abi(*model, &last);
+    bfo_set_model(&c->cloud, &c->model, &last);
+    return BF_OK;
+}
+
+int bf_run(bf_ctx *c, const bf_run_opts *opts, bf_model *model_out, bf_run_info *info) {
+    bf_run_opts o;
+    if (opts) o = *opts; else bf_run_opts_default(&o);
+    bfo_loop lp;
+    int rc = bfo_run(&c->cloud, &c->win, &c->model, o.max_iter, o.res_x, o.res_y, o.min_events, o.hard_iter_cap,
+                     &lp, NULL, 0);
+    if (model_out) to_abi(c->model, model_out);
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->rc = rc < 0 ? BF_ERR_NOCONV : rc;
+        info->iterations = (int32_t)lp.itercount;
+        info->x_divider = lp.x_divider; info->y_divider = lp.y_divider;
+        info->rot_divider = lp.rot_divider; info->div_divider = lp.div_divider;
+    }
+    return rc < 0 ? BF_ERR_NOCONV : rc;
+}
+
+}  // extern "C"

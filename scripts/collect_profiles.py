@@ -1,0 +1,36 @@
+"""Copy the judged rocprofv3 summaries from gpurun_out/ into profiles/ (tracked)."""
+import csv, collections, statistics, re, glob, os, shutil, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+def kname(n):
+    m = re.search(r"(k_[a-z_0-9]+)(<[^>(]*>)?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n[:40]
+ks = glob.glob(os.path.join(ROOT, "gpurun_out/prof_bench/**/*kernel_stats.csv"), recursive=True)
+if ks:
+    shutil.copy(ks[0], os.path.join(out, tag + "_bench_kernel_stats.csv"))
+lines = []
+for cname, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+    fs = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**/*counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] == cname:
+            acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        live = [x for x in v if x > 64] or [0.0]
+        lines.append("%-12s %-34s dispatches %5d  live %5d  median %12.1f KB  mean %12.1f KB" %
+                     (cname, k, len(v), len(live), statistics.median(live), sum(live) / len(live)))
+open(os.path.join(out, tag + "_pmc_hbm_traffic.txt"), "w").write(
+    "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over\n"
+    "`python scripts/run_once.py 1` (one cold 1M-event 346x260 slice).  Values are the counters' KB per dispatch;\n"
+    "'live' excludes the early-exit launches after convergence.  On gfx950 FETCH_SIZE under-reports wide coalesced\n"
+    "reads by 2x (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n\n" + "\n".join(lines) + "\n")
+bl = os.path.join(ROOT, "gpurun_out/prof_bench.log")
+if os.path.exists(bl):
+    for ln in open(bl):
+        if ln.startswith('{"metric"'):
+            open(os.path.join(out, tag + "_bench_under_rocprof.json"), "w").write(ln)
+print(open(os.path.join(out, tag + "_pmc_hbm_traffic.txt")).read())

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libbf_accel.so")
+LIB_PATH = os.environ.get("BF_ACCEL_LIB") or os.path.join(_DIR, "libbf_accel.so")
 
 BF_OK, BF_SKIPPED = 0, 1
 BF_ERR_ARG, BF_ERR_HIP, BF_ERR_STATE, BF_ERR_NOCONV, BF_ERR_NODEVICE, BF_ERR_CAPACITY = (

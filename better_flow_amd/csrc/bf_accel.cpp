@@ -48,7 +48,7 @@ struct bf_ctx {
     // tile-binned scatter
     bool opt_binned = true;
     bool opt_bin_predict = true;
-    int opt_bin_tile = 32, opt_bin_margin = 8, opt_bin_threads = 256;
+    int opt_bin_tile = 64, opt_bin_margin = 8, opt_bin_threads = 1024;
     bool use_binned = false;         // decided per slice in bf_set_cloud
     BinGrid grid;
     uint16_t* d_binid = nullptr;

@@ -136,13 +136,13 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  even when they fit one packed 64-bit word.
  *   "binned"       1 (default): tile-binned LDS scatter inside bf_run; 0: one global
  *                  atomic per event.  Results are identical.
- *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 32).
+ *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 64).
  *   "bin_margin"   LDS margin around a bin's tile (even, default 8); events drifting
  *                  further take the exact overflow path and trigger a re-bin.
  *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x margin
  *                  (bounded analytically), i.e. before they overflow; 0: re-bin only on
  *                  observed overflow.
- *   "bin_threads"  work-group size of the binned warp+scatter kernel (256, 512, 1024). */
+ *   "bin_threads"  work-group size of the binned warp+scatter kernel (256, 512, 1024 (default)). */
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 
 /* ---- slice set-up -------------------------------------------------------------- */

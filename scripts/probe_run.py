@@ -12,7 +12,7 @@ W = int(sys.argv[3]) if len(sys.argv) > 3 else 346
 s = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 poll = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 binned = int(sys.argv[6]) if len(sys.argv) > 6 else 1
-tile = int(sys.argv[7]) if len(sys.argv) > 7 else 32
+tile = int(sys.argv[7]) if len(sys.argv) > 7 else 64
 margin = int(sys.argv[8]) if len(sys.argv) > 8 else 8
 sl = synth.make_slice(N, H, W, 0.030, seed=1)
 sl2 = synth.make_slice(N, H, W, 0.030, seed=2)

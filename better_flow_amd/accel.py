@@ -59,6 +59,15 @@ class RunInfo(C.Structure):
     ]
 
 
+class TileOpts(C.Structure):
+    _fields_ = [
+        ("grid_rows", C.c_int32), ("grid_cols", C.c_int32), ("scale", C.c_int32),
+        ("sensor_res_x", C.c_int32), ("sensor_res_y", C.c_int32),
+        ("guard_res_x", C.c_int32), ("guard_res_y", C.c_int32),
+        ("min_events", C.c_int32), ("max_iter", C.c_int32), ("hard_iter_cap", C.c_int32),
+    ]
+
+
 class TraceRec(C.Structure):
     _fields_ = [
         ("model", Model),
@@ -83,7 +92,7 @@ EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
     "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_upload_events", "bf_upload_events_device",
     "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
-    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_get_trace",
+    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_tiles", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
 ]
@@ -126,6 +135,7 @@ def load():
         L.bf_compute_uv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bf_set_model.argtypes = [C.c_void_p, C.POINTER(Model)]
         L.bf_run.argtypes = [C.c_void_p, C.POINTER(RunOpts), C.POINTER(Model), C.POINTER(RunInfo)]
+        L.bf_run_tiles.argtypes = [C.c_void_p, C.POINTER(TileOpts), C.c_void_p, C.c_void_p]
         L.bf_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.bf_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.bf_profile_reset.argtypes = [C.c_void_p]
@@ -254,6 +264,17 @@ class Accel:
                            C.byref(info))
         self._chk(rc, ok=(BF_OK, BF_SKIPPED))
         return rc, m, info
+
+    def run_tiles(self, grid_rows, grid_cols, scale, sensor_res, guard_res, min_events, max_iter=-1,
+                  hard_iter_cap=20000):
+        """One independent optimizer per sensor tile (bf_run_tiles); returns (models, infos)."""
+        o = TileOpts(grid_rows, grid_cols, scale, sensor_res[0], sensor_res[1], guard_res[0], guard_res[1],
+                     min_events, max_iter, hard_iter_cap)
+        nt = grid_rows * grid_cols
+        models = (Model * nt)()
+        infos = (RunInfo * nt)()
+        self._chk(self.L.bf_run_tiles(self.h, C.byref(o), models, infos))
+        return list(models), list(infos)
 
     def get_trace(self, cap):
         buf = (TraceRec * max(cap, 1))()

@@ -59,6 +59,10 @@ struct bf_ctx {
     int bins_alloc = 0;
     size_t slabs_alloc = 0;
     bool bin_setup_done = false;
+    // per-tile optimizers (bf_run_tiles)
+    uint32_t *d_tile_hist = nullptr, *d_tile_start = nullptr, *d_tile_cursor = nullptr;
+    DevState* d_tile_states = nullptr;
+    int tiles_alloc = 0;
     int32_t *d_in_x = nullptr, *d_in_y = nullptr, *d_in_t = nullptr;
     double2 *d_nxny = nullptr, *d_uv = nullptr;
     unsigned long long* d_plane[2] = {nullptr, nullptr};
@@ -440,7 +444,8 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_hist_ts, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
                     c->d_trace};
@@ -1046,6 +1051,101 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (info) *info = inf;
     if (d.rc < 0) return fail(c, d.rc, "iteration cap (%d) reached without convergence", o.hard_iter_cap);
     return d.rc;
+}
+
+int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_info* infos_out) {
+    if (!c || !o) return BF_ERR_ARG;
+    if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_run_tiles before bf_upload_events");
+    if (o->grid_rows < 1 || o->grid_cols < 1 || (long long)o->grid_rows * o->grid_cols > 16384)
+        return fail(c, BF_ERR_ARG, "bad tile grid %d x %d", o->grid_rows, o->grid_cols);
+    if (o->scale < 1 || o->scale % 2 == 0 || o->scale / 2 > kMaxHalfScale) return fail(c, BF_ERR_ARG, "scale must be odd");
+    if (o->sensor_res_x < 1 || o->sensor_res_y < 1) return fail(c, BF_ERR_ARG, "bad sensor size");
+    if (c->has_noise) return fail(c, BF_ERR_ARG, "bf_run_tiles does not take a noise mask");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int nt = o->grid_rows * o->grid_cols;
+    // second event set + permutation (shared with the tile-binned scatter)
+    if (!c->set[1].xy) {
+        HIP_TRY(c, hipMalloc(&c->set[1].xy, (size_t)c->cap_events * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[1].t, (size_t)c->cap_events * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->set[1].p, (size_t)c->cap_events * sizeof(float2)));
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!c->set[i].perm) HIP_TRY(c, hipMalloc(&c->set[i].perm, (size_t)c->cap_events * sizeof(uint32_t)));
+    if (nt > c->tiles_alloc) {
+        void* old[] = {c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states};
+        for (void* p : old) if (p) HIP_TRY(c, hipFree(p));
+        c->d_tile_hist = c->d_tile_start = c->d_tile_cursor = nullptr;
+        c->d_tile_states = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_tile_hist, (size_t)(nt + 1) * 4));
+        HIP_TRY(c, hipMalloc(&c->d_tile_start, (size_t)(nt + 1) * 4));
+        HIP_TRY(c, hipMalloc(&c->d_tile_cursor, (size_t)(nt + 1) * 4));
+        HIP_TRY(c, hipMalloc(&c->d_tile_states, (size_t)nt * sizeof(DevState)));
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_hist, 0, (size_t)(nt + 1) * 4, c->stream));
+        c->tiles_alloc = nt;
+    }
+    // LDS image capacity: the largest window a tile can have
+    const int tr = (o->sensor_res_x + o->grid_rows - 1) / o->grid_rows + 1;
+    const int tc = (o->sensor_res_y + o->grid_cols - 1) / o->grid_cols + 1;
+    const long long max_px = (long long)(o->scale * tr + o->scale) * (o->scale * tc + o->scale);
+    if (max_px * 16 > 156 * 1024)
+        return fail(c, BF_ERR_CAPACITY, "a tile window of up to %lld pixels does not fit the LDS", max_px);
+
+    DevState tmpl;
+    memset(&tmpl, 0, sizeof(tmpl));
+    tmpl.x_div = tmpl.y_div = 1.0f;           // optimizer_rolling.h:61-63
+    tmpl.rot_div = tmpl.div_div = 10000.0f;
+    tmpl.max_iter = o->max_iter;
+    tmpl.hard_cap = o->hard_iter_cap;
+    tmpl.hot.wp = identity_warp();
+    launch_fill_states(c->d_tile_states, tmpl, nt, c->stream);
+
+    TileGrid g;
+    g.rows = o->grid_rows; g.cols = o->grid_cols; g.res_x = o->sensor_res_x; g.res_y = o->sensor_res_y;
+    const bf_ctx::EvSet& src = c->set[c->cs];
+    const bf_ctx::EvSet& dst = c->set[c->cs ^ 1];
+    {
+        ProfScope ps(c, 3);
+        launch_tile_sort(src.xy, src.t, c->has_perm ? src.perm : nullptr, c->n, g, c->d_tile_hist, c->d_tile_start,
+                         c->d_tile_cursor, dst.xy, dst.t, dst.p, dst.perm, c->stream);
+    }
+    c->cs ^= 1;
+    c->has_perm = true;
+    TileArgs a;
+    a.xy = dst.xy; a.t = dst.t; a.p = dst.p; a.perm = dst.perm;
+    a.nxny = c->d_nxny;
+    a.tile_start = c->d_tile_start;
+    a.states = c->d_tile_states;
+    a.scale = o->scale;
+    a.seed_res_x = o->sensor_res_x; a.seed_res_y = o->sensor_res_y;
+    a.guard_res_x = o->guard_res_x; a.guard_res_y = o->guard_res_y;
+    a.min_events = o->min_events;
+    a.max_px = (int32_t)max_px;
+    {
+        ProfScope ps(c, 0, c->n);
+        if (launch_tile_optimizer(a, nt, c->stream) != 0) return fail(c, BF_ERR_HIP, "cannot configure the tile kernel");
+    }
+    HIP_TRY(c, hipGetLastError());
+    std::vector<DevState> st((size_t)nt);
+    HIP_TRY(c, hipMemcpyAsync(st.data(), c->d_tile_states, (size_t)nt * sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nt; ++i) {
+        if (models_out) models_out[i] = st[(size_t)i].model;
+        if (infos_out) {
+            bf_run_info inf;
+            memset(&inf, 0, sizeof(inf));
+            inf.rc = st[(size_t)i].rc;
+            inf.iterations = st[(size_t)i].hot.it;
+            inf.x_divider = st[(size_t)i].x_div; inf.y_divider = st[(size_t)i].y_div;
+            inf.rot_divider = st[(size_t)i].rot_div; inf.div_divider = st[(size_t)i].div_div;
+            infos_out[i] = inf;
+        }
+    }
+    c->n_valid = true;
+    c->pending_warp = false;
+    c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
+    c->degenerate = false;
+    c->use_binned = false;
+    return BF_OK;
 }
 
 int bf_get_trace(bf_ctx* c, bf_trace_rec* out, int32_t cap, int32_t* written) {

@@ -71,6 +71,26 @@ void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,
                       hipStream_t s);
 
+// bf_tiles.hip -- grid of independent per-tile optimizers (BASELINE config 4)
+struct TileGrid {
+    int32_t rows, cols, res_x, res_y;   // tile (r, c) = (fr_x * rows / res_x, fr_y * cols / res_y)
+};
+struct TileArgs {
+    const uint32_t* xy;
+    const int32_t* t;
+    float2* p;
+    const uint32_t* perm;
+    double2* nxny;
+    const uint32_t* tile_start;
+    DevState* states;                  // one per tile: in = zero-model template, out = final state
+    int32_t scale, seed_res_x, seed_res_y, guard_res_x, guard_res_y, min_events, max_px;
+};
+void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm_in, long long n, const TileGrid& g,
+                      uint32_t* hist, uint32_t* start, uint32_t* cursor, uint32_t* oxy, int32_t* ot, float2* op,
+                      uint32_t* operm, hipStream_t s);
+int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s);
+void launch_fill_states(DevState* states, const DevState& tmpl, int nt, hipStream_t s);
+
 // bf_binned.hip
 int bin_kernel_setup();
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);

@@ -1,0 +1,333 @@
+// bf_tiles.hip -- BASELINE config 4: a grid of independent local optimizers over one slice
+// (the reference's multi-object task queue, dvs_flow.h:200-231: one OptimizerRolling per
+// (events, model) pair).  MI355X-native form: events are counting-sorted by sensor tile and ONE
+// WORK-GROUP PER TILE runs the whole OptimizerRolling::run loop on chip -- the tile's time /
+// count image lives in LDS (LDS atomics for the scatter, same integer accumulators), the
+// stencil and moment reduction are work-group local, and the same model_update() code as the
+// global path advances the model.  No grid-wide synchronisation, no host round trip: 1024 tiles
+// = 1024 concurrent gradient-descent loops.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "bf_device.h"
+#include "bf_device_fns.h"
+#include "bf_kernels.h"
+
+namespace bf {
+
+__device__ __forceinline__ int tile_of(uint32_t xy, const TileGrid& g) {
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    int tr = (int)(((long long)x * g.rows) / g.res_x), tc = (int)(((long long)y * g.cols) / g.res_y);
+    tr = min(max(tr, 0), g.rows - 1);
+    tc = min(max(tc, 0), g.cols - 1);
+    return tr * g.cols + tc;
+}
+
+__global__ __launch_bounds__(kThreads) void k_tile_count(const uint32_t* __restrict__ xy, long long n, TileGrid g,
+                                                         uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t s_h[];
+    const int nt = g.rows * g.cols;
+    for (int i = threadIdx.x; i < nt; i += kThreads) s_h[i] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+        atomicAdd(&s_h[tile_of(xy[i], g)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += kThreads)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ hist, int nt, uint32_t* __restrict__ start,
+                                                    uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t s_sum[1024];
+    const int tid = threadIdx.x;
+    const int per = (nt + 1023) / 1024;
+    uint32_t local = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < nt) local += hist[b];
+    }
+    s_sum[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (tid >= off) ? s_sum[tid - off] : 0u;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - local;
+    for (int k = 0; k < per; ++k) {
+        const int b = tid * per + k;
+        if (b < nt) {
+            start[b] = run;
+            run += hist[b];
+            cursor[b] = 0;
+            hist[b] = 0;
+        }
+    }
+    if (tid == 1023) start[nt] = s_sum[1023];
+}
+
+__global__ __launch_bounds__(kThreads) void k_tile_scatter(const uint32_t* __restrict__ xy, const int32_t* __restrict__ t,
+                                                           const uint32_t* __restrict__ perm_in, long long n, TileGrid g,
+                                                           const uint32_t* __restrict__ start, uint32_t* __restrict__ cursor,
+                                                           uint32_t* __restrict__ oxy, int32_t* __restrict__ ot,
+                                                           float2* __restrict__ op, uint32_t* __restrict__ operm) {
+    extern __shared__ uint32_t s_u[];
+    const int nt = g.rows * g.cols;
+    uint32_t* s_cnt = s_u;
+    uint32_t* s_base = s_u + nt;
+    for (int i = threadIdx.x; i < nt; i += kThreads) s_cnt[i] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * kThreads * 4;
+    uint32_t rank[4];
+    int bin[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * kThreads + threadIdx.x;
+        bin[k] = -1;
+        if (i < n) {
+            bin[k] = tile_of(xy[i], g);
+            rank[k] = atomicAdd(&s_cnt[bin[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += kThreads)
+        if (s_cnt[i]) s_base[i] = start[i] + atomicAdd(&cursor[i], s_cnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * kThreads + threadIdx.x;
+        if (bin[k] >= 0) {
+            const uint32_t o = s_base[bin[k]] + rank[k];
+            oxy[o] = xy[i];
+            ot[o] = t[i];
+            op[o] = make_float2(0.f, 0.f);   // Event::reset
+            operm[o] = perm_in ? perm_in[i] : (uint32_t)i;
+        }
+    }
+}
+
+// One OptimizerRolling (set_cloud, set_time already applied, run) per work-group.
+__global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
+    extern __shared__ unsigned long long s_dyn[];
+    __shared__ DevState s_st;
+    __shared__ Sums s_red[kThreads / 64];
+    __shared__ int s_box[4];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const uint32_t beg = a.tile_start[tile], end = a.tile_start[tile + 1];
+    const int n = (int)(end - beg);
+    unsigned long long* s_ts = s_dyn;                                         // sum of t (i64 as u64)
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_dyn + a.max_px);          // event count
+    float* s_time = reinterpret_cast<float*>(s_cnt + a.max_px);               // time image
+
+    // ---- OptimizerRolling::set_cloud + set_scale (optimizer_rolling.h:248-283) ----
+    int xmin = INT_MAX, xmax = INT_MIN, ymin = INT_MAX, ymax = INT_MIN;
+    for (uint32_t i = beg + tid; i < end; i += kThreads) {
+        const uint32_t v = a.xy[i];
+        const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
+        xmin = min(xmin, x); xmax = max(xmax, x);
+        ymin = min(ymin, y); ymax = max(ymax, y);
+    }
+    xmin = wave_min(xmin); xmax = wave_max(xmax); ymin = wave_min(ymin); ymax = wave_max(ymax);
+    if (tid == 0) { s_box[0] = INT_MAX; s_box[1] = INT_MIN; s_box[2] = INT_MAX; s_box[3] = INT_MIN; }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        atomicMin(&s_box[0], xmin); atomicMax(&s_box[1], xmax);
+        atomicMin(&s_box[2], ymin); atomicMax(&s_box[3], ymax);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        DevState& st = s_st;
+        st = a.states[tile];   // zero model / loop-control template prepared by the host
+        const int s = a.scale;
+        int x_min = a.seed_res_x, y_min = a.seed_res_y, x_max = 0, y_max = 0;   // :252-253
+        if (n > 0) {
+            x_max = max(x_max, s_box[1]); y_max = max(y_max, s_box[3]);
+            x_min = min(x_min, s_box[0]); y_min = min(y_min, s_box[2]);
+        }
+        const int wsx = s * (x_max - x_min), wsy = s * (y_max - y_min);
+        st.hot.scale = s;
+        st.hot.wsx = wsx; st.hot.wsy = wsy;
+        st.hot.R = wsx + s; st.hot.C = wsy + s;
+        st.x_shift = -(double)((x_max - x_min) / 2 + x_min) * (double)s + (double)wsx / 2.0 + (double)(s / 2);
+        st.y_shift = -(double)((y_max - y_min) / 2 + y_min) * (double)s + (double)wsy / 2.0 + (double)(s / 2);
+        st.hot.x_sh = (int)st.x_shift;
+        st.hot.y_sh = (int)st.y_shift;
+        st.hot.tmin = 0;
+        st.n_events = (uint32_t)n;
+        // ---- guards of run() (optimizer_rolling.h:49-58), with run-time RES / minimum ----
+        int rc = 0, done = 0;
+        if ((st.hot.R < s * a.guard_res_x / 15) && (st.hot.C < s * a.guard_res_y / 15)) { rc = BF_SKIPPED; done = 1; }
+        else if (n < a.min_events) { rc = BF_SKIPPED; done = 1; }
+        else if (st.hot.R <= 0 || st.hot.C <= 0 || (long long)st.hot.R * st.hot.C > a.max_px) { rc = BF_ERR_CAPACITY; done = 1; }
+        st.rc = rc;
+        st.hot.done = done;
+    }
+    __syncthreads();
+    const int R = s_st.hot.R, C = s_st.hot.C, P = R * C;
+    const int s = a.scale, hsc = s / 2;
+    const int x_sh = s_st.hot.x_sh, y_sh = s_st.hot.y_sh, wsx = s_st.hot.wsx, wsy = s_st.hot.wsy;
+    const int hR = R / 2, hC = C / 2;
+
+    while (!s_st.hot.done) {
+        const WarpParams wp = s_st.hot.wp;
+        const bool warp = s_st.hot.it > 0;
+        for (int i = tid; i < P; i += kThreads) { s_ts[i] = 0; s_cnt[i] = 0; }
+        __syncthreads();
+        // ---- warp (event.h:99-110,164-168) + point scatter (accel_lib.h:151-166) ----
+        for (uint32_t i = beg + tid; i < end; i += kThreads) {
+            const uint32_t v = a.xy[i];
+            const int32_t ti = a.t[i];
+            float2 q = a.p[i];
+            const uint32_t fx = v & 0xffffu, fy = v >> 16;
+            double pr_x = pr_from_p(fx, q.x), pr_y = pr_from_p(fy, q.y);
+            if (warp) {
+                const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
+                const double qx = wp.c * rx - wp.s * ry;
+                const double qy = wp.s * rx + wp.c * ry;
+                const double nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
+                const double ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
+                const float kx = div_127((float)nx), ky = div_127((float)ny);
+                const float ft = (float)ti;
+                q.x = kx * ft;
+                q.y = ky * ft;
+                a.p[i] = q;
+                pr_x = pr_from_p(fx, q.x);
+                pr_y = pr_from_p(fy, q.y);
+            }
+            const int X = trunc_x86(pr_x * (double)s + (double)x_sh);
+            const int Y = trunc_x86(pr_y * (double)s + (double)y_sh);
+            if (!((X >= wsx + hsc) || (X < hsc) || (Y >= wsy + hsc) || (Y < hsc))) {
+                atomicAdd(&s_ts[X * C + Y], (unsigned long long)(long long)ti);
+                atomicAdd(&s_cnt[X * C + Y], 1u);
+            }
+        }
+        __syncthreads();
+        // ---- s x s box sum + normalise (accel_lib.h:160-175) ----
+        for (int i = tid; i < P; i += kThreads) {
+            const int r = i / C, c = i - r * C;
+            long long ts = 0;
+            uint32_t cn = 0;
+            for (int dr = -hsc; dr <= hsc; ++dr)
+                for (int dc = -hsc; dc <= hsc; ++dc) {
+                    const int rr = r + dr, cc = c + dc;
+                    if (rr >= 0 && rr < R && cc >= 0 && cc < C) {
+                        ts += (long long)s_ts[rr * C + cc];
+                        cn += s_cnt[rr * C + cc];
+                    }
+                }
+            s_time[i] = time_from_sums(cn, ts, 0);
+        }
+        __syncthreads();
+        // ---- gated Scharr (accel_lib.h:513-615) + centre of mass + moments (object_model.cpp) ----
+        Sums sm;
+        sums_zero(sm);
+        for (int i = tid; i < P; i += kThreads) {
+            const int r = i / C, c = i - r * C;
+            const float ctr = s_time[i];
+            if (!valid_px(ctr)) continue;
+            float gx = 0.f, gy = 0.f;
+            if (r >= 1 && r < R - 1 && c >= 1 && c < C - 1) {
+                const float* tp = &s_time[i];
+                const float t00 = tp[-C - 1], t10 = tp[-1], t20 = tp[C - 1];
+                const float t01 = tp[-C], t21 = tp[C];
+                const float t02 = tp[-C + 1], t12 = tp[1], t22 = tp[C + 1];
+                if (valid_px(t00) && valid_px(t10) && valid_px(t20) && valid_px(t01) && valid_px(t21) &&
+                    valid_px(t02) && valid_px(t12) && valid_px(t22)) {
+                    float dx = 0.f, dy = 0.f;
+                    dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
+                    dx = dx + t10 * 0.f;   dy = dy + t10 * 10.f;
+                    dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
+                    dx = dx + t01 * 10.f;  dy = dy + t01 * 0.f;
+                    dx = dx + ctr * 0.f;   dy = dy + ctr * 0.f;
+                    dx = dx + t21 * -10.f; dy = dy + t21 * 0.f;
+                    dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
+                    dx = dx + t12 * 0.f;   dy = dy + t12 * -10.f;
+                    dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
+                    gx = dx;
+                    gy = dy;
+                }
+            }
+            const int ci = r - hR, cj = c - hC;
+            sm.n += 1; sm.sci += ci; sm.scj += cj;
+            const double gxd = (double)gx, gyd = (double)gy;
+            sm.sgx += gxd; sm.sgy += gyd;
+            sm.sigx += (double)ci * gxd; sm.sigy += (double)ci * gyd;
+            sm.sjgx += (double)cj * gxd; sm.sjgy += (double)cj * gyd;
+        }
+        sums_wave_reduce(sm);
+        if ((tid & 63) == 0) s_red[tid >> 6] = sm;
+        __syncthreads();
+        if (tid == 0) {
+            Sums t = s_red[0];
+            for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
+            model_update(&s_st, t, nullptr, 1, 0);   // update_accumulators + iteration_step glue + run() control
+        }
+        __syncthreads();
+    }
+    // ---- final state: the last project_4param_reinit of the loop, n for compute_uv ----
+    const WarpParams wp = s_st.hot.wp;
+    const bool ran = s_st.rc == 0 && s_st.hot.it > 0;
+    for (uint32_t i = beg + tid; i < end; i += kThreads) {
+        double nx = 0.0, ny = 0.0;
+        if (ran) {
+            const uint32_t v = a.xy[i];
+            float2 q = a.p[i];
+            const double pr_x = pr_from_p(v & 0xffffu, q.x), pr_y = pr_from_p(v >> 16, q.y);
+            const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
+            const double qx = wp.c * rx - wp.s * ry;
+            const double qy = wp.s * rx + wp.c * ry;
+            nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
+            ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
+            const float ft = (float)a.t[i];
+            q.x = div_127((float)nx) * ft;
+            q.y = div_127((float)ny) * ft;
+            a.p[i] = q;
+        }
+        a.nxny[a.perm[i]] = make_double2(nx, ny);
+    }
+    if (tid == 0) a.states[tile] = s_st;
+}
+
+__global__ void k_fill_states(DevState* states, DevState tmpl, int nt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt) states[i] = tmpl;
+}
+
+void launch_fill_states(DevState* states, const DevState& tmpl, int nt, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_states, dim3((nt + 63) / 64), dim3(64), 0, s, states, tmpl, nt);
+}
+
+void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm_in, long long n, const TileGrid& g,
+                      uint32_t* hist, uint32_t* start, uint32_t* cursor, uint32_t* oxy, int32_t* ot, float2* op,
+                      uint32_t* operm, hipStream_t s) {
+    const int nt = g.rows * g.cols;
+    long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)blocks), dim3(kThreads), (size_t)nt * 4, s, xy, n, g, hist);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, hist, nt, start, cursor);
+    if (n > 0) {
+        const long long per = (long long)kThreads * 4;
+        hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((n + per - 1) / per)), dim3(kThreads), (size_t)nt * 8, s, xy, t,
+                           perm_in, n, g, start, cursor, oxy, ot, op, operm);
+    }
+}
+
+int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s) {
+    const size_t lds = (size_t)a.max_px * (8 + 4 + 4);
+    static bool raised = false;
+    if (!raised) {
+        hipFuncAttributes at;
+        const void* fn = reinterpret_cast<const void*>(&k_tile_optimizer);
+        if (hipFuncGetAttributes(&at, fn) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes) != hipSuccess)
+            return -1;
+        raised = true;
+    }
+    hipLaunchKernelGGL(k_tile_optimizer, dim3(ntiles), dim3(kThreads), lds, s, a);
+    return 0;
+}
+
+}  // namespace bf

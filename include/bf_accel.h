@@ -209,6 +209,26 @@ int bf_set_model(bf_ctx *ctx, const bf_model *model);
  * Returns info->rc. */
 int bf_run(bf_ctx *ctx, const bf_run_opts *opts, bf_model *model_out, bf_run_info *info);
 
+/* A grid of independent optimizers over the staged slice (BASELINE config 4; the reference's
+ * queue of (events, model) tasks, dvs_flow.h:200-231, with one task per sensor tile).  Events are
+ * bucketed by tile (row = fr_x * grid_rows / sensor_res_x, column likewise); every tile gets its
+ * own OptimizerRolling: set_cloud (bounding box seeded with sensor_res, optimizer_rolling.h:252),
+ * cold start, run() with the guards evaluated against guard_res_x / guard_res_y / min_events (the
+ * reference's RES / 15 and 1000 would skip every small tile).  One work-group per tile runs the
+ * whole loop on chip.  Needs bf_upload_events first (not bf_set_cloud).  models_out / infos_out
+ * hold grid_rows * grid_cols entries (row-major); infos[i].rc is 0, 1 (skipped) or < 0.
+ * Afterwards bf_compute_uv / bf_writeout_events return the per-event results of all tiles. */
+typedef struct bf_tile_opts {
+    int32_t grid_rows, grid_cols;
+    int32_t scale;
+    int32_t sensor_res_x, sensor_res_y;
+    int32_t guard_res_x, guard_res_y;
+    int32_t min_events;
+    int32_t max_iter;        /* <= 0: unlimited */
+    int32_t hard_iter_cap;
+} bf_tile_opts;
+int bf_run_tiles(bf_ctx *ctx, const bf_tile_opts *opts, bf_model *models_out, bf_run_info *infos_out);
+
 /* Records of the last bf_run (opts->trace_cap > 0).  Returns the number written. */
 int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
 

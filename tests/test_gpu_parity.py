@@ -372,3 +372,46 @@ def test_binned_warm_start_bit_identical(accel_mod):
     assert w0[2].iterations == w1[2].iterations and w0[1].as_dict() == w1[1].as_dict()
     for x, y in zip(w0[4], w1[4]):
         assert np.array_equal(x, y)
+
+
+def test_tile_grid_matches_per_tile_oracle(oracle_lib, accel_mod):
+    """BASELINE config 4 in small: an 8 x 8 grid of independent optimizers over one slice; every
+    tile must behave like its own OptimizerRolling (oracle run on the tile's events)."""
+    H, W, s, G = 128, 160, 3, 8
+    sl = synth.make_slice(120000, H, W, 0.020, seed=41, velocity=(-60.0, 110.0))
+    acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    guard = (H // G, W // G)
+    models, infos = acc.run_tiles(G, G, s, (H, W), guard, min_events=200, hard_iter_cap=5000)
+    u, v = acc.compute_uv()
+    tr = np.minimum(sl["fr_x"].astype(np.int64) * G // H, G - 1)
+    tc = np.minimum(sl["fr_y"].astype(np.int64) * G // W, G - 1)
+    tid = tr * G + tc
+    ran = skipped = 0
+    for k in range(G * G):
+        sel = np.nonzero(tid == k)[0]
+        oc = oracle_lib.Cloud(sl["fr_x"][sel], sl["fr_y"][sel], sl["t"][sel])
+        ow = oc.set_cloud(s, H, W)
+        om = oracle_lib.Model()
+        orc, oloop, _ = oc.run(ow, om, res_x=guard[0], res_y=guard[1], min_events=200, hard_cap=5000)
+        orc = accel_mod.BF_ERR_NOCONV if orc < 0 else orc
+        assert infos[k].rc == orc, (k, infos[k].rc, orc)
+        if orc == 1:
+            skipped += 1
+            assert not u[sel].any() and not v[sel].any()
+            continue
+        if orc != 0:
+            continue
+        ran += 1
+        assert abs(infos[k].iterations - oloop.itercount) <= 1, (k, infos[k].iterations, oloop.itercount)
+        ou, ov = oc.compute_uv()
+        if infos[k].iterations == oloop.itercount:
+            assert _flow_close(u[sel], ou, rel=1e-4, abs_=0.05) and _flow_close(v[sel], ov, rel=1e-4, abs_=0.05), k
+        else:
+            assert _flow_close(u[sel], ou, rel=5e-3, abs_=1.0) and _flow_close(v[sel], ov, rel=5e-3, abs_=1.0), k
+    assert ran >= G * G // 2, (ran, skipped)
+    # the run is repeatable bit for bit (integer accumulators, fixed reduction order)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    models2, infos2 = acc.run_tiles(G, G, s, (H, W), guard, min_events=200, hard_iter_cap=5000)
+    assert [m.as_dict() for m in models] == [m.as_dict() for m in models2]
+    acc.close()

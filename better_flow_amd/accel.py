@@ -95,6 +95,7 @@ EXPORTS = [
     "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_tiles", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
+    "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
 ]
 
 _lib = None
@@ -147,6 +148,10 @@ def load():
         L.bf_device_malloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
         L.bf_device_free.argtypes = [C.c_void_p, C.c_void_p]
         L.bf_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.bf_host_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+        L.bf_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.bf_upload_events_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.bf_commit_upload.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -177,6 +182,9 @@ class Accel:
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.L.bf_host_free(self.h, p)
+            self._pinned = []
             self.L.bf_destroy(self.h)
             self.h = None
 
@@ -295,6 +303,23 @@ class Accel:
 
     def synchronize(self):
         self._chk(self.L.bf_synchronize(self.h))
+
+    def pinned_int32(self, n):
+        """A pinned host int32 array of n elements (bf_host_alloc) viewed through numpy."""
+        p = C.c_void_p()
+        self._chk(self.L.bf_host_alloc(self.h, max(4 * n, 16), C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_int32 * n).from_address(p.value))
+        self._pinned = getattr(self, "_pinned", []) + [p]   # released in close()
+        return arr
+
+    def upload_events_async(self, fr_x, fr_y, t_ns, n):
+        """fr_x / fr_y / t_ns: pinned int32 arrays (pinned_int32); returns immediately."""
+        self._chk(self.L.bf_upload_events_async(self.h, _ptr(fr_x), _ptr(fr_y), _ptr(t_ns), int(n)))
+        self._pending_n = getattr(self, "_pending_n", []) + [int(n)]
+
+    def commit_upload(self):
+        self._chk(self.L.bf_commit_upload(self.h))
+        self.n = self._pending_n.pop(0)
 
     def to_device(self, arr):
         """Copy a numpy array into a fresh device buffer; returns the device pointer."""

@@ -64,6 +64,12 @@ struct bf_ctx {
     DevState* d_tile_states = nullptr;
     int tiles_alloc = 0;
     int32_t *d_in_x = nullptr, *d_in_y = nullptr, *d_in_t = nullptr;
+    // streaming: a second staging slot, a copy stream and one event per slot
+    int32_t* d_in2[3] = {nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done[2] = {nullptr, nullptr};
+    long long pending_n[2] = {0, 0};
+    int pend_head = 0, pend_count = 0;   // FIFO of pending async uploads (slot = index & 1)
     double2 *d_nxny = nullptr, *d_uv = nullptr;
     unsigned long long* d_plane[2] = {nullptr, nullptr};
     uint32_t* d_cplane[2] = {nullptr, nullptr};
@@ -442,6 +448,9 @@ void bf_destroy(bf_ctx* c) {
     for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
+    for (int i = 0; i < 2; ++i) if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_hist_ts, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_armed, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
@@ -540,6 +549,59 @@ int bf_upload_events(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, const 
     // host arrays are only borrowed for the duration of the call
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BF_OK;
+}
+
+int bf_host_alloc(bf_ctx* c, int64_t bytes, void** out) {
+    if (!c || !out || bytes <= 0) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return BF_OK;
+}
+
+int bf_host_free(bf_ctx* c, void* ptr) {
+    if (!c) return BF_ERR_ARG;
+    if (ptr) HIP_TRY(c, hipHostFree(ptr));
+    return BF_OK;
+}
+
+int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_ns, int64_t n) {
+    if (!c) return BF_ERR_ARG;
+    if (n <= 0 || !fr_x || !fr_y || !t_ns) return fail(c, BF_ERR_ARG, "bad event arrays");
+    if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
+    if (c->pend_count >= 2) return fail(c, BF_ERR_STATE, "two uploads are already pending");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    }
+    const int slot = (c->pend_head + c->pend_count) & 1;
+    int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
+    int32_t* dy = slot ? c->d_in2[1] : c->d_in_y;
+    int32_t* dt = slot ? c->d_in2[2] : c->d_in_t;
+    const size_t nb = (size_t)n * sizeof(int32_t);
+    HIP_TRY(c, hipMemcpyAsync(dx, fr_x, nb, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(dy, fr_y, nb, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(dt, t_ns, nb, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
+    c->pending_n[slot] = n;
+    c->pend_count++;
+    return BF_OK;
+}
+
+int bf_commit_upload(bf_ctx* c) {
+    if (!c) return BF_ERR_ARG;
+    if (c->pend_count == 0) return fail(c, BF_ERR_STATE, "no upload is pending");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int slot = c->pend_head & 1;
+    // the staging kernel (compute stream) waits for the copy; nothing blocks on the host
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[slot], 0));
+    c->has_noise = false;
+    int rc = stage_common(c, slot ? c->d_in2[0] : c->d_in_x, slot ? c->d_in2[1] : c->d_in_y,
+                          slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot]);
+    c->pend_head++;
+    c->pend_count--;
+    return rc;
 }
 
 int bf_upload_events_device(bf_ctx* c, const int32_t* d_fr_x, const int32_t* d_fr_y, const int32_t* d_t_ns,

@@ -158,6 +158,18 @@ int bf_upload_events(bf_ctx *ctx, const int32_t *fr_x, const int32_t *fr_y, cons
 int bf_upload_events_device(bf_ctx *ctx, const int32_t *d_fr_x, const int32_t *d_fr_y,
                             const int32_t *d_t_ns, int64_t n);
 
+/* Streaming front end (BASELINE config 3): stage the NEXT slice while the current one is being
+ * optimised.  bf_host_alloc returns pinned host memory; bf_upload_events_async copies a slice from
+ * pinned arrays into one of two device staging slots on the ctx's COPY stream and returns at once
+ * (the arrays must stay untouched until the matching bf_commit_upload returns);
+ * bf_commit_upload makes the compute stream wait for the oldest pending copy and stages it
+ * (== bf_upload_events without the blocking copy).  At most two uploads may be pending. */
+int bf_host_alloc(bf_ctx *ctx, int64_t bytes, void **out);
+int bf_host_free(bf_ctx *ctx, void *ptr);
+int bf_upload_events_async(bf_ctx *ctx, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns,
+                           int64_t n);
+int bf_commit_upload(bf_ctx *ctx);
+
 /* OptimizerRolling::set_cloud + set_scale (optimizer_rolling.h:248-283): bounding
  * box over fr (device reduction), window geometry, Event::reset for every event.
  * res_x / res_y seed x_min / y_min (:252).  scale must be odd (:274). */

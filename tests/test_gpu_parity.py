@@ -415,3 +415,45 @@ def test_tile_grid_matches_per_tile_oracle(oracle_lib, accel_mod):
     models2, infos2 = acc.run_tiles(G, G, s, (H, W), guard, min_events=200, hard_iter_cap=5000)
     assert [m.as_dict() for m in models] == [m.as_dict() for m in models2]
     acc.close()
+
+
+def test_streaming_upload_matches_blocking(accel_mod):
+    """Config 3 plumbing: the copy-stream upload (two staging slots) must give exactly the
+    results of the blocking upload over an STM chain of slices."""
+    H, W, s = 180, 240, 3
+    sls = [synth.make_slice(30000, H, W, 0.03, seed=60 + i) for i in range(4)]
+    nmax = max(len(sl["t"]) for sl in sls)
+    acc = accel_mod.Accel(max_events=nmax, max_rows=s * H + s, max_cols=s * W + s)
+
+    def chain(upload):
+        prev, out = None, []
+        for i, sl in enumerate(sls):
+            upload(i, sl)
+            acc.set_cloud(s, H, W)
+            if prev is not None:
+                acc.set_model(prev)
+            rc, prev, info = acc.run()
+            out.append((rc, info.iterations, prev.as_dict()))
+        return out
+
+    ref = chain(lambda i, sl: acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]))
+    pin = [[acc.pinned_int32(nmax) for _ in range(3)] for _ in range(2)]
+
+    def put(i):
+        sl, k = sls[i], i & 1
+        n = len(sl["t"])
+        pin[k][0][:n], pin[k][1][:n], pin[k][2][:n] = sl["fr_x"], sl["fr_y"], sl["t"]
+        acc.upload_events_async(pin[k][0], pin[k][1], pin[k][2], n)
+
+    put(0)
+
+    def up(i, sl):
+        acc.commit_upload()
+        if i + 1 < len(sls):
+            put(i + 1)
+
+    got = chain(up)
+    assert got == ref
+    with pytest.raises(accel_mod.BfError):
+        acc.commit_upload()                       # nothing pending
+    acc.close()

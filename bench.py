@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--scale", type=int, default=3)
     ap.add_argument("--slices", type=int, default=4, help="distinct resident slices per rank")
     ap.add_argument("--poll", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="BASELINE.json config: 2 = 1M-event 346x260 slice (default, the metric's config); "
+                         "5 = 1M-event 1280x720 slices (the 8-GPU farm geometry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     args = ap.parse_args()
@@ -64,6 +67,8 @@ def main():
     import numpy as np
     from better_flow_amd import accel, synth
 
+    if args.config == 5:
+        args.height, args.width = 720, 1280
     H, W, s = args.height, args.width, args.scale
     ndev = accel.device_count()
     if ndev <= 0:
@@ -168,17 +173,27 @@ def main():
             copy_gbps = acc.copy_bandwidth(1 << 30, 5)
         except Exception:
             copy_gbps = None
+        # HBM traffic per launch from the PMC passes (profiles/k1_traffic.json is written by
+        # scripts/collect_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  null if not collected
+        # or not for this workload.
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tj) and (H, W, s, args.events) == (260, 346, 3, 1000000):
+            t_ = json.load(open(tj))
+            traffic = (2.0 * t_["fetch_kb"] + t_["write_kb"]) * 1024.0
         roofline = {
-            "bound": "hbm", "kernel": "k_warp_scatter", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "bound": "hbm", "kernel": "k_bin_warp_scatter (warp + tile-binned LDS scatter)", "achieved": achieved,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "avg_launch_us": k1_s * 1e6, "launches": int(p.warp_scatter_launches),
             "algorithmic_bytes_per_launch": K1_BYTES_PER_EVENT_ITER * ev_per_launch,
             "measured_copy_ceiling_gbps": copy_gbps,
             "per_kernel_us": {
                 "warp_scatter": 1e3 * p.warp_scatter_ms / max(1, p.warp_scatter_launches),
-                "stencil_moments": 1e3 * p.stencil_ms / max(1, p.stencil_launches),
-                "update": 1e3 * p.update_ms / max(1, p.update_launches),
+                "stencil_moments_update": 1e3 * p.stencil_ms / max(1, p.stencil_launches),
             },
+            "note": "durations are hipEvent-bracketed launches on the ctx stream (adds ~1.5 us per launch over "
+                    "rocprofv3's kernel time, see profiles/)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------

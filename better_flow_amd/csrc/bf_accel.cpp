@@ -77,6 +77,8 @@ struct bf_ctx {
     uint32_t* d_count = nullptr;
     Partial* d_partials = nullptr;
     unsigned int* d_ticket = nullptr;
+    unsigned long long* d_tl = nullptr;   // debug timeline (BF_TIMELINE=<file>, `make tl` build)
+    const char* tl_path = nullptr;
     DevState* d_state = nullptr;
     SliceStats* d_stats = nullptr;
     bf_trace_rec* d_trace = nullptr;
@@ -427,6 +429,11 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
         HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
+        c->tl_path = getenv("BF_TIMELINE");
+        if (c->tl_path && *c->tl_path) {
+            HIP_TRY(c, hipMalloc(&c->d_tl, 64 * 2 * 16 * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_tl, 0, 64 * 2 * 16 * sizeof(unsigned long long), c->stream));
+        }
         int r = clear_planes(c);
         if (r != BF_OK) return r;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -445,6 +452,16 @@ void bf_destroy(bf_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_tl) {   // debug timeline dump: launch group slot ticks(100 MHz)
+        std::vector<unsigned long long> tl(64 * 2 * 16);
+        (void)hipMemcpy(tl.data(), c->d_tl, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(c->tl_path, "w")) {
+            for (size_t i = 0; i < tl.size(); ++i)
+                if (tl[i]) fprintf(f, "%zu %zu %zu %llu\n", i / 32, (i / 16) % 2, i % 16, tl[i]);
+            fclose(f);
+        }
+        (void)hipFree(c->d_tl);
+    }
     for (auto& r : c->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
@@ -1053,6 +1070,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 a.st_rw = c->d_state;
                 a.trace = trace;
                 a.update_mode = 1;
+                a.tl = c->d_tl;
+                a.tl_launch = launched_iters;
                 ProfScope ps(c, 1);
                 launch_stencil(a, stencil_src(c, binned), c->stream);
             }

@@ -286,8 +286,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
 // covered by at most 2 x 2 bins) and every slab load of a thread is issued up front.
 template <int HS>
 __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
+    tl_stamp(a.tl, a.tl_launch, 0);
     const HotState hs = a.st->hot;   // one burst of scalar loads, then the branch
     if (a.check_done && hs.done) return;
+    tl_stamp(a.tl, a.tl_launch, 1);
     constexpr int TR = kTileR, TC = kTileC;
     constexpr int H = HS + 1;
     constexpr int PR = TR + 2 * H, PC = TC + 2 * H;
@@ -344,7 +346,9 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
             s_cnt[idx] = cn;
         }
     }
+    tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
+    tl_stamp(a.tl, a.tl_launch, 3);
     for (int idx = tid; idx < TH * TW; idx += kThreads) {
         const int tr = idx / TW, tc = idx - tr * TW;
         const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
         s_time[idx] = tv;
     }
     __syncthreads();
+    tl_stamp(a.tl, a.tl_launch, 4);
     const bool do_zero = a.zero_plane && (a.cur ? hs.ovf_cnt[0] : hs.ovf_cnt[1]) != 0;
     stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
 }

@@ -41,6 +41,17 @@ __device__ __forceinline__ float div_127(float x) {
     return (x == 0.0f || isinf(x)) ? q0 : q;
 }
 
+// (double)ts / 1e9 for an integer nanosecond sum ts (accel_lib.h:162): same sequence; checked on
+// 2^32 pseudo-random integer dividends of all magnitudes plus every integer below 2^26
+// (tests/exhaustive_div.c).  The per-pixel IEEE division expansion was ~1 us of the stencil.
+__device__ __forceinline__ double div_1e9(double x) {
+    constexpr double R = 1.0 / 1000000000.0;
+    const double q0 = x * R;
+    const double r = fma(-q0, 1000000000.0, x);
+    const double q = fma(r, R, q0);
+    return (x == 0.0 || isinf(x)) ? q0 : q;
+}
+
 // Previous / new projected position from the stored f32 product (event.h:167-168):
 //   pr = float(fr) - (kx * float(t)) / 10000.0      (f32 product, f64 divide and subtract)
 __device__ __forceinline__ double pr_from_p(uint32_t fr, float prod) {
@@ -66,6 +77,24 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 constexpr int kTicketGroups = 32;   // arrival counters of the fused reduction (64 B apart)
 
+// Debug timeline: 100 MHz wall-clock stamps of kernel phases for work-groups 0 and `mid`, 16
+// slots per (launch, group).  Compiled in only with -DBF_TIMELINE (`make tl`, BF_TIMELINE=<file> at
+// run time): the stamps cost registers, so the production library does not contain them.
+constexpr int kTlLaunches = 64;
+__device__ __forceinline__ void tl_stamp(unsigned long long* tl, int launch, int slot) {
+#ifdef BF_TIMELINE
+    if (!tl || launch >= kTlLaunches || threadIdx.x != 0) return;
+    const int nb = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+    int g = -1;
+    if (me == 0) g = 0;
+    else if (me == nb / 2) g = 1;
+    if (g < 0) return;
+    tl[((size_t)launch * 2 + g) * 16 + slot] = wall_clock64();
+#else
+    (void)tl; (void)launch; (void)slot;
+#endif
+}
+
 struct Sums {
     long long n, sci, scj;
     double sgx, sgy, sigx, sigy, sjgx, sjgy;
@@ -87,12 +116,71 @@ __device__ __forceinline__ void sums_wave_reduce(Sums& s) {
     s.sjgx = wave_sum(s.sjgx); s.sjgy = wave_sum(s.sjgy);
 }
 
+// Work-group reduction of a Sums through LDS, transposed: every thread stores its nine values
+// ([field][thread]), then 9 x (T/64) lanes each add one wave's 64 values of one field in a fixed
+// order, then the per-wave results are added in wave order.  The wave64 __shfl_down tree needs
+// 107 ds_bpermute_b32 per wave (~1.9 us of the stencil kernel, every wave doing it at once); this
+// moves ~6x fewer bytes through the LDS.  Every thread gets the total.
+constexpr int kSumFields = 9;
+template <int THREADS>
+__device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_buf /* 9 * THREADS */,
+                                                  unsigned long long* s_part /* 9 * THREADS / 64 */) {
+    const int tid = threadIdx.x;
+    constexpr int W = THREADS / 64;
+    s_buf[0 * THREADS + tid] = (unsigned long long)sm.n;
+    s_buf[1 * THREADS + tid] = (unsigned long long)sm.sci;
+    s_buf[2 * THREADS + tid] = (unsigned long long)sm.scj;
+    s_buf[3 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sgx);
+    s_buf[4 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sgy);
+    s_buf[5 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sigx);
+    s_buf[6 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sigy);
+    s_buf[7 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sjgx);
+    s_buf[8 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sjgy);
+    __syncthreads();
+    if (tid < kSumFields * W) {
+        const int f = tid / W, w = tid - f * W;
+        const unsigned long long* src = &s_buf[f * THREADS + w * 64];
+        unsigned long long acc;
+        if (f < 3) {   // exact integer sums
+            long long a = 0;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) a += (long long)src[j];
+            acc = (unsigned long long)a;
+        } else {       // doubles in a fixed order: 4 interleaved accumulators, then a fixed tree
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < 64; j += 4) {
+                a0 += __longlong_as_double((long long)src[j]);
+                a1 += __longlong_as_double((long long)src[j + 1]);
+                a2 += __longlong_as_double((long long)src[j + 2]);
+                a3 += __longlong_as_double((long long)src[j + 3]);
+            }
+            acc = (unsigned long long)__double_as_longlong((a0 + a1) + (a2 + a3));
+        }
+        s_part[f * W + w] = acc;
+    }
+    __syncthreads();
+    Sums t;
+    long long in_[3] = {0, 0, 0};
+    double d_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) in_[f] += (long long)s_part[f * W + w];
+#pragma unroll
+        for (int f = 3; f < kSumFields; ++f) d_[f - 3] += __longlong_as_double((long long)s_part[f * W + w]);
+    }
+    t.n = in_[0]; t.sci = in_[1]; t.scj = in_[2];
+    t.sgx = d_[0]; t.sgy = d_[1]; t.sigx = d_[2]; t.sigy = d_[3]; t.sjgx = d_[4]; t.sjgy = d_[5];
+    return t;
+}
+
 // Mean time of one pixel from its exact integer sums (accel_lib.h:162,172): the f32 sum of
 // seconds is the integer-ns sum rounded once, then the f32 divide by the count.
 __device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_biased, long long tmin) {
     if (cnt == 0) return 0.f;
     const long long ts = tsum_biased + (long long)cnt * tmin;
-    const float sum_s = (float)((double)ts / 1000000000.0);
+    const float sum_s = (float)div_1e9((double)ts);
     return sum_s / (float)cnt;
 }
 
@@ -100,8 +188,8 @@ __device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_bia
 // ObjectModel::update_accumulators (object_model.h:48-53), the glue of iteration_step
 // (optimizer_rolling.h:328-346) and the loop control of run() (optimizer_rolling.h:61-101).
 // Runs on ONE thread (the reducer).  mode 0: model only (AccelLib::fast_model).
-__device__ __noinline__ void model_update(DevState* st, const Sums& t, bf_trace_rec* trace, int mode,
-                                          int cur) {
+__device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, bf_trace_rec* trace, int mode,
+                                                   int cur) {
     bf_model m = st->model;
     const int R = st->hot.R, C = st->hot.C;
     const double dn = (double)t.n;   // cnt == 0 -> 0/0 = NaN, as in the reference (assert off)
@@ -205,6 +293,16 @@ __device__ __noinline__ void model_update(DevState* st, const Sums& t, bf_trace_
     }
 }
 
+// The update on an LDS copy of the state: with the state in global memory every field access of
+// model_update_local is a dependent round trip (3.2 us measured), and a register copy spills
+// (the stencil kernel is at ~120 VGPRs).  Called by ONE thread; s_copy is work-group LDS.
+__device__ __forceinline__ void model_update(DevState* st, DevState* s_copy, const Sums& t, bf_trace_rec* trace,
+                                             int mode, int cur) {
+    *s_copy = *st;
+    model_update_local(s_copy, t, trace, mode, cur);
+    *st = *s_copy;
+}
+
 // Second half of the stencil kernels: given the time tile in LDS ((TR+2) x (TC+2), halo 1),
 // the gated 3x3 Scharr (accel_lib.h:513-615), the centre-of-mass and moment sums
 // (object_model.cpp:4-39,103-126), optional gradient output, clearing of the other plane
@@ -281,19 +379,26 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         }
     }
     if (a.partials) {
-        sums_wave_reduce(sm);
-        if ((tid & 63) == 0) s_red[tid >> 6] = sm;
-        __syncthreads();
+        tl_stamp(a.tl, a.tl_launch, 5);
+        __shared__ unsigned long long s_rbuf[kSumFields * kThreads];
+        __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
+        const Sums blk = block_reduce_sums<kThreads>(sm, s_rbuf, s_rpart);
+        tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
         if (!a.ticket) {   // stand-alone pass: partials only, reduced by k_update
             if (tid == 0) {
-                Sums t = s_red[0];
-                for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
-                Partial& o = a.partials[me];
-                o.n = t.n; o.sci = t.sci; o.scj = t.scj;
-                o.sgx = t.sgx; o.sgy = t.sgy;
-                o.sigx = t.sigx; o.sigy = t.sigy; o.sjgx = t.sjgx; o.sjgy = t.sjgy;
+                const Sums t = blk;
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partials) + me;
+                const size_t st_ = (size_t)nblk;
+                o[0 * st_] = (unsigned long long)t.n; o[1 * st_] = (unsigned long long)t.sci;
+                o[2 * st_] = (unsigned long long)t.scj;
+                o[3 * st_] = (unsigned long long)__double_as_longlong(t.sgx);
+                o[4 * st_] = (unsigned long long)__double_as_longlong(t.sgy);
+                o[5 * st_] = (unsigned long long)__double_as_longlong(t.sigx);
+                o[6 * st_] = (unsigned long long)__double_as_longlong(t.sigy);
+                o[7 * st_] = (unsigned long long)__double_as_longlong(t.sjgx);
+                o[8 * st_] = (unsigned long long)__double_as_longlong(t.sjgy);
             }
             return;
         }
@@ -304,9 +409,10 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         // ticket; the reducer reads the payload with agent-scope (L1-bypassing) loads.
         __shared__ int s_last;
         if (tid == 0) {
-            Sums t = s_red[0];
-            for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(&a.partials[me]);
+            const Sums t = blk;
+            // structure-of-arrays: field k of work-group i at [k * nblk + i], so that the reducer's
+            // loads are coalesced (with 80-byte records every load touched 64 cache lines)
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partials) + me;
             const unsigned long long v[9] = {
                 (unsigned long long)t.n, (unsigned long long)t.sci, (unsigned long long)t.scj,
                 (unsigned long long)__double_as_longlong(t.sgx), (unsigned long long)__double_as_longlong(t.sgy),
@@ -314,7 +420,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
                 (unsigned long long)__double_as_longlong(t.sjgx), (unsigned long long)__double_as_longlong(t.sjgy)};
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                __hip_atomic_store(&o[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&o[(size_t)k * nblk], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
             // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
@@ -334,6 +440,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             s_last = last;
         }
         __syncthreads();
+        tl_stamp(a.tl, a.tl_launch, 7);
         if (!s_last) return;
         Sums acc;
         sums_zero(acc);
@@ -344,10 +451,11 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             for (int k = 0; k < 4; ++k) {
                 const int i = base + k * kThreads + tid;
                 const unsigned long long* src =
-                    reinterpret_cast<const unsigned long long*>(&a.partials[i < nblk ? i : 0]);
+                    reinterpret_cast<const unsigned long long*>(a.partials) + (i < nblk ? i : 0);
 #pragma unroll
                 for (int j = 0; j < 9; ++j)
-                    q[k][j] = (i < nblk) ? __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    q[k][j] = (i < nblk) ? __hip_atomic_load(&src[(size_t)j * nblk], __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)
                                          : 0ull;
             }
 #pragma unroll
@@ -361,15 +469,24 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
                 acc.sjgy += __longlong_as_double((long long)q[k][8]);
             }
         }
-        sums_wave_reduce(acc);
-        __syncthreads();   // s_red is reused
-        if ((tid & 63) == 0) s_red[tid >> 6] = acc;
-        __syncthreads();
+        if (tid == 0 && a.tl) {
+#ifdef BF_TIMELINE
+            if (a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 10] = wall_clock64();
+#endif
+        }
+        __syncthreads();   // s_rbuf / s_rpart are reused
+        const Sums tot = block_reduce_sums<kThreads>(acc, s_rbuf, s_rpart);
         if (tid == 0) {
-            Sums t = s_red[0];
-            for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
+            const Sums t = tot;
             a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
-            model_update(a.st_rw, t, a.trace, a.update_mode, a.cur);
+#ifdef BF_TIMELINE
+            if (a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 11] = wall_clock64();
+#endif
+            __shared__ DevState s_state;
+            model_update(a.st_rw, &s_state, t, a.trace, a.update_mode, a.cur);
+#ifdef BF_TIMELINE
+            if (a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 12] = wall_clock64();
+#endif
         }
     }
 }

@@ -51,6 +51,8 @@ struct StencilArgs {
     DevState* st_rw;
     bf_trace_rec* trace;
     int update_mode;                   // 1: full iteration_step / run() update, 0: model only
+    unsigned long long* tl;            // debug timeline (BF_TIMELINE builds), usually NULL
+    int tl_launch;
     // SRC 3 (tile-binned): per-bin slabs + the overflow planes of buffer `cur`
     const unsigned long long* slabs;
     BinGrid g;

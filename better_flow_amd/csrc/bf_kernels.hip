@@ -267,7 +267,17 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(DevState* st, const Part
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = base + k * kUpdThreads + tid;
-            if (i < nblocks) q[k] = partials[i];
+            if (i < nblocks) {   // structure-of-arrays records written by the stencil kernels
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(partials) + i;
+                q[k].n = (long long)src[0 * (size_t)nblocks]; q[k].sci = (long long)src[1 * (size_t)nblocks];
+                q[k].scj = (long long)src[2 * (size_t)nblocks];
+                q[k].sgx = __longlong_as_double((long long)src[3 * (size_t)nblocks]);
+                q[k].sgy = __longlong_as_double((long long)src[4 * (size_t)nblocks]);
+                q[k].sigx = __longlong_as_double((long long)src[5 * (size_t)nblocks]);
+                q[k].sigy = __longlong_as_double((long long)src[6 * (size_t)nblocks]);
+                q[k].sjgx = __longlong_as_double((long long)src[7 * (size_t)nblocks]);
+                q[k].sjgy = __longlong_as_double((long long)src[8 * (size_t)nblocks]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -286,7 +296,8 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(DevState* st, const Part
     Sums t = s_red[0];
     for (int w = 1; w < kUpdThreads / 64; ++w) sums_add(t, s_red[w]);
 
-    model_update(st, t, trace, mode, cur);
+    __shared__ DevState s_state;
+    model_update(st, &s_state, t, trace, mode, cur);
 }
 
 // Event::compute_uv, event.h:135-142.

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
         if (tid == 0) {
             Sums t = s_red[0];
             for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
-            model_update(&s_st, t, nullptr, 1, 0);   // update_accumulators + iteration_step glue + run() control
+            model_update_local(&s_st, t, nullptr, 1, 0);   // update_accumulators + iteration_step glue + run() control (state in LDS)
         }
         __syncthreads();
     }

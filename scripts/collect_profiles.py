@@ -28,6 +28,18 @@ open(os.path.join(out, tag + "_pmc_hbm_traffic.txt"), "w").write(
     "`python scripts/run_once.py 1` (one cold 1M-event 346x260 slice).  Values are the counters' KB per dispatch;\n"
     "'live' excludes the early-exit launches after convergence.  On gfx950 FETCH_SIZE under-reports wide coalesced\n"
     "reads by 2x (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n\n" + "\n".join(lines) + "\n")
+# per-launch HBM traffic of the dominant kernel for bench.py's roofline.traffic
+k1 = {}
+for cname, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
+    fs = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**/*counter_collection.csv"), recursive=True)
+    if fs:
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0]))
+             if r["Counter_Name"] == cname and "k_bin_warp_scatter<true" in r["Kernel_Name"] and float(r["Counter_Value"]) > 64]
+        if v:
+            k1["fetch_kb" if cname == "FETCH_SIZE" else "write_kb"] = statistics.median(v)
+if len(k1) == 2:
+    k1["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, median over live k_bin_warp_scatter launches (config 2)"
+    json.dump(k1, open(os.path.join(out, "k1_traffic.json"), "w"), indent=1)
 bl = os.path.join(ROOT, "gpurun_out/prof_bench.log")
 if os.path.exists(bl):
     for ln in open(bl):

@@ -1,0 +1,26 @@
+import sys, os, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["BF_TIMELINE"] = "/tmp/bf_tl.txt"
+os.environ["BF_ACCEL_LIB"] = os.path.join(ROOT, "better_flow_amd", "libbf_accel_tl.so")
+from better_flow_amd import accel, synth
+N, H, W, s = 1000000, 260, 346, 3
+sl = synth.make_slice(N, H, W, 0.030, seed=1)
+acc = accel.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+opts = acc.default_opts(); opts.res_x, opts.res_y = H, W
+opts.max_iter = 40
+acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]); acc.set_cloud(s, H, W)
+rc, m, info = acc.run(opts)
+acc.close()
+d = collections.defaultdict(dict)
+for ln in open("/tmp/bf_tl.txt"):
+    L, g, slot, t = [int(x) for x in ln.split()]
+    d[(L, g)][slot] = t
+names = {0: "entry", 1: "state", 2: "slabs loaded+LDS", 3: "sync", 4: "time img+sync", 5: "tail pixels", 6: "wave reduce+sync", 7: "published+ticket",
+         10: "LAST:partials loaded", 11: "LAST:reduced", 12: "LAST:update done"}
+for L in (10, 11, 20, 21):
+    base = min(d[(L, 0)].values()) if d.get((L, 0)) else None
+    for g in (0, 1):
+        st = d.get((L, g), {})
+        if st and base:
+            print("launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st)))

@@ -25,7 +25,38 @@ static inline float div127(float x) {
     return (x == 0.0f || isinf(x)) ? q0 : q;
 }
 
+/* (c)  (double)ts / 1e9 with ts an integer number of nanoseconds (accel_lib.h:162): the dividend
+ * is an integer |ts| < 2^53, too many to enumerate; checked on 2^32 pseudo-random integers over
+ * all magnitudes plus every integer in [0, 2^26) (the one-event-per-pixel range of a 67 ms slice). */
+static inline double div1e9(double x) {
+    const double R = 1.0 / 1000000000.0;
+    double q0 = x * R;
+    double r = fma(-q0, 1000000000.0, x);
+    double q = fma(r, R, q0);
+    return (x == 0.0 || isinf(x)) ? q0 : q;
+}
+
 int main(void) {
+    unsigned long long bad_c = 0;
+#pragma omp parallel for reduction(+ : bad_c)
+    for (long long i = 0; i < (1LL << 32); ++i) {
+        unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0xD1342543DE82EF95ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const int sh = (int)(i & 63) % 52;                 /* all magnitudes up to 2^52 */
+        long long v = (long long)(z >> 11) >> sh;
+        if (i & 64) v = -v;
+        double x = (double)v;
+        double a = x / 1000000000.0, b = div1e9(x);
+        if (memcmp(&a, &b, 8) != 0) bad_c++;
+        if (i < (1LL << 26)) {
+            x = (double)i;
+            a = x / 1000000000.0; b = div1e9(x);
+            if (memcmp(&a, &b, 8) != 0) bad_c++;
+        }
+    }
+    printf("div1e9   (f64, integer dividends): %llu mismatches in 2^32 samples + [0, 2^26)\n", bad_c);
     unsigned long long bad_a = 0, bad_b = 0;
     float max_bad_b = 0.f, min_bad_b = INFINITY, max_bad_a = 0.f;
 #pragma omp parallel for reduction(+ : bad_a, bad_b) reduction(max : max_bad_b, max_bad_a) reduction(min : min_bad_b)
@@ -51,5 +82,5 @@ int main(void) {
     }
     printf("div10000 (f64): %llu mismatches (max |f| %.9g)\n", bad_a, (double)max_bad_a);
     printf("div127   (f32): %llu mismatches (|f| in [%.9g, %.9g])\n", bad_b, (double)min_bad_b, (double)max_bad_b);
-    return (bad_a || bad_b) ? 1 : 0;
+    return (bad_a || bad_b || bad_c) ? 1 : 0;
 }

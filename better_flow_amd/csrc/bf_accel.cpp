@@ -431,8 +431,8 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
-            HIP_TRY(c, hipMalloc(&c->d_tl, 64 * 2 * 16 * sizeof(unsigned long long)));
-            HIP_TRY(c, hipMemsetAsync(c->d_tl, 0, 64 * 2 * 16 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMalloc(&c->d_tl, 2 * 64 * 2 * 16 * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_tl, 0, 2 * 64 * 2 * 16 * sizeof(unsigned long long), c->stream));
         }
         int r = clear_planes(c);
         if (r != BF_OK) return r;
@@ -453,11 +453,11 @@ void bf_destroy(bf_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tl) {   // debug timeline dump: launch group slot ticks(100 MHz)
-        std::vector<unsigned long long> tl(64 * 2 * 16);
+        std::vector<unsigned long long> tl(2 * 64 * 2 * 16);   // [kernel][launch][group][slot]
         (void)hipMemcpy(tl.data(), c->d_tl, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(c->tl_path, "w")) {
             for (size_t i = 0; i < tl.size(); ++i)
-                if (tl[i]) fprintf(f, "%zu %zu %zu %llu\n", i / 32, (i / 16) % 2, i % 16, tl[i]);
+                if (tl[i]) fprintf(f, "%zu %zu %zu %zu %llu\n", i / 2048, (i / 32) % 64, (i / 16) % 2, i % 16, tl[i]);
             fclose(f);
         }
         (void)hipFree(c->d_tl);
@@ -1058,7 +1058,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             if (binned) {
                 ProfScope ps(c, 0, c->n);
                 launch_bin_warp_scatter(ev_sets(c), c->d_bin_start, c->d_slabs, c->d_plane[buf],
-                                        c->d_cplane[buf], c->d_state, c->grid, buf, warp, 1, c->opt_bin_threads, c->stream);
+                                        c->d_cplane[buf], c->d_state, c->grid, buf, warp, 1, c->opt_bin_threads,
+                                        c->d_tl ? c->d_tl + 64 * 2 * 16 : nullptr, launched_iters, c->stream);
             } else {
                 ProfScope ps(c, 0, c->n);
                 launch_warp_scatter(ws_args(c, buf, 1), warp, true, false, c->stream);

@@ -194,10 +194,11 @@ template <bool WARP, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     EvSets sets, const uint32_t* __restrict__ bin_start, unsigned long long* __restrict__ slabs,
     unsigned long long* __restrict__ ovf_plane, uint32_t* __restrict__ ovf_cplane, DevState* st,
-    BinGrid g, int cur, int check_done) {
+    BinGrid g, int cur, int check_done, unsigned long long* tl, int tl_launch) {
     extern __shared__ unsigned long long s_tile[];
     const int L = g.L, LL = g.L * g.L;
     const int b = blockIdx.x;
+    tl_stamp(tl, tl_launch, 0);
     // everything the block needs from global memory is requested up front, in one burst
     const uint32_t beg = bin_start[b], end = bin_start[b + 1];
     const HotState hs = st->hot;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
         for (int i = threadIdx.x; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
     }
     if (check_done && hs.done) return;
+    tl_stamp(tl, tl_launch, 1);
     const EvSetPtrs ev = sets.s[hs.cs ^ hs.flip];
     const uint32_t* __restrict__ xy = ev.xy;
     const int32_t* __restrict__ t = ev.t;
@@ -251,7 +253,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
                 const float ft = (float)ti;
                 q.x = kx * ft;
                 q.y = ky * ft;
-                p[i] = q;
+                // write-through as well (see the slab flush below)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(&p[i]),
+                                   ((unsigned long long)__float_as_uint(q.y) << 32) | (unsigned long long)__float_as_uint(q.x),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pr_x = pr_from_p(fx, q.x);
                 pr_y = pr_from_p(fy, q.y);
             }
@@ -272,12 +277,18 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
         }
     }
     if (n_ovf) atomicAdd(&st->hot.ovf_cnt[cur], n_ovf);
+    tl_stamp(tl, tl_launch, 2);
     __syncthreads();
-    {   // flush: the whole tile, plain 16-byte stores (nothing to zero, no atomics)
-        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_tile);
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(slabs + (size_t)b * (size_t)LL);
-        for (int i = threadIdx.x; i < LL / 2; i += THREADS) dst[i] = src[i];
+    tl_stamp(tl, tl_launch, 3);
+    {   // flush: the whole tile (nothing to zero, no atomics).  WRITE-THROUGH stores (agent-scope
+        // relaxed = global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat
+        // dirty in the L2s until the end of the kernel, and their write-back stretched the kernel
+        // boundary to ~5.6 us (measured; "B / 6 TB/s" in the MI355X notes).
+        unsigned long long* dst = slabs + (size_t)b * (size_t)LL;
+        for (int i = threadIdx.x; i < LL; i += THREADS)
+            __hip_atomic_store(&dst[i], s_tile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    tl_stamp(tl, tl_launch, 4);
 }
 
 // K3 (binned): merge the slabs covering each pixel, box-sum, normalise, then the shared tail.
@@ -407,22 +418,23 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 
 template <int THREADS>
 static void launch_bws(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane, uint32_t* ovf_cplane,
-                       DevState* st, const BinGrid& g, int cur, bool warp, int check_done, hipStream_t s) {
+                       DevState* st, const BinGrid& g, int cur, bool warp, int check_done, unsigned long long* tl,
+                       int tl_launch, hipStream_t s) {
     const size_t lds = (size_t)g.L * g.L * sizeof(unsigned long long);
     if (warp)
         hipLaunchKernelGGL((k_bin_warp_scatter<true, THREADS>), dim3(g.nbins), dim3(THREADS), lds, s, sets,
-                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done);
+                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
     else
         hipLaunchKernelGGL((k_bin_warp_scatter<false, THREADS>), dim3(g.nbins), dim3(THREADS), lds, s, sets,
-                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done);
+                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
 }
 
 void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane,
                              uint32_t* ovf_cplane, DevState* st, const BinGrid& g, int cur, bool warp,
-                             int check_done, int threads, hipStream_t s) {
-    if (threads >= 1024) launch_bws<1024>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, s);
-    else if (threads >= 512) launch_bws<512>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, s);
-    else launch_bws<256>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, s);
+                             int check_done, int threads, unsigned long long* tl, int tl_launch, hipStream_t s) {
+    if (threads >= 1024) launch_bws<1024>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, tl, tl_launch, s);
+    else if (threads >= 512) launch_bws<512>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, tl, tl_launch, s);
+    else launch_bws<256>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, tl, tl_launch, s);
 }
 
 template <bool W, int T>

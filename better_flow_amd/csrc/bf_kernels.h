@@ -102,7 +102,7 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs,
                              unsigned long long* ovf_plane, uint32_t* ovf_cplane, DevState* st,
                              const BinGrid& g, int cur, bool warp, int check_done, int threads,
-                             hipStream_t s);
+                             unsigned long long* tl, int tl_launch, hipStream_t s);
 
 void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 

@@ -14,13 +14,18 @@ rc, m, info = acc.run(opts)
 acc.close()
 d = collections.defaultdict(dict)
 for ln in open("/tmp/bf_tl.txt"):
-    L, g, slot, t = [int(x) for x in ln.split()]
-    d[(L, g)][slot] = t
+    kern, L, g, slot, t = [int(x) for x in ln.split()]
+    d[(kern, L, g)][slot] = t
 names = {0: "entry", 1: "state", 2: "slabs loaded+LDS", 3: "sync", 4: "time img+sync", 5: "tail pixels", 6: "wave reduce+sync", 7: "published+ticket",
          10: "LAST:partials loaded", 11: "LAST:reduced", 12: "LAST:update done"}
-for L in (10, 11, 20, 21):
-    base = min(d[(L, 0)].values()) if d.get((L, 0)) else None
+k1names = {0: "entry", 1: "state+zero", 2: "events done", 3: "sync", 4: "flushed"}
+for L in (20, 21):
+    base = min(d[(1, L, 0)].values()) if d.get((1, L, 0)) else None
     for g in (0, 1):
-        st = d.get((L, g), {})
+        st = d.get((1, L, g), {})
         if st and base:
-            print("launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st)))
+            print("K1b launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (k1names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st)))
+    for g in (0, 1):
+        st = d.get((0, L, g), {})
+        if st and base:
+            print("K3  launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st)))

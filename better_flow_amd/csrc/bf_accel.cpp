@@ -1047,11 +1047,20 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
     DevState fin;
+    bool want_rebin = false;
+    int skip_rebin_checks = 0;
     for (int batch = 0;; ++batch) {
-        if (binned) {   // runs only if the update asked for it (and always before iteration 1)
+        // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
+        // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
+        // when a polled snapshot shows the update asking for one.  The request is predictive
+        // (0.6 x margin of drift), which covers the one-to-two batches of polling lag; anything
+        // that still escapes takes the exact overflow path.
+        if (binned && (batch == 0 || want_rebin)) {
             int rc = enqueue_rebin(c, perm_at_start);
             if (rc != BF_OK) return rc;
             inf.launches += 4;
+            want_rebin = false;
+            skip_rebin_checks = 1;   // the next snapshot predates this re-bin
         }
         for (int k = 0; k < o.poll_interval; ++k) {
             const bool warp = first ? first_warp : true;
@@ -1093,6 +1102,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             fin = snap;
             break;
         }
+        if (skip_rebin_checks > 0) --skip_rebin_checks;
+        else if (binned && snap.hot.need_rebin) want_rebin = true;
         if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
             return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
     }

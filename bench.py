@@ -42,11 +42,14 @@ def main():
     ap.add_argument("--height", type=int, default=260)
     ap.add_argument("--width", type=int, default=346)
     ap.add_argument("--scale", type=int, default=3)
-    ap.add_argument("--slices", type=int, default=4, help="distinct resident slices per rank")
+    ap.add_argument("--slices", type=int, default=6, help="distinct resident slices per rank")
     ap.add_argument("--poll", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="BASELINE.json config: 2 = 1M-event 346x260 slice (default, the metric's config); "
                          "5 = 1M-event 1280x720 slices (the 8-GPU farm geometry)")
+    ap.add_argument("--concurrent", type=int, default=4,
+                    help="independent slices in flight per GPU: one host thread + bf_ctx + HIP stream each "
+                         "(the slice farm of SURVEY 8(e) applied inside one GPU; a step = this many slices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     args = ap.parse_args()
@@ -77,41 +80,66 @@ def main():
     slices = [synth.make_slice(args.events, H, W, 0.030, seed=1 + rank * 1000 + i)
               for i in range(args.slices)]
     nmax = max(len(sl["t"]) for sl in slices)
-    acc = accel.Accel(device=device, max_events=nmax, max_rows=s * H + s, max_cols=s * W + s)
+    import threading
+    B = max(1, args.concurrent)
+    accs = [accel.Accel(device=device, max_events=nmax, max_rows=s * H + s, max_cols=s * W + s) for _ in range(B)]
+    acc = accs[0]
     resident = []
     for sl in slices:
         resident.append((acc.to_device(sl["fr_x"]), acc.to_device(sl["fr_y"]),
                          acc.to_device(sl["t"].astype(np.int32)), len(sl["t"])))
-    opts = acc.default_opts()
-    opts.res_x, opts.res_y, opts.poll_interval, opts.want_uv = H, W, args.poll, 1
 
-    def step(i, warm_model=None, max_iter=-1):
+    def make_opts(a):
+        o = a.default_opts()
+        o.res_x, o.res_y, o.poll_interval, o.want_uv = H, W, args.poll, 1
+        return o
+    all_opts = [make_opts(a) for a in accs]
+    opts = all_opts[0]
+
+    def step(i, warm_model=None, max_iter=-1, lane=0):
+        a, o = accs[lane], all_opts[lane]
         dx, dy, dt, n = resident[i % len(resident)]
-        acc.upload_events_device(dx, dy, dt, n)
-        acc.set_cloud(s, H, W)
+        a.upload_events_device(dx, dy, dt, n)
+        a.set_cloud(s, H, W)
         if warm_model is not None:
-            acc.set_model(warm_model)
-        opts.max_iter = max_iter
-        rc, m, info = acc.run(opts)
+            a.set_model(warm_model)
+        o.max_iter = max_iter
+        rc, m, info = a.run(o)
         return n, m, info
 
+    def run_steps(first, count):
+        """`count` steps; a step = B independent cold slices, one per lane, in flight together
+        (ctypes releases the GIL inside the C-ABI calls).  Returns (events, iterations)."""
+        tot = [[0, 0] for _ in range(B)]
+
+        def lane_loop(lane):
+            for k in range(count):
+                n, _, info = step(first + k + lane, lane=lane)   # consecutive steps of a lane: different slices
+                tot[lane][0] += n
+                tot[lane][1] += info.iterations
+        if B == 1:
+            lane_loop(0)
+        else:
+            th = [threading.Thread(target=lane_loop, args=(l,)) for l in range(B)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+        for a in accs:
+            a.synchronize()
+        return sum(x[0] for x in tot), sum(x[1] for x in tot)
+
     def barrier():
-        acc.synchronize()
+        for a in accs:
+            a.synchronize()
         if dist is not None:
             dist.barrier()
 
-    # ---- timed region: exactly K cold-start steps -------------------------------------
-    for i in range(args.warmup):
-        step(i)
+    # ---- timed region: exactly K cold-start steps (each step = B slices in flight) ----------
+    run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    events = 0
-    iters = 0
-    for i in range(args.steps):
-        n, m, info = step(i)
-        events += n
-        iters += info.iterations
-    acc.synchronize()
+    events, iters = run_steps(args.warmup, args.steps)
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
@@ -125,36 +153,70 @@ def main():
     else:
         events_all, iters_all = float(events), float(iters)
 
-    # ---- other regimes (untimed extras; N = 1 semantics per rank) ----------------------
+    # ---- other regimes (untimed extras, rank 0): B independent chains in flight, like the steps ----
     regimes = {}
     if rank == 0:
-        # warm: consecutive slices of one stream, each started from the previous model (STM)
-        _, m_prev, _ = step(0)
-        acc.synchronize()
-        t1 = time.perf_counter()
-        wev = wit = 0
         reps = max(4, min(args.steps, 16))
-        for i in range(1, 1 + reps):
-            n, m_prev, info = step(i, warm_model=m_prev)
-            wev += n
-            wit += info.iterations
-        acc.synchronize()
-        dtw = time.perf_counter() - t1
-        regimes["warm_stm"] = {"mevents_per_s": wev / dtw / 1e6, "iterations_per_slice": wit / reps,
-                               "ms_per_slice": 1e3 * dtw / reps}
-        # capped: the reference's real-time setting max_iter = 10 (ros bf_visualizer.cpp:103)
-        acc.synchronize()
+
+        def run_regime(warm, max_iter):
+            tot = [[0, 0] for _ in range(B)]
+
+            def lane_loop(lane):
+                prev = None
+                if warm:   # consecutive slices of one stream, each started from the previous model (STM)
+                    _, prev, _ = step(lane, lane=lane)
+                for k in range(reps):
+                    n, m, info = step(1 + k + lane, warm_model=prev if warm else None, max_iter=max_iter, lane=lane)
+                    if warm:
+                        prev = m
+                    tot[lane][0] += n
+                    tot[lane][1] += info.iterations
+            for a in accs:
+                a.synchronize()
+            th = [threading.Thread(target=lane_loop, args=(l,)) for l in range(B)]
+            t1 = time.perf_counter()
+            if warm:   # the cold first slice of every chain is not part of the warm regime
+                pass
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            for a in accs:
+                a.synchronize()
+            dt = time.perf_counter() - t1
+            return sum(x[0] for x in tot), sum(x[1] for x in tot), dt
+
+        # warm: time only the warm slices -> run the cold heads first, outside the clock
+        heads = []
+        for lane in range(B):
+            _, m0, _ = step(lane, lane=lane)
+            heads.append(m0)
+        for a in accs:
+            a.synchronize()
+        tot = [[0, 0] for _ in range(B)]
+
+        def warm_loop(lane):
+            prev = heads[lane]
+            for k in range(reps):
+                n, prev, info = step(1 + k + lane, warm_model=prev, lane=lane)   # slice k+1 of this chain
+                tot[lane][0] += n
+                tot[lane][1] += info.iterations
+        th = [threading.Thread(target=warm_loop, args=(l,)) for l in range(B)]
         t1 = time.perf_counter()
-        cev = cit = 0
-        for i in range(reps):
-            n, _, info = step(i, max_iter=10)
-            cev += n
-            cit += info.iterations
-        acc.synchronize()
-        dtc = time.perf_counter() - t1
-        regimes["capped_max_iter_10"] = {"mevents_per_s": cev / dtc / 1e6,
-                                         "iterations_per_slice": cit / reps,
-                                         "ms_per_slice": 1e3 * dtc / reps}
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for a in accs:
+            a.synchronize()
+        dtw = time.perf_counter() - t1
+        wev, wit = sum(x[0] for x in tot), sum(x[1] for x in tot)
+        regimes["warm_stm"] = {"mevents_per_s": wev / dtw / 1e6, "iterations_per_slice": wit / (reps * B),
+                               "ms_per_slice_per_chain": 1e3 * dtw / reps, "chains_in_flight": B}
+        # capped: the reference's real-time setting max_iter = 10 (ros bf_visualizer.cpp:103)
+        cev, cit, dtc = run_regime(False, 10)
+        regimes["capped_max_iter_10"] = {"mevents_per_s": cev / dtc / 1e6, "iterations_per_slice": cit / (reps * B),
+                                         "ms_per_slice_per_chain": 1e3 * dtc / reps, "chains_in_flight": B}
 
     # ---- roofline of the dominant kernel (warp+scatter), hipEvent-bracketed launches -----
     roofline = None
@@ -208,7 +270,7 @@ def main():
         _, oloop, _ = oc.run(ow, om, max_iter=args.cpu_iters - 1, res_x=H, res_y=W)
         dtc = time.perf_counter() - tc
         per_iter = dtc / max(1, oloop.itercount)
-        full_iters = iters / max(1, args.steps)          # the GPU run's iterations per slice
+        full_iters = iters / max(1, args.steps * B)      # the GPU run's iterations per slice
         cpu_baseline = {
             "value": len(sl["t"]) / (per_iter * full_iters) / 1e6, "unit": "Mevents/s",
             "cores": 1, "kind": "port",
@@ -234,12 +296,15 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%d-event 30 ms slice, %dx%d, scale %d, global-flow gradient descent, "
-                            "cold start (STM off) to the reference loop's own termination; one slice "
-                            "per step per GPU, slices resident in HBM" % (args.events, W, H, s),
-                "events_per_slice": events_all / (args.steps * world),
-                "iterations_per_slice": iters_all / (args.steps * world),
-                "event_iterations_per_s": events_all / (args.steps * world) * iters_all / elapsed,
-                "parallelism": "slice-parallel x%d, no collectives" % world,
+                            "cold start (STM off) to the reference loop's own termination; a step = %d "
+                            "independent slices per GPU in flight together, slices resident in HBM"
+                            % (args.events, W, H, s, B),
+                "slices_per_step_per_gpu": B,
+                "events_per_slice": events_all / (args.steps * world * B),
+                "iterations_per_slice": iters_all / (args.steps * world * B),
+                "event_iterations_per_s": events_all / (args.steps * world * B) * iters_all / elapsed,
+                "parallelism": "slice-parallel: %d GPU(s) x %d concurrent slice contexts (HIP streams) per GPU, "
+                               "no collectives" % (world, B),
             },
             "regimes": regimes,
             "roofline": roofline,
@@ -248,7 +313,8 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    acc.close()
+    for a in accs:
+        a.close()
 
 
 if __name__ == "__main__":

@@ -457,3 +457,74 @@ def test_streaming_upload_matches_blocking(accel_mod):
     with pytest.raises(accel_mod.BfError):
         acc.commit_upload()                       # nothing pending
     acc.close()
+
+
+def test_full_size_config2(oracle_lib, accel_mod):
+    """BASELINE config 2 at full size (1M events, 346x260, scale 3): event-count image bit-exact,
+    time image within 1e-6, first iterations of the loop on the oracle's trajectory, binned and
+    global-atomic scatters bit-identical, runs repeatable."""
+    H, W, s = 260, 346, 3
+    sl = synth.make_slice(1000000, H, W, 0.030, seed=1)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, s)
+    for prm in ((0.0, 0.0, 0.0, 0.0, 0.0, 0.0), (0.27, -0.55, 129.0, 172.0, 2.0e-4, 2.5e-5)):
+        oc.project_4param_reinit(*prm)
+        acc.project_4param_reinit(*prm)
+        otime, ocnt = oc.get_time_img(ow)
+        gtime, gcnt = acc.get_time_img()
+        assert np.array_equal(gcnt, ocnt.astype(np.uint32))
+        one = ocnt == 1.0
+        assert np.array_equal(gtime[one], otime[one])
+        np.testing.assert_allclose(gtime, otime, rtol=1e-6, atol=0)
+        assert int(gcnt.max()) > 20 and int(gcnt.sum()) > 8000000
+    acc.close()
+    K = 12
+    oc2 = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    ow2 = oc2.set_cloud(s, H, W)
+    om = oracle_lib.Model()
+    orc, oloop, otr = oc2.run(ow2, om, max_iter=K, res_x=H, res_y=W, trace_cap=K + 1)
+    runs = {}
+    for name, opts in (("binned", dict(binned=1)), ("atomics", dict(binned=0)), ("binned2", dict(binned=1))):
+        a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+        for k, v in opts.items():
+            a2.set_option(k, v)
+        a2.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        a2.set_cloud(s, H, W)
+        o = a2.default_opts()
+        o.res_x, o.res_y, o.max_iter, o.trace_cap = H, W, K, K + 1
+        rc, m, info = a2.run(o)
+        runs[name] = (rc, info.iterations, m.as_dict(), [t_.model.as_dict() for t_ in a2.get_trace(K + 1)], a2.compute_uv())
+        a2.close()
+    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4]
+    assert np.array_equal(runs["binned"][4][0], runs["atomics"][4][0])
+    assert runs["binned"][1] == oloop.itercount == K + 1
+    for k in range(K + 1):
+        g, o_ = runs["binned"][3][k], otr[k].model
+        assert g["cnt"] == o_.cnt, k
+        for f in ("dx", "dy", "rot", "div", "total_dx", "total_dy", "total_rot", "total_div"):
+            assert abs(g[f] - getattr(o_, f)) <= 1e-6 * max(abs(getattr(o_, f)), 1e-4), (k, f, g[f], getattr(o_, f))
+
+
+def test_concurrent_contexts_match_sequential(accel_mod):
+    """Several slice contexts in flight on one GPU (bench.py --concurrent): same results as one
+    after the other."""
+    import threading
+    H, W, s = 180, 240, 3
+    sls = [synth.make_slice(50000, H, W, 0.04, seed=80 + i) for i in range(4)]
+
+    def solve(sl, out, k):
+        a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        a.set_cloud(s, H, W)
+        rc, m, info = a.run()
+        out[k] = (rc, info.iterations, m.as_dict(), a.compute_uv()[0].sum())
+        a.close()
+
+    seq, par = {}, {}
+    for k, sl in enumerate(sls):
+        solve(sl, seq, k)
+    th = [threading.Thread(target=solve, args=(sl, par, k)) for k, sl in enumerate(sls)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert par == seq

@@ -50,6 +50,13 @@ struct bf_ctx {
     bool opt_bin_predict = true;
     int opt_bin_tile = 64, opt_bin_margin = 8, opt_bin_threads = 1024;
     bool use_binned = false;         // decided per slice in bf_set_cloud
+    // whole loop in one cooperative launch (bf_persist.hip)
+    bool opt_persist = false;        // measured slower than the multi-kernel loop: opt-in
+    int opt_persist_threads = 1024;
+    bool use_persist = false;        // decided per slice in bf_set_cloud
+    unsigned int* d_bar = nullptr;   // grid-barrier counters
+    int persist_key[3] = {0, 0, 0};  // (L, scale, threads) the cached co-residency limit is for
+    int persist_max = 0;
     BinGrid grid;
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
@@ -172,6 +179,7 @@ int prof_fold(bf_ctx* c) {
                     c->prof.warp_scatter_events += (uint64_t)r.nev; break;
             case 1: c->prof.stencil_ms += ms; c->prof.stencil_launches++; break;
             case 2: c->prof.update_ms += ms; c->prof.update_launches++; break;
+            case 4: c->prof.persist_ms += ms; c->prof.persist_launches++; break;
             default: c->prof.other_ms += ms; c->prof.other_launches++; break;
         }
         c->ev_pool.push_back(r.a);
@@ -470,7 +478,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_hist_ts, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
@@ -499,6 +507,15 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         if (value != 16 && value != 32 && value != 64 && value != 128)
             return fail(c, BF_ERR_ARG, "bin_tile must be 16, 32, 64 or 128");
         c->opt_bin_tile = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "persist")) {
+        c->opt_persist = value != 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "persist_threads")) {
+        if (value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "persist_threads must be 512 or 1024");
+        c->opt_persist_threads = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "bin_predict")) {
@@ -745,6 +762,16 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
             if (rc == BF_OK) rc = ensure_bin_buffers(c, g);
             if (rc != BF_OK) return rc;
             c->grid = g;
+        }
+        c->use_persist = false;
+        if (c->use_binned && c->opt_persist) {
+            const int key[3] = {g.L, scale, c->opt_persist_threads};
+            if (memcmp(key, c->persist_key, sizeof(key)) != 0) {
+                c->persist_max = persist_max_groups(g, scale, c->opt_persist_threads, c->device);
+                memcpy(c->persist_key, key, sizeof(key));
+            }
+            c->use_persist = g.nbins <= c->persist_max;
+            if (c->use_persist && !c->d_bar) HIP_TRY(c, hipMalloc(&c->d_bar, 4096));
         }
         h.hot.binned = c->use_binned ? 1 : 0;
         h.n_events = (uint32_t)c->n;
@@ -1043,13 +1070,64 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     bool first = true;
     bf_trace_rec* trace = o.trace_cap > 0 ? c->d_trace : nullptr;
     int launched_iters = 0;
+    DevState fin;
+    if (c->use_persist) {
+        // The whole loop in one cooperative launch; it comes back when the loop is done or the
+        // update wants the events re-sorted (the device-gated re-bin kernels that follow do it).
+        int gx, gy;
+        stencil_grid(w.scale_img_x, w.scale_img_y, &gx, &gy);
+        for (int round = 0;; ++round) {
+            int rc = enqueue_rebin(c, perm_at_start);   // round 0: builds the bins
+            if (rc != BF_OK) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->d_bar, 0, 4096, c->stream));
+            PersistArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.sets = ev_sets(c);
+            pa.bin_start = c->d_bin_start;
+            pa.slabs = c->d_slabs;
+            for (int i = 0; i < 2; ++i) { pa.ovf_plane[i] = c->d_plane[i]; pa.ovf_cplane[i] = c->d_cplane[i]; }
+            pa.st = c->d_state;
+            pa.partials = reinterpret_cast<unsigned long long*>(c->d_partials);
+            pa.bar = c->d_bar;
+            pa.trace = trace;
+            pa.tl = c->d_tl;
+            pa.g = c->grid;
+            pa.cur0 = buf;
+            pa.first_nowarp = (first && !first_warp) ? 1 : 0;
+            pa.max_iters = INT_MAX;
+            pa.gx = gx; pa.gy = gy;
+            {
+                ProfScope ps(c, 4);
+                HIP_TRY(c, launch_persist(pa, w.scale, c->opt_persist_threads, c->stream));
+            }
+            inf.launches += 5;
+            HIP_TRY(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(DevState), hipMemcpyDeviceToHost,
+                                      c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            inf.polls++;
+            const DevState& snap = c->h_state[0];
+            if (c->prof_mode == 1) {
+                c->prof.persist_iterations += (uint64_t)(snap.hot.it - launched_iters);
+                c->prof.persist_events += (uint64_t)(snap.hot.it - launched_iters) * (uint64_t)c->n;
+            }
+            if (snap.hot.it == launched_iters && !snap.hot.done)
+                return fail(c, BF_ERR_HIP, "single-launch loop made no progress (grid barrier timed out?)");
+            launched_iters = snap.hot.it;
+            buf = b0 ^ (snap.hot.it & 1);
+            first = false;
+            if (snap.hot.done) {
+                fin = snap;
+                break;
+            }
+            if (round > 100000) return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
+        }
+    }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
-    DevState fin;
     bool want_rebin = false;
     int skip_rebin_checks = 0;
-    for (int batch = 0;; ++batch) {
+    for (int batch = 0; !c->use_persist; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
         // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
         // when a polled snapshot shows the update asking for one.  The request is predictive

@@ -124,8 +124,8 @@ __device__ __forceinline__ void sums_wave_reduce(Sums& s) {
 constexpr int kSumFields = 9;
 template <int THREADS>
 __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_buf /* 9 * THREADS */,
-                                                  unsigned long long* s_part /* 9 * THREADS / 64 */) {
-    const int tid = threadIdx.x;
+                                                  unsigned long long* s_part /* 9 * THREADS / 64 */,
+                                                  const int tid /* 0 .. THREADS-1 within its buffers */) {
     constexpr int W = THREADS / 64;
     s_buf[0 * THREADS + tid] = (unsigned long long)sm.n;
     s_buf[1 * THREADS + tid] = (unsigned long long)sm.sci;
@@ -303,6 +303,105 @@ __device__ __forceinline__ void model_update(DevState* st, DevState* s_copy, con
     *st = *s_copy;
 }
 
+// One pixel of the gated 3x3 Scharr (accel_lib.h:513-615) and its contribution to the centre-of-
+// mass and moment sums (object_model.cpp:4-39,103-126).  tp points at the pixel inside an LDS time
+// tile whose row pitch is TW (halo 1 all round); (gr, gc) is the pixel in the R x C image.
+template <int TW>
+__device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int R, int C, int hR, int hC, Sums& sm,
+                                           float& gx, float& gy) {
+    const float ctr = tp[0];
+    gx = 0.f;
+    gy = 0.f;
+    const bool v = valid_px(ctr);
+    if (v && gr >= 1 && gr < R - 1 && gc >= 1 && gc < C - 1) {
+        // accel_lib.h:594-604: k = column offset (outer), l = row offset (inner),
+        // idx = 3k + l; sharr_x = {3,0,-3,10,0,-10,3,0,-3},
+        // sharr_y = {3,10,3,0,0,0,-3,-10,-3}; any tap <= 1e-6 -> gradient stays 0.
+        const float t00 = tp[-TW - 1], t10 = tp[-1], t20 = tp[TW - 1];
+        const float t01 = tp[-TW], t21 = tp[TW];
+        const float t02 = tp[-TW + 1], t12 = tp[1], t22 = tp[TW + 1];
+        const bool all = valid_px(t00) && valid_px(t10) && valid_px(t20) &&
+                         valid_px(t01) && valid_px(t21) && valid_px(t02) &&
+                         valid_px(t12) && valid_px(t22);
+        if (all) {
+            float dx = 0.f, dy = 0.f;
+            // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
+            dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
+            dx = dx + t10 * 0.f;   dy = dy + t10 * 10.f;
+            dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
+            // k = 1 (column c)
+            dx = dx + t01 * 10.f;  dy = dy + t01 * 0.f;
+            dx = dx + ctr * 0.f;   dy = dy + ctr * 0.f;
+            dx = dx + t21 * -10.f; dy = dy + t21 * 0.f;
+            // k = 2 (column c+1)
+            dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
+            dx = dx + t12 * 0.f;   dy = dy + t12 * -10.f;
+            dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
+            gx = dx;
+            gy = dy;
+        }
+    }
+    if (v) {
+        // object_model.cpp:22-30 and :112-116 in one pass, centred coordinates
+        const int ci = gr - hR, cj = gc - hC;
+        sm.n += 1;
+        sm.sci += ci;
+        sm.scj += cj;
+        const double gxd = (double)gx, gyd = (double)gy;
+        sm.sgx += gxd;
+        sm.sgy += gyd;
+        sm.sigx += (double)ci * gxd;
+        sm.sigy += (double)ci * gyd;
+        sm.sjgx += (double)cj * gxd;
+        sm.sjgy += (double)cj * gyd;
+    }
+}
+
+// Publishes one work-group's reduced sums as field-major (structure-of-arrays) partials with
+// write-through stores: field k of work-group i at [k * nblk + i].
+__device__ __forceinline__ void publish_partial(unsigned long long* partials, int nblk, int me, const Sums& t) {
+    unsigned long long* o = partials + me;
+    const unsigned long long v[9] = {
+        (unsigned long long)t.n, (unsigned long long)t.sci, (unsigned long long)t.scj,
+        (unsigned long long)__double_as_longlong(t.sgx), (unsigned long long)__double_as_longlong(t.sgy),
+        (unsigned long long)__double_as_longlong(t.sigx), (unsigned long long)__double_as_longlong(t.sigy),
+        (unsigned long long)__double_as_longlong(t.sjgx), (unsigned long long)__double_as_longlong(t.sjgy)};
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        __hip_atomic_store(&o[(size_t)k * nblk], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The reducer's first step: thread tid of 256 adds partials tid, tid + 256, ... in a fixed order
+// (agent-scope loads: the partials were published by other work-groups of the same launch).
+__device__ __forceinline__ Sums gather_partials(const unsigned long long* partials, int nblk, int tid) {
+    Sums acc;
+    sums_zero(acc);
+    for (int base = 0; base < nblk; base += kThreads * 4) {
+        unsigned long long q[4][9];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * kThreads + tid;
+            const unsigned long long* src = partials + (i < nblk ? i : 0);
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                q[k][j] = (i < nblk) ? __hip_atomic_load(&src[(size_t)j * nblk], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)
+                                     : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc.n += (long long)q[k][0]; acc.sci += (long long)q[k][1]; acc.scj += (long long)q[k][2];
+            acc.sgx += __longlong_as_double((long long)q[k][3]);
+            acc.sgy += __longlong_as_double((long long)q[k][4]);
+            acc.sigx += __longlong_as_double((long long)q[k][5]);
+            acc.sigy += __longlong_as_double((long long)q[k][6]);
+            acc.sjgx += __longlong_as_double((long long)q[k][7]);
+            acc.sjgy += __longlong_as_double((long long)q[k][8]);
+        }
+    }
+    return acc;
+}
+
 // Second half of the stencil kernels: given the time tile in LDS ((TR+2) x (TC+2), halo 1),
 // the gated 3x3 Scharr (accel_lib.h:513-615), the centre-of-mass and moment sums
 // (object_model.cpp:4-39,103-126), optional gradient output, clearing of the other plane
@@ -322,55 +421,11 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         const int lr = pidx / TC, lc = pidx - lr * TC;
         const int gr = r0 + lr, gc = c0 + lc;
         if (gr < R && gc < C) {
-            const float* tp = &s_time[(lr + 1) * TW + (lc + 1)];
-            const float ctr = tp[0];
-            float gx = 0.f, gy = 0.f;
-            const bool v = valid_px(ctr);
-            if (v && gr >= 1 && gr < R - 1 && gc >= 1 && gc < C - 1) {
-                // accel_lib.h:594-604: k = column offset (outer), l = row offset (inner),
-                // idx = 3k + l; sharr_x = {3,0,-3,10,0,-10,3,0,-3},
-                // sharr_y = {3,10,3,0,0,0,-3,-10,-3}; any tap <= 1e-6 -> gradient stays 0.
-                const float t00 = tp[-TW - 1], t10 = tp[-1], t20 = tp[TW - 1];
-                const float t01 = tp[-TW], t21 = tp[TW];
-                const float t02 = tp[-TW + 1], t12 = tp[1], t22 = tp[TW + 1];
-                const bool all = valid_px(t00) && valid_px(t10) && valid_px(t20) &&
-                                 valid_px(t01) && valid_px(t21) && valid_px(t02) &&
-                                 valid_px(t12) && valid_px(t22);
-                if (all) {
-                    float dx = 0.f, dy = 0.f;
-                    // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
-                    dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
-                    dx = dx + t10 * 0.f;   dy = dy + t10 * 10.f;
-                    dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
-                    // k = 1 (column c)
-                    dx = dx + t01 * 10.f;  dy = dy + t01 * 0.f;
-                    dx = dx + ctr * 0.f;   dy = dy + ctr * 0.f;
-                    dx = dx + t21 * -10.f; dy = dy + t21 * 0.f;
-                    // k = 2 (column c+1)
-                    dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
-                    dx = dx + t12 * 0.f;   dy = dy + t12 * -10.f;
-                    dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
-                    gx = dx;
-                    gy = dy;
-                }
-            }
+            float gx, gy;
+            stencil_px<TW>(&s_time[(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, sm, gx, gy);
             if (a.gx_out) {
                 a.gx_out[(size_t)gr * C + gc] = gx;
                 a.gy_out[(size_t)gr * C + gc] = gy;
-            }
-            if (v) {
-                // object_model.cpp:22-30 and :112-116 in one pass, centred coordinates
-                const int ci = gr - hR, cj = gc - hC;
-                sm.n += 1;
-                sm.sci += ci;
-                sm.scj += cj;
-                const double gxd = (double)gx, gyd = (double)gy;
-                sm.sgx += gxd;
-                sm.sgy += gyd;
-                sm.sigx += (double)ci * gxd;
-                sm.sigy += (double)ci * gyd;
-                sm.sjgx += (double)cj * gxd;
-                sm.sjgy += (double)cj * gyd;
             }
             if (do_zero) {
                 a.zero_plane[(size_t)gr * C + gc] = 0ull;
@@ -382,7 +437,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         tl_stamp(a.tl, a.tl_launch, 5);
         __shared__ unsigned long long s_rbuf[kSumFields * kThreads];
         __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
-        const Sums blk = block_reduce_sums<kThreads>(sm, s_rbuf, s_rpart);
+        const Sums blk = block_reduce_sums<kThreads>(sm, s_rbuf, s_rpart, tid);
         tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
@@ -409,18 +464,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         // ticket; the reducer reads the payload with agent-scope (L1-bypassing) loads.
         __shared__ int s_last;
         if (tid == 0) {
-            const Sums t = blk;
-            // structure-of-arrays: field k of work-group i at [k * nblk + i], so that the reducer's
-            // loads are coalesced (with 80-byte records every load touched 64 cache lines)
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partials) + me;
-            const unsigned long long v[9] = {
-                (unsigned long long)t.n, (unsigned long long)t.sci, (unsigned long long)t.scj,
-                (unsigned long long)__double_as_longlong(t.sgx), (unsigned long long)__double_as_longlong(t.sgy),
-                (unsigned long long)__double_as_longlong(t.sigx), (unsigned long long)__double_as_longlong(t.sigy),
-                (unsigned long long)__double_as_longlong(t.sjgx), (unsigned long long)__double_as_longlong(t.sjgy)};
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                __hip_atomic_store(&o[(size_t)k * nblk], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish_partial(reinterpret_cast<unsigned long long*>(a.partials), nblk, me, blk);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
             // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
@@ -442,40 +486,15 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         __syncthreads();
         tl_stamp(a.tl, a.tl_launch, 7);
         if (!s_last) return;
-        Sums acc;
-        sums_zero(acc);
-        // fixed summation order (thread-strided, then the wave / LDS trees): bitwise repeatable
-        for (int base = 0; base < nblk; base += kThreads * 4) {
-            unsigned long long q[4][9];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = base + k * kThreads + tid;
-                const unsigned long long* src =
-                    reinterpret_cast<const unsigned long long*>(a.partials) + (i < nblk ? i : 0);
-#pragma unroll
-                for (int j = 0; j < 9; ++j)
-                    q[k][j] = (i < nblk) ? __hip_atomic_load(&src[(size_t)j * nblk], __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)
-                                         : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc.n += (long long)q[k][0]; acc.sci += (long long)q[k][1]; acc.scj += (long long)q[k][2];
-                acc.sgx += __longlong_as_double((long long)q[k][3]);
-                acc.sgy += __longlong_as_double((long long)q[k][4]);
-                acc.sigx += __longlong_as_double((long long)q[k][5]);
-                acc.sigy += __longlong_as_double((long long)q[k][6]);
-                acc.sjgx += __longlong_as_double((long long)q[k][7]);
-                acc.sjgy += __longlong_as_double((long long)q[k][8]);
-            }
-        }
+        // fixed summation order (thread-strided, then the LDS trees): bitwise repeatable
+        const Sums acc = gather_partials(reinterpret_cast<const unsigned long long*>(a.partials), nblk, tid);
         if (tid == 0 && a.tl) {
 #ifdef BF_TIMELINE
             if (a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 10] = wall_clock64();
 #endif
         }
         __syncthreads();   // s_rbuf / s_rpart are reused
-        const Sums tot = block_reduce_sums<kThreads>(acc, s_rbuf, s_rpart);
+        const Sums tot = block_reduce_sums<kThreads>(acc, s_rbuf, s_rpart, tid);
         if (tid == 0) {
             const Sums t = tot;
             a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)

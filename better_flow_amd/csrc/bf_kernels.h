@@ -104,6 +104,29 @@ void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsi
                              const BinGrid& g, int cur, bool warp, int check_done, int threads,
                              unsigned long long* tl, int tl_launch, hipStream_t s);
 
+// bf_persist.hip -- the whole loop in one cooperative launch
+constexpr int kPersistUR = 8;   // register-resident events per thread at 1024 threads (16 at 512)
+struct PersistArgs {
+    EvSets sets;
+    const uint32_t* bin_start;
+    unsigned long long* slabs;          // per-tile slabs; only the rings are exchanged
+    unsigned long long* ovf_plane[2];   // overflow planes (double buffered), as in the binned path
+    uint32_t* ovf_cplane[2];
+    DevState* st;
+    unsigned long long* partials;       // field-major, a.gx * a.gy records
+    unsigned int* bar;                  // grid-barrier counters, zeroed by the host before the launch
+    bf_trace_rec* trace;
+    unsigned long long* tl;             // debug timeline (BF_TIMELINE builds)
+    BinGrid g;
+    int cur0;                           // plane buffer the first iteration scatters overflow into
+    int first_nowarp;                   // first iteration of a cold run: scatter only
+    int max_iters;
+    int gx, gy;                         // stencil tile grid (16 x 64 tiles): partial indexing
+};
+size_t persist_lds_bytes(const BinGrid& g, int scale, int threads);
+int persist_max_groups(const BinGrid& g, int scale, int threads, int device);
+hipError_t launch_persist(const PersistArgs& a, int scale, int threads, hipStream_t s);
+
 void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 
 }  // namespace bf

@@ -100,6 +100,10 @@ typedef struct bf_profile {
     double update_ms;        uint64_t update_launches;
     double other_ms;         uint64_t other_launches;
     uint64_t warp_scatter_events;   /* sum over launches of events processed */
+    /* single-launch loop ("persist"): one launch runs many iterations */
+    double persist_ms;       uint64_t persist_launches;
+    uint64_t persist_iterations;    /* iterations executed inside those launches */
+    uint64_t persist_events;        /* sum over launches of events x iterations */
 } bf_profile;
 
 /* ---- life cycle -------------------------------------------------------------- */
@@ -139,6 +143,12 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 64).
  *   "bin_margin"   LDS margin around a bin's tile (even, default 8); events drifting
  *                  further take the exact overflow path and trigger a re-bin.
+ *   "persist"      1: when the tile grid fits the GPU (one resident work-group per 64 x 64
+ *                  tile), bf_run executes the whole loop in ONE cooperative launch with the
+ *                  events held in registers (bf_persist.hip).  Results are bit-identical to the
+ *                  default (0: one launch per stage), which is faster on MI355X because the
+ *                  loop is instruction-issue bound, not launch bound.
+ *   "persist_threads"  work-group size of that launch (1024 default, or 512).
  *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x margin
  *                  (bounded analytically), i.e. before they overflow; 0: re-bin only on
  *                  observed overflow.

@@ -528,3 +528,32 @@ def test_concurrent_contexts_match_sequential(accel_mod):
     for t_ in th:
         t_.join()
     assert par == seq
+
+
+def test_single_launch_loop_bit_identical(accel_mod):
+    """Option "persist": the whole loop in one cooperative launch (events in registers, ring exchange
+    between resident tiles, every work-group running the update) gives the same bits as the default
+    multi-kernel loop -- model, iteration count, dividers, trace and per-event flow."""
+    H, W, s = 260, 346, 3
+    for n, seed, max_iter in ((1000000, 1, 60), (120000, 5, -1)):
+        sl = synth.make_slice(n, H, W, 0.030, seed=seed)
+        runs = {}
+        for name, opts in (("multi", dict(persist=0)), ("single", dict(persist=1)),
+                           ("single512", dict(persist=1, persist_threads=512))):
+            a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+            for k, v in opts.items():
+                a.set_option(k, v)
+            a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+            a.set_cloud(s, H, W)
+            o = a.default_opts()
+            o.res_x, o.res_y, o.max_iter, o.trace_cap = H, W, max_iter, 64
+            rc, m, info = a.run(o)
+            u, v = a.compute_uv()
+            runs[name] = (rc, info.iterations, info.x_divider, info.rot_divider, m.as_dict(),
+                          [t_.model.as_dict() for t_ in a.get_trace(64)], u.tobytes(), v.tobytes())
+            if name != "multi":
+                assert info.launches < 200, info.launches   # really the single-launch path
+            a.close()
+        assert runs["single"] == runs["multi"]
+        assert runs["single512"] == runs["multi"]
+        assert runs["multi"][1] > 30

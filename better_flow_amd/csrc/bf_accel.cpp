@@ -439,8 +439,8 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
-            HIP_TRY(c, hipMalloc(&c->d_tl, 2 * 64 * 2 * 16 * sizeof(unsigned long long)));
-            HIP_TRY(c, hipMemsetAsync(c->d_tl, 0, 2 * 64 * 2 * 16 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMalloc(&c->d_tl, 3 * 64 * 2 * 16 * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_tl, 0, 3 * 64 * 2 * 16 * sizeof(unsigned long long), c->stream));
         }
         int r = clear_planes(c);
         if (r != BF_OK) return r;
@@ -461,7 +461,7 @@ void bf_destroy(bf_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tl) {   // debug timeline dump: launch group slot ticks(100 MHz)
-        std::vector<unsigned long long> tl(2 * 64 * 2 * 16);   // [kernel][launch][group][slot]
+        std::vector<unsigned long long> tl(3 * 64 * 2 * 16);   // [kernel][launch][group][slot]; third block: per-work-group stamps of K1 launch 20
         (void)hipMemcpy(tl.data(), c->d_tl, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(c->tl_path, "w")) {
             for (size_t i = 0; i < tl.size(); ++i)

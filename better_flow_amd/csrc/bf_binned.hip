@@ -199,6 +199,11 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     const int L = g.L, LL = g.L * g.L;
     const int b = blockIdx.x;
     tl_stamp(tl, tl_launch, 0);
+#ifdef BF_TIMELINE
+    // per-work-group stamps of launch 20 (third 2048-entry block of the timeline buffer; tl points at the second)
+    unsigned long long* tlw = (tl && tl_launch == 20 && b < 512 && threadIdx.x == 0) ? tl + 2048 + b * 4 : nullptr;
+    if (tlw) tlw[0] = wall_clock64();
+#endif
     // everything the block needs from global memory is requested up front, in one burst
     const uint32_t beg = bin_start[b], end = bin_start[b + 1];
     const HotState hs = st->hot;
@@ -219,18 +224,22 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     const long long tmin = hs.tmin;
     uint32_t n_ovf = 0;
     __syncthreads();
-    constexpr int U = 4;   // events in flight per thread: all loads of a pass are issued first
+    // Events in flight per thread: all loads of a pass are issued first.  U * THREADS covers a whole
+    // bin of the usual size in ONE pass: a second pass would wait (vmcnt) for the first pass's
+    // write-through stores of p before it sees its own loads (~2 us per extra pass, measured).
+    constexpr int U = 8192 / THREADS;
     for (uint32_t base = beg; base < end; base += THREADS * U) {
         uint32_t vxy[U];
         int32_t vt[U];
         float2 vp[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint32_t i = base + k * THREADS + threadIdx.x;
-            const bool live = i < end;
-            vxy[k] = live ? xy[i] : 0u;
-            vt[k] = live ? t[i] : 0;
-            vp[k] = live ? p[i] : make_float2(0.f, 0.f);
+            // unconditional loads from a clamped index (no branch per load); dead slots are skipped below
+            uint32_t i = base + k * THREADS + threadIdx.x;
+            i = i < end ? i : beg;
+            vxy[k] = xy[i];
+            vt[k] = t[i];
+            vp[k] = p[i];
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -279,6 +288,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     if (n_ovf) atomicAdd(&st->hot.ovf_cnt[cur], n_ovf);
     tl_stamp(tl, tl_launch, 2);
     __syncthreads();
+#ifdef BF_TIMELINE
+    if (tlw) { tlw[1] = wall_clock64(); tlw[3] = end - beg; }
+#endif
     tl_stamp(tl, tl_launch, 3);
     {   // flush: the whole tile (nothing to zero, no atomics).  WRITE-THROUGH stores (agent-scope
         // relaxed = global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat
@@ -289,6 +301,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
             __hip_atomic_store(&dst[i], s_tile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     tl_stamp(tl, tl_launch, 4);
+#ifdef BF_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tlw) tlw[2] = wall_clock64();
+#endif
 }
 
 // K3 (binned): merge the slabs covering each pixel, box-sum, normalise, then the shared tail.
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     const unsigned long long bm = (1ull << bt) - 1ull;
     // (static indices only: a runtime index would push the HotState copy into scratch memory)
     const bool ovf = (a.cur ? hs.ovf_cnt[1] : hs.ovf_cnt[0]) != 0;
-    const size_t LL = (size_t)g.L * (size_t)g.L;
+    const int LLi = g.L * g.L;
 
     unsigned long long w[NC][4];
     unsigned long long ov[NC];
@@ -337,10 +353,11 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
             const int br = (q & 2) ? brh : brl, bc = (q & 1) ? bch : bcl;
             const bool use = in && (!(q & 2) || brh > brl) && (!(q & 1) || bch > bcl);
             const int lx = gr - ((br << g.lg) - g.D), ly = gc - ((bc << g.lg) - g.D);
-            w[c][q] = use ? a.slabs[(size_t)(br * g.nbc + bc) * LL + (size_t)(lx * g.L + ly)] : 0ull;
+            // 32-bit element offsets (the slabs and planes are far below 2^32 bytes): base + offset addressing
+            w[c][q] = use ? a.slabs[(uint32_t)((br * g.nbc + bc) * LLi + lx * g.L + ly)] : 0ull;
         }
-        ov[c] = (in && ovf) ? a.plane[(size_t)gr * C + gc] : 0ull;
-        oc[c] = (in && ovf) ? a.cplane[(size_t)gr * C + gc] : 0u;
+        ov[c] = (in && ovf) ? a.plane[(uint32_t)(gr * C + gc)] : 0ull;
+        oc[c] = (in && ovf) ? a.cplane[(uint32_t)(gr * C + gc)] : 0u;
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {

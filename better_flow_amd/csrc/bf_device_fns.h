@@ -116,48 +116,63 @@ __device__ __forceinline__ void sums_wave_reduce(Sums& s) {
     s.sjgx = wave_sum(s.sjgx); s.sjgy = wave_sum(s.sjgy);
 }
 
-// Work-group reduction of a Sums through LDS, transposed: every thread stores its nine values
-// ([field][thread]), then 9 x (T/64) lanes each add one wave's 64 values of one field in a fixed
-// order, then the per-wave results are added in wave order.  The wave64 __shfl_down tree needs
-// 107 ds_bpermute_b32 per wave (~1.9 us of the stencil kernel, every wave doing it at once); this
-// moves ~6x fewer bytes through the LDS.  Every thread gets the total.
+// Wave64 sum of a 64-bit pattern on the DPP network (no LDS traffic): inclusive scan by row_shr 1 / 2 / 4 / 8
+// inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 --
+// lane 63 ends up with the total, added in a fixed order.  Lanes without a source read the identity (0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
+__device__ __forceinline__ long long wave_total_dpp(long long v) {
+    v += (long long)dpp_u64<0x111, 0xf>((unsigned long long)v);   // row_shr:1
+    v += (long long)dpp_u64<0x112, 0xf>((unsigned long long)v);   // row_shr:2
+    v += (long long)dpp_u64<0x114, 0xf>((unsigned long long)v);   // row_shr:4
+    v += (long long)dpp_u64<0x118, 0xf>((unsigned long long)v);   // row_shr:8
+    v += (long long)dpp_u64<0x142, 0xa>((unsigned long long)v);   // row_bcast:15 -> rows 1, 3
+    v += (long long)dpp_u64<0x143, 0xc>((unsigned long long)v);   // row_bcast:31 -> rows 2, 3
+    return v;   // lane 63: sum of all 64 lanes
+}
+__device__ __forceinline__ double wave_total_dpp(double v) {
+#define BF_DPP_STEP(CTRL, MASK) \
+    v += __longlong_as_double((long long)dpp_u64<CTRL, MASK>((unsigned long long)__double_as_longlong(v)))
+    BF_DPP_STEP(0x111, 0xf);
+    BF_DPP_STEP(0x112, 0xf);
+    BF_DPP_STEP(0x114, 0xf);
+    BF_DPP_STEP(0x118, 0xf);
+    BF_DPP_STEP(0x142, 0xa);
+    BF_DPP_STEP(0x143, 0xc);
+#undef BF_DPP_STEP
+    return v;
+}
+
+// Work-group reduction of a Sums: DPP wave totals (above), lane 63 of every wave parks its nine
+// values in LDS, and after one barrier every thread adds the per-wave results in wave order.  (The
+// wave64 __shfl_down tree costs 107 ds_bpermute_b32 per wave, ~1.9 us with every wave at it; an
+// LDS-transposed version ~1.8 us; this one stays on the VALU.)  Every thread gets the total.
+// `tid` is the thread's index inside its THREADS-wide group (groups are wave aligned).
 constexpr int kSumFields = 9;
 template <int THREADS>
-__device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_buf /* 9 * THREADS */,
-                                                  unsigned long long* s_part /* 9 * THREADS / 64 */,
-                                                  const int tid /* 0 .. THREADS-1 within its buffers */) {
+__device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_part /* 9 * THREADS / 64 */,
+                                                  const int tid) {
     constexpr int W = THREADS / 64;
-    s_buf[0 * THREADS + tid] = (unsigned long long)sm.n;
-    s_buf[1 * THREADS + tid] = (unsigned long long)sm.sci;
-    s_buf[2 * THREADS + tid] = (unsigned long long)sm.scj;
-    s_buf[3 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sgx);
-    s_buf[4 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sgy);
-    s_buf[5 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sigx);
-    s_buf[6 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sigy);
-    s_buf[7 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sjgx);
-    s_buf[8 * THREADS + tid] = (unsigned long long)__double_as_longlong(sm.sjgy);
-    __syncthreads();
-    if (tid < kSumFields * W) {
-        const int f = tid / W, w = tid - f * W;
-        const unsigned long long* src = &s_buf[f * THREADS + w * 64];
-        unsigned long long acc;
-        if (f < 3) {   // exact integer sums
-            long long a = 0;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) a += (long long)src[j];
-            acc = (unsigned long long)a;
-        } else {       // doubles in a fixed order: 4 interleaved accumulators, then a fixed tree
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
-            for (int j = 0; j < 64; j += 4) {
-                a0 += __longlong_as_double((long long)src[j]);
-                a1 += __longlong_as_double((long long)src[j + 1]);
-                a2 += __longlong_as_double((long long)src[j + 2]);
-                a3 += __longlong_as_double((long long)src[j + 3]);
-            }
-            acc = (unsigned long long)__double_as_longlong((a0 + a1) + (a2 + a3));
-        }
-        s_part[f * W + w] = acc;
+    Sums r;
+    r.n = wave_total_dpp(sm.n); r.sci = wave_total_dpp(sm.sci); r.scj = wave_total_dpp(sm.scj);
+    r.sgx = wave_total_dpp(sm.sgx); r.sgy = wave_total_dpp(sm.sgy);
+    r.sigx = wave_total_dpp(sm.sigx); r.sigy = wave_total_dpp(sm.sigy);
+    r.sjgx = wave_total_dpp(sm.sjgx); r.sjgy = wave_total_dpp(sm.sjgy);
+    if ((tid & 63) == 63) {
+        const int w = tid >> 6;
+        s_part[0 * W + w] = (unsigned long long)r.n;
+        s_part[1 * W + w] = (unsigned long long)r.sci;
+        s_part[2 * W + w] = (unsigned long long)r.scj;
+        s_part[3 * W + w] = (unsigned long long)__double_as_longlong(r.sgx);
+        s_part[4 * W + w] = (unsigned long long)__double_as_longlong(r.sgy);
+        s_part[5 * W + w] = (unsigned long long)__double_as_longlong(r.sigx);
+        s_part[6 * W + w] = (unsigned long long)__double_as_longlong(r.sigy);
+        s_part[7 * W + w] = (unsigned long long)__double_as_longlong(r.sjgx);
+        s_part[8 * W + w] = (unsigned long long)__double_as_longlong(r.sjgy);
     }
     __syncthreads();
     Sums t;
@@ -357,10 +372,15 @@ __device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int 
     }
 }
 
+// Partials are field-major with an EVEN stride so that two neighbouring records of one field are one
+// aligned 16-byte word.
+__host__ __device__ __forceinline__ int partial_stride(int nblk) { return (nblk + 1) & ~1; }
+
 // Publishes one work-group's reduced sums as field-major (structure-of-arrays) partials with
-// write-through stores: field k of work-group i at [k * nblk + i].
+// write-through stores: field k of work-group i at [k * partial_stride(nblk) + i].
 __device__ __forceinline__ void publish_partial(unsigned long long* partials, int nblk, int me, const Sums& t) {
     unsigned long long* o = partials + me;
+    const int stride = partial_stride(nblk);
     const unsigned long long v[9] = {
         (unsigned long long)t.n, (unsigned long long)t.sci, (unsigned long long)t.scj,
         (unsigned long long)__double_as_longlong(t.sgx), (unsigned long long)__double_as_longlong(t.sgy),
@@ -368,35 +388,53 @@ __device__ __forceinline__ void publish_partial(unsigned long long* partials, in
         (unsigned long long)__double_as_longlong(t.sjgx), (unsigned long long)__double_as_longlong(t.sjgy)};
 #pragma unroll
     for (int k = 0; k < 9; ++k)
-        __hip_atomic_store(&o[(size_t)k * nblk], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&o[(size_t)k * stride], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The reducer's first step: thread tid of 256 adds partials tid, tid + 256, ... in a fixed order
-// (agent-scope loads: the partials were published by other work-groups of the same launch).
+typedef unsigned int bf_u32x4 __attribute__((ext_vector_type(4)));
+
+// The reducer's first step: thread tid of 256 adds the record PAIRS tid, tid + 256, ... in a fixed
+// order.  Agent-scope (sc1) 16-byte loads: the partials were published by other work-groups of the
+// same launch; all loads are issued before the single wait.
 __device__ __forceinline__ Sums gather_partials(const unsigned long long* partials, int nblk, int tid) {
     Sums acc;
     sums_zero(acc);
-    for (int base = 0; base < nblk; base += kThreads * 4) {
-        unsigned long long q[4][9];
+    const int stride = partial_stride(nblk);
+    const int npairs = stride / 2;
+    for (int base = 0; base < npairs; base += kThreads * 2) {
+        bf_u32x4 q[2][9];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * kThreads + tid;
-            const unsigned long long* src = partials + (i < nblk ? i : 0);
+        for (int k = 0; k < 2; ++k) {
+            const int pi = base + k * kThreads + tid;
+            const unsigned long long* src = partials + 2 * (pi < npairs ? pi : 0);
 #pragma unroll
             for (int j = 0; j < 9; ++j)
-                q[k][j] = (i < nblk) ? __hip_atomic_load(&src[(size_t)j * nblk], __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT)
-                                     : 0ull;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[k][j]) : "v"(src + (size_t)j * stride) : "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[0][4]), "+v"(q[0][5]),
+                       "+v"(q[0][6]), "+v"(q[0][7]), "+v"(q[0][8]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]),
+                       "+v"(q[1][3]), "+v"(q[1][4]), "+v"(q[1][5]), "+v"(q[1][6]), "+v"(q[1][7]), "+v"(q[1][8])
+                     :: "memory");
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc.n += (long long)q[k][0]; acc.sci += (long long)q[k][1]; acc.scj += (long long)q[k][2];
-            acc.sgx += __longlong_as_double((long long)q[k][3]);
-            acc.sgy += __longlong_as_double((long long)q[k][4]);
-            acc.sigx += __longlong_as_double((long long)q[k][5]);
-            acc.sigy += __longlong_as_double((long long)q[k][6]);
-            acc.sjgx += __longlong_as_double((long long)q[k][7]);
-            acc.sjgy += __longlong_as_double((long long)q[k][8]);
+        for (int k = 0; k < 2; ++k) {
+            const int pi = base + k * kThreads + tid;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (pi < npairs && 2 * pi + h < nblk) {
+                    unsigned long long v[9];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j)
+                        v[j] = ((unsigned long long)q[k][j][2 * h + 1] << 32) | (unsigned long long)q[k][j][2 * h];
+                    acc.n += (long long)v[0]; acc.sci += (long long)v[1]; acc.scj += (long long)v[2];
+                    acc.sgx += __longlong_as_double((long long)v[3]);
+                    acc.sgy += __longlong_as_double((long long)v[4]);
+                    acc.sigx += __longlong_as_double((long long)v[5]);
+                    acc.sigy += __longlong_as_double((long long)v[6]);
+                    acc.sjgx += __longlong_as_double((long long)v[7]);
+                    acc.sjgy += __longlong_as_double((long long)v[8]);
+                }
+            }
         }
     }
     return acc;
@@ -435,9 +473,15 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
     }
     if (a.partials) {
         tl_stamp(a.tl, a.tl_launch, 5);
-        __shared__ unsigned long long s_rbuf[kSumFields * kThreads];
+        // The state is stable while this kernel runs (only its own last work-group writes it), so every
+        // work-group fetches a copy into LDS now, off the critical path: the update then runs on it at
+        // once (a dependent global round trip per field cost 3.2 us; copying after the ticket ~1 us).
+        __shared__ DevState s_state;
+        static_assert(sizeof(DevState) % 8 == 0 && sizeof(DevState) / 8 <= 64, "one u64 per lane of one wave");
+        if (a.ticket && tid < (int)(sizeof(DevState) / 8))
+            reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st_rw)[tid];
         __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
-        const Sums blk = block_reduce_sums<kThreads>(sm, s_rbuf, s_rpart, tid);
+        const Sums blk = block_reduce_sums<kThreads>(sm, s_rpart, tid);
         tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
@@ -445,7 +489,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             if (tid == 0) {
                 const Sums t = blk;
                 unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partials) + me;
-                const size_t st_ = (size_t)nblk;
+                const size_t st_ = (size_t)partial_stride(nblk);
                 o[0 * st_] = (unsigned long long)t.n; o[1 * st_] = (unsigned long long)t.sci;
                 o[2 * st_] = (unsigned long long)t.scj;
                 o[3 * st_] = (unsigned long long)__double_as_longlong(t.sgx);
@@ -493,20 +537,22 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             if (a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 10] = wall_clock64();
 #endif
         }
-        __syncthreads();   // s_rbuf / s_rpart are reused
-        const Sums tot = block_reduce_sums<kThreads>(acc, s_rbuf, s_rpart, tid);
+        __syncthreads();   // s_rpart is reused
+        const Sums tot = block_reduce_sums<kThreads>(acc, s_rpart, tid);
         if (tid == 0) {
             const Sums t = tot;
             a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
 #ifdef BF_TIMELINE
             if (a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 11] = wall_clock64();
 #endif
-            __shared__ DevState s_state;
-            model_update(a.st_rw, &s_state, t, a.trace, a.update_mode, a.cur);
-#ifdef BF_TIMELINE
-            if (a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 12] = wall_clock64();
-#endif
+            model_update_local(&s_state, t, a.trace, a.update_mode, a.cur);
         }
+        __syncthreads();
+        if (tid < (int)(sizeof(DevState) / 8))
+            reinterpret_cast<unsigned long long*>(a.st_rw)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
+#ifdef BF_TIMELINE
+        if (tid == 0 && a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 12] = wall_clock64();
+#endif
     }
 }
 

@@ -269,14 +269,15 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(DevState* st, const Part
             const int i = base + k * kUpdThreads + tid;
             if (i < nblocks) {   // structure-of-arrays records written by the stencil kernels
                 const unsigned long long* src = reinterpret_cast<const unsigned long long*>(partials) + i;
-                q[k].n = (long long)src[0 * (size_t)nblocks]; q[k].sci = (long long)src[1 * (size_t)nblocks];
-                q[k].scj = (long long)src[2 * (size_t)nblocks];
-                q[k].sgx = __longlong_as_double((long long)src[3 * (size_t)nblocks]);
-                q[k].sgy = __longlong_as_double((long long)src[4 * (size_t)nblocks]);
-                q[k].sigx = __longlong_as_double((long long)src[5 * (size_t)nblocks]);
-                q[k].sigy = __longlong_as_double((long long)src[6 * (size_t)nblocks]);
-                q[k].sjgx = __longlong_as_double((long long)src[7 * (size_t)nblocks]);
-                q[k].sjgy = __longlong_as_double((long long)src[8 * (size_t)nblocks]);
+                const size_t ps = (size_t)partial_stride(nblocks);
+                q[k].n = (long long)src[0 * ps]; q[k].sci = (long long)src[1 * ps];
+                q[k].scj = (long long)src[2 * ps];
+                q[k].sgx = __longlong_as_double((long long)src[3 * ps]);
+                q[k].sgy = __longlong_as_double((long long)src[4 * ps]);
+                q[k].sigx = __longlong_as_double((long long)src[5 * ps]);
+                q[k].sigy = __longlong_as_double((long long)src[6 * ps]);
+                q[k].sjgx = __longlong_as_double((long long)src[7 * ps]);
+                q[k].sjgy = __longlong_as_double((long long)src[8 * ps]);
             }
         }
 #pragma unroll

@@ -142,7 +142,6 @@ __global__ __launch_bounds__(THREADS) void k_persist(PersistArgs a) {
     const BinGrid g = a.g;
     const int L = g.L, LL = L * L, D = g.D;
     // LDS: [s_tile LL u64 | s_ts NW^2 u64 | s_cnt NW^2 u32 | s_time TW^2 f32 | s_rpart | s_state | flags]
-    // the reduction buffer (9 x THREADS u64) overlays s_tile / s_ts, which are dead by then
     unsigned long long* s_tile = s_mem;
     unsigned long long* s_ts = s_tile + ((LL + 1) & ~1);
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_ts + NW * NW);
@@ -150,7 +149,6 @@ __global__ __launch_bounds__(THREADS) void k_persist(PersistArgs a) {
     unsigned long long* s_rpart = reinterpret_cast<unsigned long long*>(s_time + ((TW * TW + 1) & ~1));
     DevState* s_state = reinterpret_cast<DevState*>(s_rpart + kSumFields * (THREADS / 64));
     int* s_flag = reinterpret_cast<int*>(s_state + 1);
-    unsigned long long* s_rbuf = s_mem;
 
     const int b = blockIdx.x, nwg = gridDim.x, tid0 = threadIdx.x;
     const int tid = tid0;
@@ -368,9 +366,7 @@ __global__ __launch_bounds__(THREADS) void k_persist(PersistArgs a) {
                         stencil_px<TW>(&s_time[(cr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, sm, gx, gy);
                     }
                 }
-                // (s_rbuf overlays s_tile / s_ts: every thread is past the box sum)
-                const Sums blk = block_reduce_sums<kThreads>(sm, s_rbuf + sub * kSumFields * kThreads,
-                                                             s_rpart + sub * kSumFields * (kThreads / 64), tsub);
+                const Sums blk = block_reduce_sums<kThreads>(sm, s_rpart + sub * kSumFields * (kThreads / 64), tsub);
                 const int ty = mybr * (TS / kTileR) + tile;
                 if (tsub == 0 && ty < a.gy) publish_partial(a.partials, nblk, ty * a.gx + mybc, blk);
                 if (rep + 1 < 4 / SUBS) {
@@ -390,8 +386,7 @@ __global__ __launch_bounds__(THREADS) void k_persist(PersistArgs a) {
             sums_zero(acc);
             if (sub == 0) acc = gather_partials(a.partials, nblk, tsub);
             tlp(a.tl, it, b, nwg, 8);
-            const Sums tot = block_reduce_sums<kThreads>(acc, s_rbuf + sub * kSumFields * kThreads,
-                                                         s_rpart + sub * kSumFields * (kThreads / 64), tsub);
+            const Sums tot = block_reduce_sums<kThreads>(acc, s_rpart + sub * kSumFields * (kThreads / 64), tsub);
             if (tid == 0) {
                 if (cur) { s_state->hot.ovf_cnt[1] = ovf_now; } else { s_state->hot.ovf_cnt[0] = ovf_now; }
                 model_update_local(s_state, tot, b == 0 ? a.trace : nullptr, 1, cur);
@@ -421,10 +416,6 @@ size_t persist_lds_bytes(const BinGrid& g, int scale, int threads) {
     const size_t LL = ((size_t)g.L * g.L + 1) & ~(size_t)1;
     size_t bytes = LL * 8 + (size_t)NW * NW * 8 + (size_t)NW * NW * 4 + (((size_t)TW * TW + 1) & ~(size_t)1) * 4 +
                    (size_t)kSumFields * (threads / 64) * 8 + sizeof(DevState) + 64;
-    const size_t red = (size_t)kSumFields * threads * 8;
-    // the reduction buffer must end before s_time begins
-    const size_t before_time = LL * 8 + (size_t)NW * NW * 8 + (size_t)NW * NW * 4;
-    if (red > before_time) bytes += red - before_time;   // (never with the supported geometries)
     return bytes;
 }
 
@@ -456,9 +447,6 @@ int persist_max_groups(const BinGrid& g, int scale, int threads, int device) {
     if (g.TS != kPTS || g.D < scale / 2 + 1 || g.D > g.TS / 2) return 0;
     const size_t lds = persist_lds_bytes(g, scale, threads);
     if (lds > 160 * 1024) return 0;
-    const size_t red = (size_t)kSumFields * threads * 8;
-    const int H = scale / 2 + 1, NW = kPTS + 2 * H;
-    if (red > (((size_t)g.L * g.L + 1) & ~(size_t)1) * 8 + (size_t)NW * NW * 12) return 0;
     int coop = 0, cus = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;

@@ -40,6 +40,27 @@ for cname, d in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
 if len(k1) == 2:
     k1["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, median over live k_bin_warp_scatter launches (config 2)"
     json.dump(k1, open(os.path.join(out, "k1_traffic.json"), "w"), indent=1)
+# SQ issue / wait counters per launch of the two loop kernels
+fs = glob.glob(os.path.join(ROOT, "gpurun_out/pmc_sq/**/*counter_collection.csv"), recursive=True)
+if fs:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(fs[0])):
+        k = kname(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen[k].add(r["Dispatch_Id"])
+    rows = ["rocprofv3 --kernel-trace --pmc SQ_* (own pass) over `python scripts/run_once.py 1` (one cold config-2 slice).",
+            "Per launch, summed over the device.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles",
+            "(MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.", ""]
+    for k in sorted(agg, key=lambda k: -agg[k]["SQ_BUSY_CYCLES"])[:6]:
+        a, n = agg[k], len(seen[k])
+        wc = a["SQ_WAVE_CYCLES"] or 1.0
+        rows.append("%-34s launches %4d  waves %6.0f  VALU insts/wave %6.0f  wave-cycles: active %4.1f%% (VALU %4.1f%%)  "
+                    "wait(s_waitcnt/barrier) %4.1f%%  issue-stall %4.1f%%" %
+                    (k, n, a["SQ_WAVES"] / n, a["SQ_INSTS_VALU"] / max(a["SQ_WAVES"], 1), 100 * a["SQ_ACTIVE_INST_ANY"] / wc,
+                     100 * a["SQ_ACTIVE_INST_VALU"] / wc, 100 * a["SQ_WAIT_ANY"] / wc, 100 * a["SQ_WAIT_INST_ANY"] / wc))
+    open(os.path.join(out, tag + "_pmc_sq_issue.txt"), "w").write("\n".join(rows) + "\n")
+    print("\n".join(rows))
 bl = os.path.join(ROOT, "gpurun_out/prof_bench.log")
 if os.path.exists(bl):
     for ln in open(bl):

@@ -89,6 +89,21 @@ class Profile(C.Structure):
     ]
 
 
+class LocalWindow(C.Structure):
+    _fields_ = [
+        ("scale", C.c_int32), ("metric_wsizex", C.c_int32), ("metric_wsizey", C.c_int32),
+        ("scale_img_x", C.c_int32), ("scale_img_y", C.c_int32),
+        ("c_fr_x", C.c_int32), ("c_fr_y", C.c_int32), ("_pad", C.c_int32), ("c_t", C.c_int64),
+    ]
+
+
+class LocalState(C.Structure):
+    _fields_ = [
+        ("nx", C.c_double), ("ny", C.c_double), ("last_score", C.c_double),
+        ("dnx", C.c_double), ("dny", C.c_double), ("dn_th", C.c_double), ("evaluations", C.c_int64),
+    ]
+
+
 # every symbol include/bf_accel.h declares
 EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
@@ -98,6 +113,7 @@ EXPORTS = [
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
+    "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
 ]
 
 _lib = None
@@ -130,6 +146,10 @@ def load():
         L.bf_upload_events.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64]
         L.bf_upload_events_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int64]
         L.bf_set_cloud.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Window)]
+        L.bf_local_set_window.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                          C.POINTER(LocalWindow)]
+        L.bf_local_iteration_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p]
+        L.bf_local_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(LocalState)]
         L.bf_project_4param_reinit.argtypes = [C.c_void_p] + [C.c_double] * 6
         L.bf_get_time_img.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bf_sobel.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -262,6 +282,29 @@ class Accel:
 
     def set_model(self, model):
         self._chk(self.L.bf_set_model(self.h, C.byref(model)))
+
+    # ---- OptimizerLocal (optimizer_sampler.h:12-68): the contrast-score optimiser ----
+    def local_set_window(self, scale, center=None, wsz=0):
+        """center=None: window = bounding box of the cloud; else center = (fr_x, fr_y, t_ns) and wsz."""
+        w = LocalWindow()
+        cx, cy, ct = center if center is not None else (0, 0, 0)
+        self._chk(self.L.bf_local_set_window(self.h, scale, wsz if center is not None else 0, cx, cy, ct,
+                                             C.byref(w)))
+        self._lwin = w
+        return w
+
+    def local_iteration_step(self, nx, ny, want_img=False):
+        sc = C.c_double()
+        img = np.empty((self._lwin.scale_img_x, self._lwin.scale_img_y), dtype=np.uint8) if want_img else None
+        self._chk(self.L.bf_local_iteration_step(self.h, nx, ny, C.byref(sc), _ptr(img) if want_img else None))
+        return (sc.value, img) if want_img else sc.value
+
+    def local_run(self, res_x=180, res_y=240, max_evaluations=100000):
+        st = LocalState()
+        rc = self.L.bf_local_run(self.h, res_x, res_y, max_evaluations, C.byref(st))
+        if rc < 0:
+            self._chk(rc)
+        return rc, st
 
     def default_opts(self):
         o = RunOpts()

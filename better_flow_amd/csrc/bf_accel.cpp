@@ -92,6 +92,17 @@ struct bf_ctx {
     int trace_alloc = 0;
     int trace_valid = 0;
 
+    // contrast-score optimiser (bf_local.hip)
+    uint32_t* d_lplane[2] = {nullptr, nullptr};   // point planes, double buffered
+    unsigned long long* d_lscore = nullptr;       // non-zero sum / count of the blurred image
+    uint8_t* d_limg = nullptr;                    // project_img
+    unsigned long long* h_lscore = nullptr;       // pinned
+    bf_local_window lwin;
+    bool have_lwin = false;
+    int lcur = 0;
+    SliceStats stats;                // folded k_prepare statistics of the uploaded slice
+    bool stats_valid = false;
+
     DevState* h_state = nullptr;     // pinned, D2H target only: 2 slots (pipelined polling)
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     SliceStats* h_stats = nullptr;   // pinned, D2H target only
@@ -339,7 +350,32 @@ int d2h_state(bf_ctx* c) {
     return BF_OK;
 }
 
+// Folds the per-work-group min / max / sum records k_prepare wrote for the uploaded slice (one
+// device-to-host copy per slice, cached).
+int fold_stats(bf_ctx* c) {
+    if (c->stats_valid) return BF_OK;
+    HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->d_stats, kPrepBlocks * sizeof(SliceStats), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SliceStats s = c->h_stats[0];
+    for (int k = 1; k < kPrepBlocks; ++k) {
+        const SliceStats& q = c->h_stats[k];
+        if (q.xmin < s.xmin) s.xmin = q.xmin;
+        if (q.xmax > s.xmax) s.xmax = q.xmax;
+        if (q.ymin < s.ymin) s.ymin = q.ymin;
+        if (q.ymax > s.ymax) s.ymax = q.ymax;
+        if (q.tmin < s.tmin) s.tmin = q.tmin;
+        if (q.tmax > s.tmax) s.tmax = q.tmax;
+        s.tsum += q.tsum;
+    }
+    c->stats = s;
+    c->stats_valid = true;
+    return BF_OK;
+}
+
 int after_upload(bf_ctx* c, long long n) {
+    c->stats_valid = false;
+    c->have_lwin = false;
     c->n = n;
     c->uploaded = true;
     c->have_window = false;
@@ -363,11 +399,12 @@ int bf_device_count(int32_t* count) {
 }
 
 int bf_abi_struct_sizes(int32_t* out, int32_t n) {
-    const int32_t sz[6] = {(int32_t)sizeof(bf_model),    (int32_t)sizeof(bf_window),
-                           (int32_t)sizeof(bf_run_opts), (int32_t)sizeof(bf_run_info),
-                           (int32_t)sizeof(bf_trace_rec), (int32_t)sizeof(bf_profile)};
-    for (int i = 0; out && i < n && i < 6; ++i) out[i] = sz[i];
-    return 6;
+    const int32_t sz[8] = {(int32_t)sizeof(bf_model),     (int32_t)sizeof(bf_window),
+                           (int32_t)sizeof(bf_run_opts),  (int32_t)sizeof(bf_run_info),
+                           (int32_t)sizeof(bf_trace_rec), (int32_t)sizeof(bf_profile),
+                           (int32_t)sizeof(bf_local_window), (int32_t)sizeof(bf_local_state)};
+    for (int i = 0; out && i < n && i < 8; ++i) out[i] = sz[i];
+    return 8;
 }
 
 void bf_run_opts_default(bf_run_opts* o) {
@@ -478,7 +515,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_hist_ts, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
@@ -487,6 +524,7 @@ void bf_destroy(bf_ctx* c) {
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->h_lscore) (void)hipHostFree(c->h_lscore);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -654,20 +692,11 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     if (scale < 1 || scale % 2 == 0 || scale / 2 > kMaxHalfScale)   // optimizer_rolling.h:274
         return fail(c, BF_ERR_ARG, "scale must be odd and <= %d (got %d)", 2 * kMaxHalfScale + 1, scale);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->d_stats, kPrepBlocks * sizeof(SliceStats), hipMemcpyDeviceToHost,
-                              c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    SliceStats s = c->h_stats[0];   // fold the per-work-group records of k_prepare
-    for (int k = 1; k < kPrepBlocks; ++k) {
-        const SliceStats& q = c->h_stats[k];
-        if (q.xmin < s.xmin) s.xmin = q.xmin;
-        if (q.xmax > s.xmax) s.xmax = q.xmax;
-        if (q.ymin < s.ymin) s.ymin = q.ymin;
-        if (q.ymax > s.ymax) s.ymax = q.ymax;
-        if (q.tmin < s.tmin) s.tmin = q.tmin;
-        if (q.tmax > s.tmax) s.tmax = q.tmax;
-        s.tsum += q.tsum;
+    {
+        int rc = fold_stats(c);
+        if (rc != BF_OK) return rc;
     }
+    const SliceStats s = c->stats;
     bf_window w;
     memset(&w, 0, sizeof(w));
     w.scale = scale;
@@ -1316,6 +1345,149 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
     c->degenerate = false;
     c->use_binned = false;
+    return BF_OK;
+}
+
+// ---- OptimizerLocal: the contrast-score optimiser (optimizer_sampler.h / .cpp) ------------------
+
+namespace {
+
+// Event::project -> apply_project (event.h:65-70,164-168) of one event on the host (the centre
+// event of the window); this file is compiled with -ffp-contract=off like the kernels.
+void project_one(int32_t fr_x, int32_t fr_y, int64_t t, float kx, float ky, double* pr_x, double* pr_y) {
+    const float ft = (float)t;
+    const float px = kx * ft, py = ky * ft;
+    *pr_x = (double)(float)fr_x - (double)px / 10000.0;
+    *pr_y = (double)(float)fr_y - (double)py / 10000.0;
+}
+
+int local_step(bf_ctx* c, double nx, double ny, double* score, bool want_img) {
+    const bf_local_window& w = c->lwin;
+    LocalGeom g;
+    memset(&g, 0, sizeof(g));
+    g.scale = w.scale; g.wsx = w.metric_wsizex; g.wsy = w.metric_wsizey;
+    g.R = w.scale_img_x; g.C = w.scale_img_y;
+    g.kx = (float)((double)(float)nx / 127.0);   // event.h:164-165, nz is the double 127
+    g.ky = (float)((double)(float)ny / 127.0);
+    double cpx, cpy;
+    project_one(w.c_fr_x, w.c_fr_y, w.c_t, g.kx, g.ky, &cpx, &cpy);           // optimizer_sampler.cpp:122
+    g.x_shift = -cpx * (double)w.scale + (double)w.metric_wsizex / 2.0;        // :126
+    g.y_shift = -cpy * (double)w.scale + (double)w.metric_wsizey / 2.0;        // :127
+    const bf_ctx::EvSet& e = c->set[c->cs];
+    HIP_TRY(c, hipMemsetAsync(c->d_lscore, 0, 2 * sizeof(unsigned long long), c->stream));
+    launch_local_project_count(e.xy, e.t, c->n, g, c->d_lplane[c->lcur], c->stream);
+    if (launch_local_blur_score(c->d_lplane[c->lcur], c->d_lplane[c->lcur ^ 1], g, c->d_lscore,
+                                want_img ? c->d_limg : nullptr, c->stream) != 0)
+        return fail(c, BF_ERR_ARG, "the 8-bit Gaussian is defined for scale <= 7 (got %d)", w.scale);
+    c->lcur ^= 1;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_lscore, c->d_lscore, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // get_event_score, optimizer_sampler.cpp:192-205 (integer sums are exact in a double far beyond any image)
+    *score = c->h_lscore[1] == 0 ? 0.0 : (double)c->h_lscore[0] / (double)c->h_lscore[1];
+    return BF_OK;
+}
+
+}  // namespace
+
+int bf_local_set_window(bf_ctx* c, int32_t scale, int32_t wsz, int32_t c_fr_x, int32_t c_fr_y, int64_t c_t,
+                        bf_local_window* window_out) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_local_set_window before bf_upload_events");
+    if (scale < 1 || scale % 2 == 0 || scale > 7)   // optimizer_sampler.cpp:206 (odd); the Gaussian is stated to 7
+        return fail(c, BF_ERR_ARG, "scale must be odd and <= 7 (got %d)", scale);
+    HIP_TRY(c, hipSetDevice(c->device));
+    bf_local_window w;
+    memset(&w, 0, sizeof(w));
+    w.scale = scale;
+    if (wsz <= 0) {   // OptimizerLocal(events, scale), optimizer_sampler.h:35-48
+        if (c->n <= 0) return fail(c, BF_ERR_STATE, "the bounding box of an empty cloud is undefined");
+        int rc = fold_stats(c);
+        if (rc != BF_OK) return rc;
+        const SliceStats& s = c->stats;
+        w.metric_wsizex = scale * (s.xmax - s.xmin);
+        w.metric_wsizey = scale * (s.ymax - s.ymin);
+        w.c_fr_x = (s.xmax - s.xmin) / 2 + s.xmin;
+        w.c_fr_y = (s.ymax - s.ymin) / 2 + s.ymin;
+        w.c_t = 0;
+    } else {          // OptimizerLocal(events, e, scale, wsz), :29-33
+        w.metric_wsizex = scale * wsz;
+        w.metric_wsizey = scale * wsz;
+        w.c_fr_x = c_fr_x; w.c_fr_y = c_fr_y; w.c_t = c_t;
+    }
+    w.scale_img_x = w.metric_wsizex + scale;   // optimizer_sampler.cpp:208-209
+    w.scale_img_y = w.metric_wsizey + scale;
+    if ((size_t)w.scale_img_x * (size_t)w.scale_img_y > c->cap_px)
+        return fail(c, BF_ERR_CAPACITY, "window %d x %d exceeds the image capacity", w.scale_img_x, w.scale_img_y);
+    if (!c->d_lplane[0]) {
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMalloc(&c->d_lplane[i], c->cap_px * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_lscore, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_limg, c->cap_px));
+        HIP_TRY(c, hipHostMalloc(&c->h_lscore, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    // a new window lays the planes out afresh
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMemsetAsync(c->d_lplane[i], 0, c->cap_px * sizeof(uint32_t), c->stream));
+    c->lcur = 0;
+    c->lwin = w;
+    c->have_lwin = true;
+    if (window_out) *window_out = w;
+    return BF_OK;
+}
+
+int bf_local_iteration_step(bf_ctx* c, double nx, double ny, double* score, uint8_t* img_out) {
+    if (!c || !score) return BF_ERR_ARG;
+    if (!c->have_lwin) return fail(c, BF_ERR_STATE, "bf_local_iteration_step before bf_local_set_window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = local_step(c, nx, ny, score, img_out != nullptr);
+    if (rc != BF_OK) return rc;
+    if (img_out)
+        HIP_TRY(c, hipMemcpy(img_out, c->d_limg, (size_t)c->lwin.scale_img_x * (size_t)c->lwin.scale_img_y,
+                             hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+int bf_local_run(bf_ctx* c, int32_t res_x, int32_t res_y, int64_t max_evaluations, bf_local_state* out) {
+    if (!c || !out) return BF_ERR_ARG;
+    if (!c->have_lwin) return fail(c, BF_ERR_STATE, "bf_local_run before bf_local_set_window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bf_local_window& w = c->lwin;
+    bf_local_state st;
+    memset(&st, 0, sizeof(st));
+    st.dnx = 0.01; st.dny = 0.01;   // optimizer_sampler.cpp:7
+    // (NZ * T_DIVIDER * 1000.0) / (10 * scale * FROM_MS(MAX_TIME_MS)), common.h:36,49,60,64
+    st.dn_th = (127 * 1 * 1000.0) / (double)(10ull * (unsigned long long)w.scale * 100000000ull);
+    *out = st;
+    if ((w.scale_img_x < w.scale * res_x / 15) && (w.scale_img_y < w.scale * res_y / 15)) return BF_SKIPPED;   // :9-13
+    int rc = local_step(c, st.nx, st.ny, &st.last_score, false);   // :16
+    if (rc != BF_OK) return rc;
+    st.evaluations = 1;
+    while (std::hypot(st.dnx, st.dny) > st.dn_th) {   // :20
+        {   // compute_new_nx, :90-102
+            const double nx_new = st.nx + st.dnx;
+            double new_score;
+            if ((rc = local_step(c, nx_new, st.ny, &new_score, false)) != BF_OK) return rc;
+            const double dscore = new_score - st.last_score;
+            st.last_score = new_score;
+            if (dscore <= 0) st.dnx = -st.dnx / 2.0;
+            st.nx = nx_new;
+        }
+        {   // compute_new_ny, :105-117
+            const double ny_new = st.ny + st.dny;
+            double new_score;
+            if ((rc = local_step(c, st.nx, ny_new, &new_score, false)) != BF_OK) return rc;
+            const double dscore = new_score - st.last_score;
+            st.last_score = new_score;
+            if (dscore <= 0) st.dny = -st.dny / 2.0;
+            st.ny = ny_new;
+        }
+        st.evaluations += 2;
+        if (max_evaluations > 0 && st.evaluations >= max_evaluations) {
+            *out = st;
+            return fail(c, BF_ERR_NOCONV, "evaluation cap (%lld) reached", (long long)max_evaluations);
+        }
+    }
+    *out = st;
     return BF_OK;
 }
 

@@ -127,6 +127,17 @@ size_t persist_lds_bytes(const BinGrid& g, int scale, int threads);
 int persist_max_groups(const BinGrid& g, int scale, int threads, int device);
 hipError_t launch_persist(const PersistArgs& a, int scale, int threads, hipStream_t s);
 
+// bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)
+struct LocalGeom {
+    int32_t scale, wsx, wsy, R, C, pad;
+    float kx, ky;              // float(n) / nz of Event::apply_project, the same for every event
+    double x_shift, y_shift;   // -event_c.pr * scale + metric_wsize / 2.0 (optimizer_sampler.cpp:126-127)
+};
+void launch_local_project_count(const uint32_t* xy, const int32_t* t, long long n, const LocalGeom& g, uint32_t* plane,
+                                hipStream_t s);
+int launch_local_blur_score(const uint32_t* plane, uint32_t* zero_plane, const LocalGeom& g, unsigned long long* score,
+                            uint8_t* img_out, hipStream_t s);
+
 void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 
 }  // namespace bf

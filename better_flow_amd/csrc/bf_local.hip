@@ -1,0 +1,149 @@
+// bf_local.hip -- the contrast-score evaluation of OptimizerLocal::iteration_step
+// (optimizer_sampler.cpp:120-153,192-205) for gfx950.
+//
+//   L1  k_local_project_count : Event::project (event.h:65-70,164-168) + the point form of the
+//       saturating s x s splat (:129-146): one 32-bit atomic per accepted event at its centre pixel.
+//   L2  k_local_blur_score    : per 16 x 64 tile, box-sum the points (== the splat), saturate at 255
+//       (each `if (< 255) ++` of :141-143 is order independent: min(255, total)), the 8-bit Gaussian
+//       (ksize = scale, this build's own stated kernel -- defined in include/bf_accel.h), and
+//       the non-zero sum / count of get_event_score (:192-205) as two integer atomics: exact whatever
+//       the order.  It also clears the OTHER point plane (consumed by the previous evaluation).
+//
+// HBM-bound integer work: 8 B read per event + one random 4-byte atomic; 4 B read + 1 B written per pixel.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "bf_device.h"
+#include "bf_device_fns.h"
+#include "bf_kernels.h"
+
+namespace bf {
+
+__global__ __launch_bounds__(kThreads) void k_local_project_count(const uint32_t* __restrict__ xy,
+                                                                  const int32_t* __restrict__ t, long long n,
+                                                                  LocalGeom g, uint32_t* __restrict__ plane) {
+    const long long i0 = ((long long)blockIdx.x * kThreads + threadIdx.x) * kEvPerThread;
+    if (i0 >= n) return;
+    uint32_t vxy[kEvPerThread];
+    int32_t vt[kEvPerThread];
+    if (i0 + kEvPerThread <= n) {   // 16-byte loads (the arrays are padded to a multiple of 4 events)
+        const uint4 a = *reinterpret_cast<const uint4*>(xy + i0);
+        const int4 b = *reinterpret_cast<const int4*>(t + i0);
+        vxy[0] = a.x; vxy[1] = a.y; vxy[2] = a.z; vxy[3] = a.w;
+        vt[0] = b.x; vt[1] = b.y; vt[2] = b.z; vt[3] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kEvPerThread; ++k) {
+            vxy[k] = i0 + k < n ? xy[i0 + k] : 0u;
+            vt[k] = i0 + k < n ? t[i0 + k] : 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kEvPerThread; ++k) {
+        if (i0 + k >= n) break;
+        // event.h:164-168 with the uniform kx, ky = float(n) / nz computed once on the host
+        const float ft = (float)vt[k];
+        const double pr_x = pr_from_p(vxy[k] & 0xffffu, g.kx * ft);
+        const double pr_y = pr_from_p(vxy[k] >> 16, g.ky * ft);
+        int X = trunc_x86(pr_x * (double)g.scale + g.x_shift);   // optimizer_sampler.cpp:130-131
+        int Y = trunc_x86(pr_y * (double)g.scale + g.y_shift);
+        if ((X >= g.wsx) || (X < 0) || (Y >= g.wsy) || (Y < 0)) continue;   // :133
+        X += g.scale / 2;
+        Y += g.scale / 2;
+        atomicAdd(&plane[(size_t)X * (size_t)g.C + (size_t)Y], 1u);
+    }
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {   // cv::BORDER_REFLECT_101
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+template <int HS>
+__global__ __launch_bounds__(kThreads) void k_local_blur_score(const uint32_t* __restrict__ plane,
+                                                               uint32_t* __restrict__ zero_plane, LocalGeom g,
+                                                               unsigned long long* __restrict__ score /* [2] */,
+                                                               uint8_t* __restrict__ img_out) {
+    constexpr int TR = kTileR, TC = kTileC;
+    constexpr int PR = TR + 4 * HS, PC = TC + 4 * HS;   // point tile: halo 2 HS
+    constexpr int CR = TR + 2 * HS, CC = TC + 2 * HS;   // count tile: halo HS
+    __shared__ uint32_t s_pts[PR * PC];
+    __shared__ uint16_t s_cnt[CR * CC];
+    __shared__ unsigned long long s_red[2 * (kThreads / 64)];
+    const int R = g.R, C = g.C, tid = threadIdx.x;
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
+    for (int idx = tid; idx < PR * PC; idx += kThreads) {
+        const int pr = idx / PC, pc = idx - pr * PC;
+        const int gr = r0 - 2 * HS + pr, gc = c0 - 2 * HS + pc;
+        s_pts[idx] = (gr >= 0 && gr < R && gc >= 0 && gc < C) ? plane[(size_t)gr * C + gc] : 0u;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < CR * CC; idx += kThreads) {
+        const int cr = idx / CC, cc = idx - cr * CC;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int da = 0; da <= 2 * HS; ++da)
+#pragma unroll
+            for (int db = 0; db <= 2 * HS; ++db) acc += s_pts[(cr + da) * PC + (cc + db)];
+        s_cnt[idx] = (uint16_t)(acc < 255u ? acc : 255u);   // optimizer_sampler.cpp:141-143
+    }
+    __syncthreads();
+    // binomial taps of one pass (OpenCV's table for sigma <= 0), sum 4 / 16 / 64
+    constexpr int kTap[4][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0}, {1, 4, 6, 4, 1, 0, 0}, {2, 7, 14, 18, 14, 7, 2}};
+    constexpr int kNorm[4] = {1, 4, 16, 64};
+    constexpr int n2 = kNorm[HS] * kNorm[HS];
+    unsigned long long nz_sum = 0, nz_cnt = 0;
+#pragma unroll
+    for (int k = 0; k < (TR * TC) / kThreads; ++k) {
+        const int pidx = tid + k * kThreads;
+        const int lr = pidx / TC, lc = pidx - lr * TC;
+        const int gr = r0 + lr, gc = c0 + lc;
+        if (gr < R && gc < C) {
+            int acc = 0;
+#pragma unroll
+            for (int a = -HS; a <= HS; ++a) {
+                const int rr = reflect101(gr + a, R) - (r0 - HS);
+                int row = 0;
+#pragma unroll
+                for (int b = -HS; b <= HS; ++b) row += kTap[HS][b + HS] * (int)s_cnt[rr * CC + (reflect101(gc + b, C) - (c0 - HS))];
+                acc += kTap[HS][a + HS] * row;
+            }
+            const uint32_t v = (uint32_t)((acc + n2 / 2) / n2);
+            if (img_out) img_out[(size_t)gr * C + gc] = (uint8_t)v;
+            if (v) { nz_sum += v; nz_cnt += 1; }
+            zero_plane[(size_t)gr * C + gc] = 0u;
+        }
+    }
+    nz_sum = (unsigned long long)wave_total_dpp((long long)nz_sum);
+    nz_cnt = (unsigned long long)wave_total_dpp((long long)nz_cnt);
+    if ((tid & 63) == 63) { s_red[2 * (tid >> 6)] = nz_sum; s_red[2 * (tid >> 6) + 1] = nz_cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
+        if (b) { atomicAdd(&score[0], a); atomicAdd(&score[1], b); }
+    }
+}
+
+void launch_local_project_count(const uint32_t* xy, const int32_t* t, long long n, const LocalGeom& g, uint32_t* plane,
+                                hipStream_t s) {
+    if (n <= 0) return;
+    const long long per = (long long)kThreads * kEvPerThread;
+    hipLaunchKernelGGL(k_local_project_count, dim3((unsigned)((n + per - 1) / per)), dim3(kThreads), 0, s, xy, t, n, g, plane);
+}
+
+int launch_local_blur_score(const uint32_t* plane, uint32_t* zero_plane, const LocalGeom& g, unsigned long long* score,
+                            uint8_t* img_out, hipStream_t s) {
+    const dim3 grid((g.C + kTileC - 1) / kTileC, (g.R + kTileR - 1) / kTileR);
+    switch (g.scale / 2) {
+        case 0: hipLaunchKernelGGL(k_local_blur_score<0>, grid, dim3(kThreads), 0, s, plane, zero_plane, g, score, img_out); break;
+        case 1: hipLaunchKernelGGL(k_local_blur_score<1>, grid, dim3(kThreads), 0, s, plane, zero_plane, g, score, img_out); break;
+        case 2: hipLaunchKernelGGL(k_local_blur_score<2>, grid, dim3(kThreads), 0, s, plane, zero_plane, g, score, img_out); break;
+        case 3: hipLaunchKernelGGL(k_local_blur_score<3>, grid, dim3(kThreads), 0, s, plane, zero_plane, g, score, img_out); break;
+        default: return -1;   // this build states its Gaussian for ksize <= 7 only
+    }
+    return 0;
+}
+
+}  // namespace bf

@@ -203,6 +203,21 @@ public:
         check(bf_set_model(ctx, &a), "set_model");
     }
 
+    // OptimizerLocal on the device (optimizer_sampler.h:29-48; optimizer_sampler.cpp:4-38,120-153)
+    void local_set_window(int scale, int wsz, int c_fr_x, int c_fr_y, long long c_t, bf_local_window *w) {
+        check(bf_local_set_window(ctx, scale, wsz, c_fr_x, c_fr_y, c_t, w), "local_set_window");
+    }
+    double local_iteration_step(double nx, double ny, uint8_t *img_out) {
+        double score = 0;
+        check(bf_local_iteration_step(ctx, nx, ny, &score, img_out), "local_iteration_step");
+        return score;
+    }
+    int local_run(bf_local_state *st) {
+        int rc = bf_local_run(ctx, RES_X, RES_Y, 0, st);
+        check(rc, "local_run");
+        return rc;
+    }
+
     // The fused OptimizerRolling::run (optimizer_rolling.h:48-125) on the device.
     int run(int max_itercount, ObjectModel &model, bf_run_info *info) {
         bf_run_opts o;

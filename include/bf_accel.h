@@ -129,9 +129,9 @@ const char *bf_version(void);
 
 void bf_run_opts_default(bf_run_opts *opts);
 
-/* sizeof() of bf_model, bf_window, bf_run_opts, bf_run_info, bf_trace_rec, bf_profile (in
- * that order) as this library was compiled -- lets a foreign-language binding verify its
- * struct layouts.  Writes min(n, 6) entries; returns 6. */
+/* sizeof() of bf_model, bf_window, bf_run_opts, bf_run_info, bf_trace_rec, bf_profile,
+ * bf_local_window, bf_local_state (in that order) as this library was compiled -- lets a
+ * foreign-language binding verify its struct layouts.  Writes min(n, 8) entries; returns 8. */
 int bf_abi_struct_sizes(int32_t *out, int32_t n);
 
 /* Tuning / test knobs that have no counterpart in the reference (each takes effect at the
@@ -255,6 +255,43 @@ int bf_run_tiles(bf_ctx *ctx, const bf_tile_opts *opts, bf_model *models_out, bf
 int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
 
 /* ---- raw device buffers ----------------------------------------------------------- */
+
+/* ---- contrast-score optimiser: OptimizerLocal (optimizer_sampler.h:12-68) ------------------
+ * The secondary score of the path: saturating 8-bit event-count image, Gaussian blur, mean of
+ * the non-zero pixels, coordinate descent on (nx, ny).  The blur is this build's own stated
+ * 8-bit Gaussian (binomial taps {1,2,1}/4, {1,4,6,4,1}/16, {2,7,14,18,14,7,2}/64 for
+ * scale 3 / 5 / 7, BORDER_REFLECT_101, exact integer sum, one rounding half up): the
+ * reference calls cv::GaussianBlur of an unpinned OpenCV, so parity is unpinned there. */
+typedef struct bf_local_window {
+    int32_t scale;
+    int32_t metric_wsizex, metric_wsizey;   /* optimizer_sampler.h:31-32,43-44 */
+    int32_t scale_img_x, scale_img_y;       /* optimizer_sampler.cpp:208-209 */
+    int32_t c_fr_x, c_fr_y;                 /* event_c, the window centre (optimizer_sampler.h:30,46) */
+    int32_t pad_;
+    int64_t c_t;                            /* event_c.t */
+} bf_local_window;
+
+typedef struct bf_local_state {
+    double nx, ny, last_score, dnx, dny, dn_th;   /* optimizer_sampler.h:26-28 */
+    int64_t evaluations;                          /* iteration_step calls */
+} bf_local_state;
+
+/* The two constructors (optimizer_sampler.h:29-48) + update_fields (optimizer_sampler.cpp:205-212).
+ * wsz <= 0: OptimizerLocal(events, scale) -- window = bounding box of the uploaded cloud, centre
+ * event in its middle with t = 0 (c_fr_x, c_fr_y, c_t are ignored).  wsz > 0:
+ * OptimizerLocal(events, e, scale, wsz) with e = (c_fr_x, c_fr_y, c_t).  scale odd, <= 7. */
+int bf_local_set_window(bf_ctx *ctx, int32_t scale, int32_t wsz, int32_t c_fr_x, int32_t c_fr_y,
+                        int64_t c_t, bf_local_window *window_out);
+
+/* OptimizerLocal::iteration_step (optimizer_sampler.cpp:120-153): Event::project(nx, ny) of every
+ * event, count image, blur, score.  img_out (optional, host, scale_img_x * scale_img_y bytes)
+ * receives project_img.  Does not touch the rolling optimizer's per-event state. */
+int bf_local_iteration_step(bf_ctx *ctx, double nx, double ny, double *score, uint8_t *img_out);
+
+/* OptimizerLocal::run (optimizer_sampler.cpp:4-38).  Returns BF_OK, BF_SKIPPED (window guard,
+ * :9-13, with the sensor size res_x x res_y) or BF_ERR_NOCONV when max_evaluations (> 0) is
+ * reached (the reference has no cap). */
+int bf_local_run(bf_ctx *ctx, int32_t res_x, int32_t res_y, int64_t max_evaluations, bf_local_state *out);
 
 /* For callers that keep slices resident in HBM (bench.py, the streaming front end) and
  * hand them over with bf_upload_events_device.  bf_memcpy_h2d is synchronous. */

@@ -363,3 +363,162 @@ void bfo_compute_uv(const double *nx, const double *ny, int64_t n, double *u, do
         v[i] = (xy_len == 0) ? 0 : speed * ny[i] / xy_len;
     }
 }
+
+
+/* ===================== OptimizerLocal: the contrast-score optimiser ===================== */
+
+void bfo_local_window_cloud(const bfo_cloud *ev, int32_t scale, bfo_local_window *w) {
+    /* datastructures.h:127,143-147: min seeded INT_MAX, max INT_MIN */
+    int32_t x_min = INT32_MAX, y_min = INT32_MAX, x_max = INT32_MIN, y_max = INT32_MIN;
+    for (int64_t i = 0; i < ev->n; ++i) {
+        if (ev->fr_x[i] > x_max) x_max = ev->fr_x[i];
+        if (ev->fr_y[i] > y_max) y_max = ev->fr_y[i];
+        if (ev->fr_x[i] < x_min) x_min = ev->fr_x[i];
+        if (ev->fr_y[i] < y_min) y_min = ev->fr_y[i];
+    }
+    w->scale = scale;
+    w->metric_wsizex = scale * (x_max - x_min);   /* optimizer_sampler.h:43 */
+    w->metric_wsizey = scale * (y_max - y_min);   /* :44 */
+    w->c_fr_x = (x_max - x_min) / 2 + x_min;      /* :46 */
+    w->c_fr_y = (y_max - y_min) / 2 + y_min;
+    w->c_t = 0;
+    w->scale_img_x = w->metric_wsizex + scale;    /* optimizer_sampler.cpp:208-209 */
+    w->scale_img_y = w->metric_wsizey + scale;
+}
+
+void bfo_local_window_at(int32_t scale, int32_t wsz, int32_t c_fr_x, int32_t c_fr_y, int64_t c_t,
+                         bfo_local_window *w) {
+    w->scale = scale;
+    w->metric_wsizex = scale * wsz;   /* optimizer_sampler.h:32 */
+    w->metric_wsizey = scale * wsz;
+    w->c_fr_x = c_fr_x;
+    w->c_fr_y = c_fr_y;
+    w->c_t = c_t;
+    w->scale_img_x = w->metric_wsizex + scale;
+    w->scale_img_y = w->metric_wsizey + scale;
+}
+
+/* Event::project -> apply_project (event.h:65-70,164-168) for one event. */
+static void project_one(int32_t fr_x, int32_t fr_y, int64_t t, double nx_, double ny_, double *pr_x, double *pr_y) {
+    float kx = (float)((double)(float)nx_ / BFO_NZ);
+    float ky = (float)((double)(float)ny_ / BFO_NZ);
+    float ft = (float)t;
+    float px = kx * ft;
+    float py = ky * ft;
+    *pr_x = (double)(float)fr_x - (double)px / 10000.0;
+    *pr_y = (double)(float)fr_y - (double)py / 10000.0;
+}
+
+void bfo_project(bfo_cloud *ev, double nx_, double ny_) {
+    for (int64_t i = 0; i < ev->n; ++i) {
+        ev->nx[i] = nx_;
+        ev->ny[i] = ny_;
+        project_one(ev->fr_x[i], ev->fr_y[i], ev->t[i], nx_, ny_, &ev->pr_x[i], &ev->pr_y[i]);
+    }
+}
+
+void bfo_local_count_img(bfo_cloud *ev, const bfo_local_window *w, double nx_, double ny_, uint8_t *img) {
+    const int32_t s = w->scale, C = w->scale_img_y;
+    bfo_project(ev, nx_, ny_);                                  /* :121 */
+    double cpx, cpy;
+    project_one(w->c_fr_x, w->c_fr_y, w->c_t, nx_, ny_, &cpx, &cpy);   /* :122 */
+    memset(img, 0, (size_t)w->scale_img_x * (size_t)w->scale_img_y);   /* :124 */
+    const double x_shift = -cpx * s + (double)w->metric_wsizex / 2.0;  /* :126 */
+    const double y_shift = -cpy * s + (double)w->metric_wsizey / 2.0;  /* :127 */
+    for (int64_t i = 0; i < ev->n; ++i) {
+        int32_t x = trunc_to_int_x86(ev->pr_x[i] * s + x_shift);  /* :130 */
+        int32_t y = trunc_to_int_x86(ev->pr_y[i] * s + y_shift);
+        if ((x >= w->metric_wsizex) || (x < 0) || (y >= w->metric_wsizey) || (y < 0)) continue;   /* :133 */
+        x += s / 2;
+        y += s / 2;
+        for (int32_t jx = x - s / 2; jx <= x + s / 2; ++jx)
+            for (int32_t jy = y - s / 2; jy <= y + s / 2; ++jy)
+                if (img[(size_t)jx * C + jy] < 255) img[(size_t)jx * C + jy]++;   /* :141-143 */
+    }
+}
+
+static int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+int bfo_gauss_u8(uint8_t *img, int32_t rows, int32_t cols, int32_t ksize, uint8_t *scratch) {
+    static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1}, k7[7] = {2, 7, 14, 18, 14, 7, 2};
+    const int *k;
+    int norm;   /* sum of the taps of one pass */
+    if (ksize == 1) return 0;
+    if (ksize == 3) { k = k3; norm = 4; }
+    else if (ksize == 5) { k = k5; norm = 16; }
+    else if (ksize == 7) { k = k7; norm = 64; }
+    else return -1;
+    const int h = ksize / 2;
+    /* two-dimensional tap sum in exact integers, one rounding: (sum + norm^2 / 2) / norm^2 */
+    const int n2 = norm * norm;
+    memcpy(scratch, img, (size_t)rows * (size_t)cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            int acc = 0;
+            for (int a = -h; a <= h; ++a) {
+                const int rr = reflect101(r + a, rows);
+                int row = 0;
+                for (int b = -h; b <= h; ++b) row += k[b + h] * scratch[(size_t)rr * cols + reflect101(c + b, cols)];
+                acc += k[a + h] * row;
+            }
+            img[(size_t)r * cols + c] = (uint8_t)((acc + n2 / 2) / n2);
+        }
+    return 0;
+}
+
+double bfo_nonzero_average(const uint8_t *img, int64_t n) {
+    double nz_avg = 0;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (img[i] == 0) continue;
+        cnt++;
+        nz_avg += img[i];
+    }
+    return (cnt == 0) ? 0 : nz_avg / (double)cnt;
+}
+
+double bfo_local_iteration_step(bfo_cloud *ev, const bfo_local_window *w, double nx_, double ny_, uint8_t *img,
+                                uint8_t *scratch) {
+    bfo_local_count_img(ev, w, nx_, ny_, img);
+    if (w->scale > 1) bfo_gauss_u8(img, w->scale_img_x, w->scale_img_y, w->scale, scratch);   /* :148-150 */
+    return bfo_nonzero_average(img, (int64_t)w->scale_img_x * w->scale_img_y);
+}
+
+int bfo_local_run(bfo_cloud *ev, const bfo_local_window *w, int32_t res_x, int32_t res_y, int64_t max_evaluations,
+                  bfo_local_state *st, uint8_t *img, uint8_t *scratch) {
+    st->nx = 0; st->ny = 0;                       /* :5 */
+    st->last_score = 0;
+    double dscore = 0;
+    st->dnx = 0.01; st->dny = 0.01;               /* :7 */
+    /* (NZ * T_DIVIDER * 1000.0) / (10 * scale * FROM_MS(MAX_TIME_MS)); FROM_MS(100) = ull(1e8) */
+    st->dn_th = (127 * 1 * 1000.0) / (double)(10ull * (unsigned long long)w->scale * 100000000ull);
+    st->evaluations = 0;
+    if ((w->scale_img_x < w->scale * res_x / 15) && (w->scale_img_y < w->scale * res_y / 15)) return 1;   /* :9-13 */
+    st->last_score = bfo_local_iteration_step(ev, w, st->nx, st->ny, img, scratch);   /* :16 */
+    st->evaluations = 1;
+    while (hypot(st->dnx, st->dny) > st->dn_th) {  /* :20 */
+        {   /* compute_new_nx, :90-102 */
+            const double nx_new = st->nx + st->dnx;
+            const double new_score = bfo_local_iteration_step(ev, w, nx_new, st->ny, img, scratch);
+            dscore = new_score - st->last_score;
+            st->last_score = new_score;
+            if (dscore <= 0) st->dnx = -st->dnx / 2.0;
+            st->nx = nx_new;
+        }
+        {   /* compute_new_ny, :105-117 */
+            const double ny_new = st->ny + st->dny;
+            const double new_score = bfo_local_iteration_step(ev, w, st->nx, ny_new, img, scratch);
+            dscore = new_score - st->last_score;
+            st->last_score = new_score;
+            if (dscore <= 0) st->dny = -st->dny / 2.0;
+            st->ny = ny_new;
+        }
+        st->evaluations += 2;
+        if (max_evaluations > 0 && st->evaluations >= max_evaluations) return -2;
+    }
+    return 0;
+}

@@ -122,6 +122,55 @@ int bfo_run(bfo_cloud *ev, const bfo_window *w, bfo_model *m, int32_t max_iterco
 /* event.h:135-142 */
 void bfo_compute_uv(const double *nx, const double *ny, int64_t n, double *u, double *v);
 
+
+/* ---- Contrast-score optimiser: OptimizerLocal (optimizer_sampler.h:12-68, optimizer_sampler.cpp) ----
+ * PARITY UNPINNED for the blur stage: the reference calls cv::GaussianBlur(CV_8UC1, ksize = scale,
+ * sigma = 0) from an un-vendored, un-versioned OpenCV; bfo_gauss_u8 below is this build's own stated
+ * 8-bit Gaussian (see its comment).  Everything before the blur restates the reference exactly. */
+typedef struct {
+    int32_t scale;
+    int32_t metric_wsizex, metric_wsizey;   /* optimizer_sampler.h:31-32,43-44 */
+    int32_t scale_img_x, scale_img_y;       /* :208-209 */
+    int32_t c_fr_x, c_fr_y;                 /* event_c (the window centre), :30,46 */
+    int64_t c_t;                            /* event_c.t (0 for the whole-cloud constructor) */
+} bfo_local_window;
+
+/* OptimizerLocal(events, scale) (optimizer_sampler.h:35-48): window = bounding box of the cloud
+ * (LinearEventCloud x_min.. seeded INT_MAX / INT_MIN, datastructures.h:127,143-147). */
+void bfo_local_window_cloud(const bfo_cloud *ev, int32_t scale, bfo_local_window *w);
+/* OptimizerLocal(events, e, scale, wsz) (optimizer_sampler.h:29-33). */
+void bfo_local_window_at(int32_t scale, int32_t wsz, int32_t c_fr_x, int32_t c_fr_y, int64_t c_t,
+                         bfo_local_window *w);
+
+/* Event::project for every event (event.h:65-70,164-168): absolute projection from fr. */
+void bfo_project(bfo_cloud *ev, double nx_, double ny_);
+
+/* The saturating u8 count image of iteration_step (optimizer_sampler.cpp:120-146), before the blur. */
+void bfo_local_count_img(bfo_cloud *ev, const bfo_local_window *w, double nx_, double ny_, uint8_t *img);
+
+/* This build's 8-bit Gaussian, in place, ksize in {1, 3, 5, 7}: the binomial taps OpenCV tabulates for
+ * sigma <= 0 ({1,2,1}/4, {1,4,6,4,1}/16, {2,7,14,18,14,7,2}/64), separable, exact integer arithmetic,
+ * border BORDER_REFLECT_101, one final rounding (half up).  Returns -1 for any other ksize. */
+int bfo_gauss_u8(uint8_t *img, int32_t rows, int32_t cols, int32_t ksize, uint8_t *scratch);
+
+/* get_event_score (optimizer_sampler.cpp:192-205): mean of the non-zero pixels. */
+double bfo_nonzero_average(const uint8_t *img, int64_t n);
+
+/* iteration_step (optimizer_sampler.cpp:120-153): project, count image, blur (scale > 1), score.
+ * img: scale_img_x * scale_img_y bytes, receives project_img. */
+double bfo_local_iteration_step(bfo_cloud *ev, const bfo_local_window *w, double nx_, double ny_, uint8_t *img,
+                                uint8_t *scratch);
+
+typedef struct {
+    double nx, ny, last_score, dnx, dny, dn_th;
+    int64_t evaluations;
+} bfo_local_state;
+
+/* run (optimizer_sampler.cpp:4-38).  Returns 0, or 1 when the window guard skips the cloud (:9-13);
+ * -2 if max_evaluations (>0) was reached (the reference has no cap). */
+int bfo_local_run(bfo_cloud *ev, const bfo_local_window *w, int32_t res_x, int32_t res_y, int64_t max_evaluations,
+                  bfo_local_state *out, uint8_t *img, uint8_t *scratch);
+
 #ifdef __cplusplus
 }
 #endif

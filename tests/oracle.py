@@ -49,6 +49,21 @@ class TraceRec(C.Structure):
     _fields_ = [("model", Model), ("loop", Loop)]
 
 
+class LocalWindow(C.Structure):
+    _fields_ = [
+        ("scale", C.c_int32), ("metric_wsizex", C.c_int32), ("metric_wsizey", C.c_int32),
+        ("scale_img_x", C.c_int32), ("scale_img_y", C.c_int32),
+        ("c_fr_x", C.c_int32), ("c_fr_y", C.c_int32), ("c_t", C.c_int64),
+    ]
+
+
+class LocalState(C.Structure):
+    _fields_ = [
+        ("nx", C.c_double), ("ny", C.c_double), ("last_score", C.c_double),
+        ("dnx", C.c_double), ("dny", C.c_double), ("dn_th", C.c_double), ("evaluations", C.c_int64),
+    ]
+
+
 class _Cloud(C.Structure):
     _fields_ = [
         ("n", C.c_int64),
@@ -74,6 +89,10 @@ def lib():
             build()
         L = C.CDLL(_LIB_PATH)
         L.bfo_run.restype = C.c_int
+        L.bfo_local_run.restype = C.c_int
+        L.bfo_gauss_u8.restype = C.c_int
+        L.bfo_nonzero_average.restype = C.c_double
+        L.bfo_local_iteration_step.restype = C.c_double
         _lib = L
     return _lib
 
@@ -144,6 +163,36 @@ class Cloud:
                            C.c_int64(trace_cap))
         return rc, loop, (list(trace)[: min(trace_cap, loop.itercount)] if trace_cap else [])
 
+    # ---- OptimizerLocal (optimizer_sampler.h / .cpp) ----
+    def local_window(self, scale, center=None, wsz=None):
+        w = LocalWindow()
+        if center is None:
+            lib().bfo_local_window_cloud(C.byref(self.c), C.c_int32(scale), C.byref(w))
+        else:
+            lib().bfo_local_window_at(C.c_int32(scale), C.c_int32(wsz), C.c_int32(center[0]), C.c_int32(center[1]),
+                                      C.c_int64(center[2]), C.byref(w))
+        return w
+
+    def local_count_img(self, w, nx, ny):
+        img = np.empty((w.scale_img_x, w.scale_img_y), dtype=np.uint8)
+        lib().bfo_local_count_img(C.byref(self.c), C.byref(w), C.c_double(nx), C.c_double(ny), _p(img, C.c_uint8))
+        return img
+
+    def local_iteration_step(self, w, nx, ny):
+        img = np.empty((w.scale_img_x, w.scale_img_y), dtype=np.uint8)
+        scratch = np.empty_like(img)
+        sc = lib().bfo_local_iteration_step(C.byref(self.c), C.byref(w), C.c_double(nx), C.c_double(ny),
+                                            _p(img, C.c_uint8), _p(scratch, C.c_uint8))
+        return sc, img
+
+    def local_run(self, w, res_x=180, res_y=240, max_evaluations=100000):
+        st = LocalState()
+        img = np.empty((max(w.scale_img_x, 1), max(w.scale_img_y, 1)), dtype=np.uint8)
+        scratch = np.empty_like(img)
+        rc = lib().bfo_local_run(C.byref(self.c), C.byref(w), C.c_int32(res_x), C.c_int32(res_y),
+                                 C.c_int64(max_evaluations), C.byref(st), _p(img, C.c_uint8), _p(scratch, C.c_uint8))
+        return rc, st, img
+
     def compute_uv(self):
         u = np.empty(self.n)
         v = np.empty(self.n)
@@ -183,3 +232,18 @@ def set_local_time(timestamp, t0):
     lib().bfo_set_local_time(_p(ts, C.c_uint64), C.c_int64(len(ts)), C.c_uint64(t0),
                              _p(out, C.c_int64))
     return out
+
+
+def gauss_u8(img, ksize):
+    out = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    scratch = np.empty_like(out)
+    rc = lib().bfo_gauss_u8(_p(out, C.c_uint8), C.c_int32(out.shape[0]), C.c_int32(out.shape[1]), C.c_int32(ksize),
+                            _p(scratch, C.c_uint8))
+    if rc != 0:
+        raise ValueError("unsupported ksize %d" % ksize)
+    return out
+
+
+def nonzero_average(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return lib().bfo_nonzero_average(_p(img, C.c_uint8), C.c_int64(img.size))

@@ -22,6 +22,7 @@ struct bf_ctx {
     bfo_window win;
     bfo_model model;
     bool have_window = false;
+    bfo_local_window lwin;
     std::vector<float> time_img;
     char err[128] = "";
     void bind() {
@@ -160,6 +161,38 @@ int bf_run(bf_ctx *c, const bf_run_opts *opts, bf_model *model_out, bf_run_info 
         info->rot_divider = lp.rot_divider; info->div_divider = lp.div_divider;
     }
     return rc < 0 ? BF_ERR_NOCONV : rc;
+}
+
+
+// ---- OptimizerLocal (optimizer_sampler.cpp) on the oracle ----
+int bf_local_set_window(bf_ctx *c, int32_t scale, int32_t wsz, int32_t c_fr_x, int32_t c_fr_y, int64_t c_t,
+                        bf_local_window *w) {
+    if (wsz <= 0) bfo_local_window_cloud(&c->cloud, scale, &c->lwin);
+    else bfo_local_window_at(scale, wsz, c_fr_x, c_fr_y, c_t, &c->lwin);
+    if (w) {
+        w->scale = c->lwin.scale; w->metric_wsizex = c->lwin.metric_wsizex; w->metric_wsizey = c->lwin.metric_wsizey;
+        w->scale_img_x = c->lwin.scale_img_x; w->scale_img_y = c->lwin.scale_img_y;
+        w->c_fr_x = c->lwin.c_fr_x; w->c_fr_y = c->lwin.c_fr_y; w->pad_ = 0; w->c_t = c->lwin.c_t;
+    }
+    return BF_OK;
+}
+
+int bf_local_iteration_step(bf_ctx *c, double nx, double ny, double *score, uint8_t *img_out) {
+    const size_t px = (size_t)c->lwin.scale_img_x * (size_t)c->lwin.scale_img_y;
+    std::vector<uint8_t> img(px), scratch(px);
+    *score = bfo_local_iteration_step(&c->cloud, &c->lwin, nx, ny, img.data(), scratch.data());
+    if (img_out) memcpy(img_out, img.data(), px);
+    return BF_OK;
+}
+
+int bf_local_run(bf_ctx *c, int32_t res_x, int32_t res_y, int64_t max_evaluations, bf_local_state *out) {
+    const size_t px = (size_t)c->lwin.scale_img_x * (size_t)c->lwin.scale_img_y;
+    std::vector<uint8_t> img(px + 1), scratch(px + 1);
+    bfo_local_state st;
+    int rc = bfo_local_run(&c->cloud, &c->lwin, res_x, res_y, max_evaluations, &st, img.data(), scratch.data());
+    out->nx = st.nx; out->ny = st.ny; out->last_score = st.last_score;
+    out->dnx = st.dnx; out->dny = st.dny; out->dn_th = st.dn_th; out->evaluations = st.evaluations;
+    return rc == -2 ? BF_ERR_NOCONV : rc;
 }
 
 }  // extern "C"

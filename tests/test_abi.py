@@ -34,9 +34,10 @@ def test_structs_match_header_sizes():
     """ctypes mirrors vs sizeof() as compiled into the library."""
     from better_flow_amd import accel
     lib = ctypes.CDLL(accel.LIB_PATH)
-    out = (ctypes.c_int32 * 6)()
-    assert lib.bf_abi_struct_sizes(out, 6) == 6
-    mirrors = [accel.Model, accel.Window, accel.RunOpts, accel.RunInfo, accel.TraceRec, accel.Profile]
+    out = (ctypes.c_int32 * 8)()
+    assert lib.bf_abi_struct_sizes(out, 8) == 8
+    mirrors = [accel.Model, accel.Window, accel.RunOpts, accel.RunInfo, accel.TraceRec, accel.Profile,
+               accel.LocalWindow, accel.LocalState]
     assert [ctypes.sizeof(m) for m in mirrors] == list(out)
     assert ctypes.sizeof(accel.Model) == 88 and accel.Model.total_dx.offset == 56
 

@@ -557,3 +557,78 @@ def test_single_launch_loop_bit_identical(accel_mod):
         assert runs["single"] == runs["multi"]
         assert runs["single512"] == runs["multi"]
         assert runs["multi"][1] > 30
+
+
+# ---- OptimizerLocal: the contrast-score optimiser (optimizer_sampler.cpp) ----
+
+def test_local_score_bit_exact(oracle_lib, accel_mod):
+    """Saturating count image, this build's 8-bit Gaussian and the non-zero mean: integer work, bit-exact
+    against the oracle for every supported scale, both constructors, a saturating cloud and shifted (nx, ny)."""
+    H, W = 180, 240
+    sl = synth.make_slice(60000, H, W, 0.05, seed=31)
+    for s in (1, 3, 5, 7):
+        oc = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+        acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=7 * H + 7, max_cols=7 * W + 7)
+        acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        for center, wsz in ((None, 0), ((70, 100, 20000000), 60)):
+            ow = oc.local_window(s, center=center, wsz=wsz)
+            gw = acc.local_set_window(s, center=center, wsz=wsz)
+            for f in ("metric_wsizex", "metric_wsizey", "scale_img_x", "scale_img_y", "c_fr_x", "c_fr_y", "c_t"):
+                assert getattr(ow, f) == getattr(gw, f), f
+            for nx, ny in ((0.0, 0.0), (-0.19, 0.38), (0.7, -1.3), (0.0, 0.0)):
+                osc, oimg = oc.local_iteration_step(ow, nx, ny)
+                gsc, gimg = acc.local_iteration_step(nx, ny, want_img=True)
+                assert np.array_equal(gimg, oimg), (s, center, nx, ny)
+                assert gsc == osc
+                assert acc.local_iteration_step(nx, ny) == osc   # without the image copy, planes alternate
+        acc.close()
+    # saturation at 255
+    n = 4000
+    fx, fy, t = np.full(n, 40, np.int32), np.full(n, 50, np.int32), np.arange(n, dtype=np.int64) * 1000
+    oc = oracle_lib.Cloud(fx, fy, t)
+    acc = accel_mod.Accel(max_events=n, max_rows=200, max_cols=200)
+    acc.upload_events(fx, fy, t)
+    ow = oc.local_window(3, center=(40, 50, 0), wsz=20)
+    acc.local_set_window(3, center=(40, 50, 0), wsz=20)
+    osc, oimg = oc.local_iteration_step(ow, 0.0, 0.0)
+    gsc, gimg = acc.local_iteration_step(0.0, 0.0, want_img=True)
+    assert oimg.max() > 200 and np.array_equal(gimg, oimg) and gsc == osc
+    acc.close()
+
+
+def test_local_run_same_trajectory(oracle_lib, accel_mod):
+    """The scores are exact, so the coordinate descent takes the same decisions: identical (nx, ny), steps,
+    final score and evaluation count; guard and state errors as specified."""
+    H, W, s = 180, 240, 3
+    sl = synth.make_slice(40000, H, W, 0.05, seed=32)
+    oc = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    ow = oc.local_window(s)
+    orc, ost, _ = oc.local_run(ow, res_x=H, res_y=W)
+    acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+    with pytest.raises(accel_mod.BfError):
+        acc.local_set_window(s)                      # nothing uploaded
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    with pytest.raises(accel_mod.BfError):
+        acc.local_run(H, W)                          # no window yet
+    acc.local_set_window(s)
+    grc, gst = acc.local_run(H, W)
+    assert (grc, gst.evaluations) == (orc, ost.evaluations) and gst.evaluations > 10
+    for f in ("nx", "ny", "last_score", "dnx", "dny", "dn_th"):
+        assert getattr(gst, f) == getattr(ost, f), f
+    # the rolling optimizer is undisturbed by local evaluations in between
+    acc.set_cloud(s, H, W)
+    rc1, m1, i1 = acc.run()
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    acc.set_cloud(s, H, W)
+    acc.local_set_window(s)
+    acc.local_iteration_step(0.1, 0.1)
+    rc2, m2, i2 = acc.run()
+    assert (rc1, i1.iterations, m1.as_dict()) == (rc2, i2.iterations, m2.as_dict())
+    # window guard (optimizer_sampler.cpp:9-13)
+    acc.upload_events(np.array([5, 6], np.int32), np.array([5, 7], np.int32), np.array([0, 10], np.int64))
+    acc.local_set_window(3)
+    rc, st = acc.local_run(H, W)
+    assert rc == accel_mod.BF_SKIPPED and st.evaluations == 0
+    with pytest.raises(accel_mod.BfError):
+        acc.local_set_window(9)                      # the Gaussian is stated up to 7
+    acc.close()

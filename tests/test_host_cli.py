@@ -105,3 +105,48 @@ def test_cli_gpu_matches_oracle_cli(oracle_cli, events_txt, tmp_path):
     # the library identifies itself as the HIP build, not the test shim
     ver = subprocess.check_output([gpu_cli, "--version"]).decode()
     assert "gfx950" in ver and "SHIM" not in ver
+
+
+# ---- OptimizerLocal through the host class (better_flow/optimizer_sampler.h) ----
+
+def _build_test_local(out_dir, against_gpu):
+    host = os.path.join(ROOT, "better_flow_amd", "host")
+    src = os.path.join(ROOT, "tests", "cpp", "test_local.cpp")
+    exe = os.path.join(out_dir, "test_local_gpu" if against_gpu else "test_local_oracle")
+    base = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-I" + host, "-I" + os.path.join(ROOT, "include"), src]
+    if against_gpu:
+        subprocess.check_call(base + ["-L" + os.path.join(ROOT, "better_flow_amd"), "-lbf_accel",
+                                      "-Wl,-rpath," + os.path.join(ROOT, "better_flow_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                                      "-o", exe])
+    else:
+        obj = os.path.join(out_dir, "bf_oracle_local.o")
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-c",
+                               os.path.join(ROOT, "oracle", "bf_oracle.c"), "-o", obj])
+        subprocess.check_call(base + [os.path.join(ROOT, "tests", "shim", "bf_accel_oracle_shim.cpp"), obj, "-lm",
+                                      "-o", exe])
+    return exe
+
+
+def _local_lines(exe, path, cwd):
+    return [ln for ln in run_cli(exe, [path], cwd).splitlines() if ln.startswith(("cloud", "window"))]
+
+
+def test_optimizer_local_host_class_oracle(events_txt, tmp_path):
+    path, _ = events_txt
+    lines = _local_lines(_build_test_local(str(tmp_path), False), path, str(tmp_path))
+    assert len(lines) == 3
+    m = re.match(r"cloud rc=0 nx=(\S+) ny=(\S+) score=(\S+) evals=(\d+)", lines[0])
+    assert m and int(m.group(4)) > 10 and float(m.group(3)) > 1.0
+    s0 = float(re.match(r"cloud score0=(\S+) img=(\d+)x(\d+)", lines[1]).group(1))
+    assert float(m.group(3)) >= s0          # the descent did not end below the score at (0, 0)
+    assert lines[2].startswith("window score=")
+
+
+@pytest.mark.gpu
+def test_optimizer_local_host_class_gpu_matches_oracle(events_txt, tmp_path):
+    """Same C++ caller, oracle shim vs libbf_accel.so: identical text (scores are exact integers ratios,
+    so the descent takes the same path)."""
+    path, _ = events_txt
+    want = _local_lines(_build_test_local(str(tmp_path), False), path, str(tmp_path))
+    got = _local_lines(_build_test_local(str(tmp_path), True), path, str(tmp_path))
+    assert got == want

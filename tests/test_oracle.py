@@ -187,3 +187,77 @@ def test_golden_vectors(oracle_lib):
                      r.loop.x_divider, r.loop.y_divider, r.loop.rot_divider, r.loop.div_divider]
                     for r in tr])
     assert np.array_equal(got, z["trajectory"])
+
+
+# ---- OptimizerLocal: the contrast-score optimiser (optimizer_sampler.cpp) ----
+
+def _np_gauss(img, k):
+    taps = {1: [1], 3: [1, 2, 1], 5: [1, 4, 6, 4, 1], 7: [2, 7, 14, 18, 14, 7, 2]}[k]
+    h = k // 2
+    pad = np.pad(img.astype(np.int64), h, mode="reflect") if h else img.astype(np.int64)   # == BORDER_REFLECT_101
+    acc = np.zeros(img.shape, dtype=np.int64)
+    for a in range(k):
+        for b in range(k):
+            acc += taps[a] * taps[b] * pad[a:a + img.shape[0], b:b + img.shape[1]]
+    n2 = sum(taps) ** 2
+    return ((acc + n2 // 2) // n2).astype(np.uint8)
+
+
+def test_local_gauss_matches_independent_numpy(oracle_lib):
+    rng = np.random.default_rng(5)
+    for shape in ((1, 1), (2, 9), (9, 2), (37, 53), (64, 64)):
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        img[rng.random(shape) < 0.4] = 0
+        for k in (1, 3, 5, 7):
+            if min(shape) > k // 2 or shape == (1, 1) and k == 1:   # np.pad cannot reflect past the array
+                assert np.array_equal(oracle_lib.gauss_u8(img, k), _np_gauss(img, k)), (shape, k)
+    # constant images stay constant; a saturated image stays 255
+    assert np.all(oracle_lib.gauss_u8(np.full((5, 7), 255, np.uint8), 7) == 255)
+    with pytest.raises(ValueError):
+        oracle_lib.gauss_u8(np.zeros((4, 4), np.uint8), 9)
+
+
+def test_local_count_image_and_score(oracle_lib):
+    H, W, s = 90, 120, 3
+    sl = synth.make_slice(6000, H, W, 0.05, seed=21)
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    w = c.local_window(s)
+    assert w.scale_img_x == w.metric_wsizex + s and w.c_t == 0
+    # independent numpy restatement of the splat at (nx, ny) = 0: pr == fr
+    img = c.local_count_img(w, 0.0, 0.0)
+    x = sl["fr_x"].astype(np.int64) * s + (-w.c_fr_x * s + w.metric_wsizex / 2.0)
+    y = sl["fr_y"].astype(np.int64) * s + (-w.c_fr_y * s + w.metric_wsizey / 2.0)
+    X, Y = np.trunc(x).astype(np.int64), np.trunc(y).astype(np.int64)
+    ok = (X >= 0) & (X < w.metric_wsizex) & (Y >= 0) & (Y < w.metric_wsizey)
+    ref = np.zeros(img.shape, dtype=np.int64)
+    for da in range(s):
+        for db in range(s):
+            np.add.at(ref, (X[ok] + da, Y[ok] + db), 1)
+    assert np.array_equal(img, np.minimum(ref, 255).astype(np.uint8))
+    # saturation really happens on a dense cloud
+    dense = oracle_lib.Cloud(np.full(5000, 40, np.int32), np.full(5000, 50, np.int32), np.arange(5000, dtype=np.int64))
+    wd = dense.local_window(3, center=(40, 50, 0), wsz=20)
+    assert dense.local_count_img(wd, 0.0, 0.0).max() == 255
+    # score == mean of the non-zero pixels of the blurred image
+    sc, blurred = c.local_iteration_step(w, 0.05, -0.02)
+    nz = blurred[blurred > 0].astype(np.float64)
+    assert sc == nz.sum() / len(nz) == oracle_lib.nonzero_average(blurred)
+    assert np.array_equal(blurred, _np_gauss(c.local_count_img(w, 0.05, -0.02), s))
+
+
+def test_local_run_sharpens_the_image(oracle_lib):
+    """Coordinate descent of optimizer_sampler.cpp:4-38 on a translating scene: terminates on the step
+    threshold and ends at a higher contrast score than it started with."""
+    H, W, s = 90, 120, 3
+    sl = synth.make_slice(8000, H, W, 0.05, seed=22)
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    w = c.local_window(s)
+    s0, _ = c.local_iteration_step(w, 0.0, 0.0)
+    rc, st, img = c.local_run(w, res_x=H, res_y=W)
+    assert rc == 0 and st.evaluations % 2 == 1 and 10 < st.evaluations < 400
+    assert np.hypot(st.dnx, st.dny) <= st.dn_th == 127000.0 / (10 * s * 1e8)
+    assert st.last_score > s0
+    # guard: a window smaller than scale * RES / 15 in both directions is skipped (:9-13)
+    tiny = oracle_lib.Cloud(np.array([5, 6], np.int32), np.array([5, 7], np.int32), np.array([0, 10], np.int64))
+    rc2, st2, _ = tiny.local_run(tiny.local_window(3), res_x=H, res_y=W)
+    assert rc2 == 1 and st2.evaluations == 0

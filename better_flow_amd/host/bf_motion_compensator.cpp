@@ -18,6 +18,7 @@ bool manual = false;
 bool quiet = false;
 char *file = NULL;
 char *outFileName = NULL;
+const char *to_bin = NULL;
 bool gpu = false;
 bool img = false;
 bool video = false;
@@ -59,6 +60,7 @@ static void usage(int ret) {
     printf("    [--scale=<odd>]\t\t\t\tImage scale used by the minimizer (default = %d)\n", opt_scale);
     printf("    [--max-iter=<n>]\t\t\t\tCap on minimizer iterations per slice (default = unlimited)\n");
     printf("    [--device=<n>]\t\t\t\tHIP device index (default = 0)\n");
+    printf("    [--to-bin=<name>]\t\t\t\tOnly convert the (text) input to the binary event format and exit\n");
     printf("    <file to process or \"-\" for stdin>\n");
     exit(ret);
 }
@@ -115,6 +117,8 @@ int main(int argc, char *argv[]) {
             opt_max_iter = atoi(argv[i] + 11);
         else if (!strncmp(argv[i], "--device=", 9))
             bf::DeviceContext::device() = atoi(argv[i] + 9);
+        else if (!strncmp(argv[i], "--to-bin=", 9))
+            to_bin = argv[i] + 9;
         else if (!strcmp(argv[i], "-o")) {
             if (++i == argc) {
                 fprintf(stderr, "No output file specified after -o option.\n");
@@ -138,6 +142,25 @@ int main(int argc, char *argv[]) {
     if (file == NULL) {
         fprintf(stderr, "No input file.\n");
         usage(1);
+    }
+    if (to_bin != NULL) {   // text -> binary structure-of-arrays (better_flow/event_reader.h); no GPU involved
+        bf::EventReader reader(file);
+        if (!reader.good()) {
+            fprintf(stderr, "cannot read '%s'\n", file);
+            return 1;
+        }
+        std::vector<uint64_t> t;
+        std::vector<uint16_t> x, y;
+        std::vector<uint8_t> p;
+        reader.for_each_event([&](unsigned row, unsigned col, unsigned long long t_ns) {
+            t.push_back(t_ns); x.push_back((uint16_t)col); y.push_back((uint16_t)row); p.push_back(1);
+        });
+        if (!bf::EventReader::write_binary(to_bin, t, x, y, p)) {
+            fprintf(stderr, "cannot write '%s'\n", to_bin);
+            return 1;
+        }
+        if (!quiet) std::cout << "Converted " << t.size() << " events to " << to_bin << std::endl;
+        return 0;
     }
     if (opt_scale < 1 || opt_scale % 2 == 0) {
         fprintf(stderr, "--scale must be odd.\n");
@@ -178,24 +201,15 @@ int main(int argc, char *argv[]) {
         std::cout << "Toatal flow elapsed: " << double(end - begin) / CLOCKS_PER_SEC << " sec." << std::endl << std::flush;
     } else {
         if (!quiet) std::cout << "Reading from file... (" << file << ")" << std::endl << std::flush;
-        std::ifstream event_file(file, std::ifstream::in);
-        ull i = 0;
-        double t = 0;
-        uint x = 0, y = 0;
-        bool p = false;
-        double t_0 = 0;   // the earliest timestamp in the file
-        if (event_file >> t_0 >> x >> y >> p) {
-            ++i;
-            Event e(y, x, FROM_SEC(0));
-            estimator.add_event(e);
+        bf::EventReader reader(file);   // text "t x y p" or binary SoA (better_flow/event_reader.h)
+        if (!reader.good()) {
+            fprintf(stderr, "cannot read '%s'\n", file);
+            return 1;
         }
-        while (event_file >> t >> x >> y >> p) {
-            t -= t_0;
-            ++i;
-            Event e(y, x, FROM_SEC(t));
+        ull i = reader.for_each_event([&](unsigned row, unsigned col, unsigned long long t_ns) {
+            Event e(row, col, (ull)t_ns);
             estimator.add_event(e);
-        }
-        event_file.close();
+        });
         if (!quiet) std::cout << "Read and processed " << i << " events" << std::endl << std::flush;
     }
 

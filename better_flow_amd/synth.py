@@ -72,3 +72,20 @@ def write_txt(path, sl, time_offset_s=1.0):
     with open(path, "w") as f:
         for t, r, c in zip(sl["t"], sl["fr_x"], sl["fr_y"]):
             f.write("%.9f %d %d 1\n" % (time_offset_s + t * 1e-9, c, r))
+
+
+def write_bin(path, sl, time_offset_s=1.0):
+    """Binary structure-of-arrays event file (better_flow_amd/host/better_flow/event_reader.h): magic
+    "BFEVSOA1", u64 n, u64 t_ns[n], u16 x[n] (column), u16 y[n] (row), u8 p[n].  Times are what the CLI
+    derives from the text form written by write_txt: ull(1e9 * (t - t_0)) on the printed decimals."""
+    import numpy as np
+    txt = np.array([float("%.9f" % (time_offset_s + t * 1e-9)) for t in sl["t"]])
+    rel = txt - txt[0] if len(txt) else txt
+    t_ns = (1000000000 * rel).astype(np.uint64)      # truncation, like the reference's FROM_SEC
+    with open(path, "wb") as f:
+        f.write(b"BFEVSOA1")
+        f.write(np.uint64(len(t_ns)).tobytes())
+        f.write(t_ns.astype("<u8").tobytes())
+        f.write(np.asarray(sl["fr_y"]).astype("<u2").tobytes())
+        f.write(np.asarray(sl["fr_x"]).astype("<u2").tobytes())
+        f.write(np.ones(len(t_ns), dtype=np.uint8).tobytes())

@@ -150,3 +150,63 @@ def test_optimizer_local_host_class_gpu_matches_oracle(events_txt, tmp_path):
     want = _local_lines(_build_test_local(str(tmp_path), False), path, str(tmp_path))
     got = _local_lines(_build_test_local(str(tmp_path), True), path, str(tmp_path))
     assert got == want
+
+
+# ---- event input: fast text parser and the binary structure-of-arrays format ----
+
+def _build_cpp(tmp_path, name):
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-I" + os.path.join(ROOT, "better_flow_amd", "host"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+                           "-o", exe])
+    return exe
+
+
+def test_event_reader_matches_iostream(events_txt, tmp_path):
+    exe = _build_cpp(tmp_path, "test_reader")
+    path, sl = events_txt
+    out = subprocess.check_output([exe, path]).decode()
+    assert out.strip() == "records %d mismatches 0" % len(sl["t"])
+    rng = np.random.default_rng(3)
+    # awkward but legal numbers, mixed whitespace, then a malformed record where both must stop
+    lines = []
+    for k in range(4000):
+        digits = int(rng.integers(1, 25))
+        t = "".join(str(d) for d in rng.integers(0, 10, digits))
+        cut = int(rng.integers(0, digits + 1))
+        t = (t[:cut] or "0") + "." + t[cut:] if rng.random() < 0.8 else t
+        if rng.random() < 0.1:
+            t += "e%d" % rng.integers(-30, 30)
+        if rng.random() < 0.1:
+            t = "-" + t
+        sep = rng.choice([" ", "\t", "  ", " \t "])
+        lines.append(sep.join([t, str(rng.integers(0, 70000)), str(rng.integers(0, 400)), str(rng.integers(0, 2))]))
+    weird = str(tmp_path / "weird.txt")
+    open(weird, "w").write("\n".join(lines[:3000]) + "\r\n\n" + "\n".join(lines[3000:]) + "\n1.5 10 20 2\n3.0 1 1 1\n")
+    out = subprocess.check_output([exe, weird]).decode()
+    assert out.strip() == "records 4000 mismatches 0"      # "... 2" is not a bool: both stop there
+    for content, n in (("", 0), ("abc 1 2 1\n", 0), ("1.0 2 3 1\n4.0 x 3 1\n", 1), ("1 2 3 1 5", 1)):
+        open(weird, "w").write(content)
+        assert subprocess.check_output([exe, weird]).decode().strip() == "records %d mismatches 0" % n
+
+
+def test_cli_binary_input_equals_text_input(oracle_cli, events_txt, tmp_path):
+    """--to-bin converts; the binary file drives the same slices and writes the same output file."""
+    path, sl = events_txt
+    binp = str(tmp_path / "ev.bin")
+    run_cli(oracle_cli, ["--to-bin=" + binp, path], str(tmp_path))
+    raw = open(binp, "rb").read()
+    n = len(sl["t"])
+    assert raw[:8] == b"BFEVSOA1" and int.from_bytes(raw[8:16], "little") == n and len(raw) == 16 + 13 * n
+    cols = np.frombuffer(raw, dtype="<u2", count=n, offset=16 + 8 * n)
+    assert np.array_equal(cols, sl["fr_y"].astype(np.uint16))        # x is the column
+    outs = []
+    for inp in (path, binp):
+        o = str(tmp_path / ("o_%d.txt" % len(outs)))
+        so = run_cli(oracle_cli, ["-o", o, inp], str(tmp_path))
+        outs.append((parse_summary(so), open(o).read()))
+    assert outs[0] == outs[1]
+    # synth.write_bin writes the same bytes as the converter
+    py = str(tmp_path / "py.bin")
+    synth.write_bin(py, sl)
+    assert open(py, "rb").read() == raw

@@ -116,6 +116,9 @@ struct bf_ctx {
     bool degenerate = false;         // window with R <= 0 or C <= 0 (empty slice)
     bool pending_warp = false;       // bf_set_model's warp not applied yet
     bool n_valid = false;            // d_nxny holds the n of the last warp
+    int warm_iters_hint = 6;         // iterations the previous warm-started run needed
+    bool p_clean = false;            // p is all zero (Event::reset state): set by the upload, cleared by any warp
+    bool uv_valid = false;           // d_uv holds compute_uv of that n (fused into bf_run's final warp)
     int cur = 0;                     // plane buffer that is guaranteed all-zero
     bool planes_unknown = true;      // both buffers must be cleared before use
     int last_R = 0, last_C = 0;
@@ -214,12 +217,21 @@ WarpParams identity_warp() {
     return w;
 }
 
+EvSets ev_sets(const bf_ctx* c) {
+    EvSets e;
+    for (int i = 0; i < 2; ++i) {
+        e.s[i].xy = c->set[i].xy; e.s[i].t = c->set[i].t; e.s[i].p = c->set[i].p; e.s[i].perm = c->set[i].perm;
+    }
+    return e;
+}
+
 WarpScatterArgs ws_args(bf_ctx* c, int buf, int check_done) {
     WarpScatterArgs a;
     const bf_ctx::EvSet& e = c->set[c->cs];
     a.xy = e.xy; a.t = e.t; a.p = e.p;
     a.noise = c->has_noise ? c->d_noise : nullptr;
     a.nxny = c->d_nxny;
+    a.uv = nullptr;
     a.perm = c->has_perm ? e.perm : nullptr;
     a.plane = c->d_plane[buf];
     a.cplane = c->d_cplane[buf];
@@ -227,6 +239,8 @@ WarpScatterArgs ws_args(bf_ctx* c, int buf, int check_done) {
     a.n = c->n;
     a.check_done = check_done;
     a.packed = c->packed;
+    a.sets = ev_sets(c);
+    a.pick_set = 0;
     return a;
 }
 
@@ -311,20 +325,13 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
     return BF_OK;
 }
 
-EvSets ev_sets(const bf_ctx* c) {
-    EvSets e;
-    for (int i = 0; i < 2; ++i) {
-        e.s[i].xy = c->set[i].xy; e.s[i].t = c->set[i].t; e.s[i].p = c->set[i].p; e.s[i].perm = c->set[i].perm;
-    }
-    return e;
-}
 
 // Device-conditional counting sort of the live events by the image tile of their current
 // target (runs only when hot.need_rebin is set); no host synchronisation.
-int enqueue_rebin(bf_ctx* c, bool has_perm_at_start) {
+int enqueue_rebin(bf_ctx* c, bool has_perm_at_start, const WarpParams* prewarp = nullptr) {
     ProfScope ps(c, 3);
     launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, c->d_state, c->grid, c->d_binid, c->d_hist_cnt,
-                 c->d_hist_ts, c->d_bin_start, c->d_cursor, c->d_armed, c->stream);
+                 c->d_hist_ts, c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->stream);
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -338,7 +345,9 @@ int flush_pending(bf_ctx* c) {
         launch_warp_scatter(ws_args(c, c->cur, 0), true, false, true, c->stream);
     }
     c->pending_warp = false;
+    c->p_clean = false;
     c->n_valid = true;
+    c->uv_valid = false;
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -374,6 +383,7 @@ int fold_stats(bf_ctx* c) {
 }
 
 int after_upload(bf_ctx* c, long long n) {
+    c->p_clean = true;   // k_prepare wrote p = 0
     c->stats_valid = false;
     c->have_lwin = false;
     c->n = n;
@@ -382,6 +392,7 @@ int after_upload(bf_ctx* c, long long n) {
     c->all_noise = false;
     c->pending_warp = false;
     c->n_valid = false;
+    c->uv_valid = false;
     return BF_OK;
 }
 
@@ -769,8 +780,10 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     c->pending_warp = false;
     c->all_noise = false;
     // Event::reset for every event (set_cloud :260).  bf_upload_events already reset p.
-    HIP_TRY(c, hipMemsetAsync(c->set[c->cs].p, 0, (size_t)c->n_pad * sizeof(float2), c->stream));
+    if (!c->p_clean) HIP_TRY(c, hipMemsetAsync(c->set[c->cs].p, 0, (size_t)c->n_pad * sizeof(float2), c->stream));
+    c->p_clean = true;
     c->n_valid = false;
+    c->uv_valid = false;
     // Tile-binned scatter: usable when the packed accumulator can hold the whole slice (then
     // it can hold any bin), there is no noise mask, and the bin grid fits the kernels' LDS.
     {
@@ -841,7 +854,9 @@ int bf_project_4param_reinit(bf_ctx* c, double dnx_, double dny_, double cx, dou
         ProfScope ps(c, 0, c->n);
         launch_warp_scatter(ws_args(c, c->cur, 0), true, false, true, c->stream);
     }
+    c->p_clean = false;
     c->n_valid = true;
+    c->uv_valid = false;
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -1004,9 +1019,10 @@ int bf_compute_uv(bf_ctx* c, double* u, double* v) {
         }
         return BF_OK;
     }
-    {
+    if (!c->uv_valid) {   // (bf_run with want_uv already produced it in its final warp)
         ProfScope ps(c, 3);
         launch_compute_uv(c->d_nxny, c->d_uv, c->n, c->stream);
+        c->uv_valid = true;
     }
     HIP_TRY(c, hipGetLastError());
     return copy_pairs(c, c->d_uv, u, v);
@@ -1065,18 +1081,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         HIP_TRY(c, hipMalloc(&c->d_trace, (size_t)o.trace_cap * sizeof(bf_trace_rec)));
         c->trace_alloc = o.trace_cap;
     }
+    c->p_clean = false;   // the loop warps the events
     const bool binned = c->use_binned;
     DevState& h = c->hst;
     // Tile-binned mode sorts the events by the tile of their CURRENT target, so a warm-start
     // warp (bf_set_model) is applied before the sort rather than inside the first iteration.
     bool first_warp = c->pending_warp;
-    if (binned && c->pending_warp) {
-        launch_set_state(c->d_state, h, c->stream);
-        ProfScope ps(c, 0, c->n);
-        launch_warp_scatter(ws_args(c, c->cur, 0), true, false, false, c->stream);
-        first_warp = false;
-        inf.launches++;
-    }
+    const bool warm_start = c->pending_warp;
+    WarpParams prewarp_wp = h.hot.wp;
+    const bool prewarp = binned && c->pending_warp;   // fused into the first counting sort (k_bin_count<true>)
+    if (prewarp) first_warp = false;
     c->pending_warp = false;
     h.x_div = h.y_div = 1.0f;            // :61
     h.rot_div = h.div_div = 10000.0f;    // :62-63
@@ -1106,7 +1120,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         int gx, gy;
         stencil_grid(w.scale_img_x, w.scale_img_y, &gx, &gy);
         for (int round = 0;; ++round) {
-            int rc = enqueue_rebin(c, perm_at_start);   // round 0: builds the bins
+            int rc = enqueue_rebin(c, perm_at_start, (prewarp && round == 0) ? &prewarp_wp : nullptr);   // round 0: builds the bins
             if (rc != BF_OK) return rc;
             HIP_TRY(c, hipMemsetAsync(c->d_bar, 0, 4096, c->stream));
             PersistArgs pa;
@@ -1155,6 +1169,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
     bool want_rebin = false;
+    bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
     for (int batch = 0; !c->use_persist; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
@@ -1163,13 +1178,21 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // (0.6 x margin of drift), which covers the one-to-two batches of polling lag; anything
         // that still escapes takes the exact overflow path.
         if (binned && (batch == 0 || want_rebin)) {
-            int rc = enqueue_rebin(c, perm_at_start);
+            int rc = enqueue_rebin(c, perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr);
             if (rc != BF_OK) return rc;
-            inf.launches += 4;
+            inf.launches += 3;
             want_rebin = false;
             skip_rebin_checks = 1;   // the next snapshot predates this re-bin
         }
-        for (int k = 0; k < o.poll_interval; ++k) {
+        // A warm start (bf_set_model) converges in a handful of iterations: its first batch is short and is
+        // polled at once, so that ~20 no-op launches and a second poll are not queued behind it.
+        int batch_len = o.poll_interval;
+        if (warm_start) {   // one more iteration than the previous warm start needed, then two at a time
+            batch_len = batch == 0 ? c->warm_iters_hint + 1 : 2;
+            if (batch_len < 2) batch_len = 2;
+            if (batch_len > o.poll_interval) batch_len = o.poll_interval;
+        }
+        for (int k = 0; k < batch_len; ++k) {
             const bool warp = first ? first_warp : true;
             if (binned) {
                 ProfScope ps(c, 0, c->n);
@@ -1197,11 +1220,37 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             ++launched_iters;
             inf.launches += 2;
         }
+        if (warm_start) {
+            // A warm start is polled batch by batch (no pipelining: it rarely needs a second batch), and the
+            // final warp rides along with every batch, gated on `done` (check_done 2) and picking the event
+            // set on the device: when the batch was enough -- the usual case -- nothing is left to launch
+            // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
+            ProfScope ps(c, 0, c->n);
+            WarpScatterArgs fa = ws_args(c, buf, 2);
+            fa.pick_set = binned ? 1 : 0;
+            if (o.want_uv) fa.uv = c->d_uv;
+            launch_warp_scatter(fa, true, false, true, c->stream);
+            inf.launches++;
+        }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState),
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipEventRecord(c->poll_ev[batch & 1], c->stream));
-        if (batch == 0) continue;
+        if (batch == 0 && !warm_start) continue;
+        if (warm_start) {   // look at this batch straight away
+            HIP_TRY(c, hipEventSynchronize(c->poll_ev[batch & 1]));
+            inf.polls++;
+            const DevState& ws = c->h_state[batch & 1];
+            if (ws.hot.done) {
+                fin = ws;
+                final_done = true;
+                break;
+            }
+            if (binned && ws.hot.need_rebin) want_rebin = true;
+            if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
+                return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
+            continue;
+        }
         HIP_TRY(c, hipEventSynchronize(c->poll_ev[(batch - 1) & 1]));
         inf.polls++;
         const DevState& snap = c->h_state[(batch - 1) & 1];
@@ -1220,17 +1269,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     }
     // final warp: the last project_4param_reinit of iteration_step (:340-344), kept so that
     // pr / nx / ny describe the converged model; n is written for compute_uv / writeout.
-    {
+    if (!final_done) {
         ProfScope ps(c, 0, c->n);
-        launch_warp_scatter(ws_args(c, buf, 0), true, false, true, c->stream);
-    }
-    inf.launches++;
-    c->n_valid = true;
-    if (o.want_uv) {
-        ProfScope ps(c, 3);
-        launch_compute_uv(c->d_nxny, c->d_uv, c->n, c->stream);
+        WarpScatterArgs fa = ws_args(c, buf, 0);
+        if (o.want_uv) fa.uv = c->d_uv;   // Event::compute_uv (event.h:135-142) in the same pass
+        launch_warp_scatter(fa, true, false, true, c->stream);
         inf.launches++;
     }
+    if (warm_start) c->warm_iters_hint = fin.hot.it;
+    c->n_valid = true;
+    c->uv_valid = o.want_uv != 0;
     HIP_TRY(c, hipGetLastError());
     if (o.want_uv) HIP_TRY(c, hipStreamSynchronize(c->stream));
 
@@ -1340,7 +1388,9 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
             infos_out[i] = inf;
         }
     }
+    c->p_clean = false;
     c->n_valid = true;
+    c->uv_valid = false;
     c->pending_warp = false;
     c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
     c->degenerate = false;

@@ -58,6 +58,27 @@ __device__ __forceinline__ double pr_from_p(uint32_t fr, float prod) {
     return (double)(float)fr - div_10000((double)prod);
 }
 
+// Event::project_4param_reinit (event.h:99-110) + apply_project (event.h:164-168) of one event -- the ONE
+// place this arithmetic lives.  In: the event's previous projected position (pr_x, pr_y) and slice-local time.
+// Out: the direction vector (nx, ny) and the two f32 products q = (kx * float(t), ky * float(t)) from which
+// pr is re-derived with pr_from_p.  No operation may be contracted (-ffp-contract=off).
+__device__ __forceinline__ void warp_products(const WarpParams& wp, double pr_x, double pr_y, int32_t t, float2& q,
+                                              double& nx, double& ny) {
+    // event.h:100-108
+    const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
+    const double qx = wp.c * rx - wp.s * ry;
+    const double qy = wp.s * rx + wp.c * ry;
+    nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
+    ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
+    // event.h:164-165: float kx = float(nx) / nz.  The double division rounded to float equals the
+    // correctly rounded f32 division (double has >= 2 * 24 + 2 digits).
+    const float kx = div_127((float)nx);
+    const float ky = div_127((float)ny);
+    const float ft = (float)t;   // round-to-nearest int -> f32, as float(sll t)
+    q.x = kx * ft;
+    q.y = ky * ft;
+}
+
 __device__ __forceinline__ int wave_min(int v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, 64));
     return v;

@@ -22,12 +22,15 @@ struct WarpScatterArgs {
     float2* p;
     const uint8_t* noise;          // may be NULL
     double2* nxny;                 // written only by the final warp, at [perm[i]]
+    double2* uv;                   // optional: Event::compute_uv fused into the final warp
     const uint32_t* perm;          // original index of slot i (NULL: identity)
     unsigned long long* plane;     // point-scatter accumulator (current buffer)
     uint32_t* cplane;              // SPLIT mode count plane (current buffer)
     const DevState* st;
     long long n;
-    int check_done;                // 1 inside the fused loop: return at once if st->done
+    int check_done;                // 1 inside the fused loop: return at once if st->done; 2: run only if done
+    EvSets sets;                   // pick_set: take xy / t / p / perm from sets.s[hot.cs ^ hot.flip] instead
+    int pick_set;
     bool packed;
 };
 
@@ -98,7 +101,7 @@ int bin_kernel_setup();
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
                   uint16_t* binid, uint32_t* hist_cnt, unsigned long long* hist_ts, uint32_t* bin_start,
-                  uint32_t* cursor, uint32_t* armed, hipStream_t s);
+                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, hipStream_t s);
 void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs,
                              unsigned long long* ovf_plane, uint32_t* ovf_cplane, DevState* st,
                              const BinGrid& g, int cur, bool warp, int check_done, int threads,

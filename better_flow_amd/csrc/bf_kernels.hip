@@ -26,9 +26,19 @@
 
 namespace bf {
 
+// Event::compute_uv, event.h:135-142.
+__device__ __forceinline__ double2 uv_from_n(double2 v) {
+    const double len = hypot(v.x, v.y);
+    const double speed = len / (127.0 / (double)(1000000000 / (1 * 10000)));
+    double2 o;
+    o.x = (len == 0) ? 0 : speed * v.x / len;
+    o.y = (len == 0) ? 0 : speed * v.y / len;
+    return o;
+}
+
 template <bool WARP, bool SCATTER, bool WRITE_N, bool PACKED>
 __device__ __forceinline__ void event_body(uint32_t xy, int32_t t, float2& p, bool live,
-                                           bool noise, double2* nxny, const uint32_t* perm,
+                                           bool noise, double2* nxny, double2* uv, const uint32_t* perm,
                                            long long slot,
                                            unsigned long long* plane, uint32_t* cplane,
                                            const HotState& st, const WarpParams& wp) {
@@ -36,22 +46,15 @@ __device__ __forceinline__ void event_body(uint32_t xy, int32_t t, float2& p, bo
     double pr_x = pr_from_p(fx, p.x);
     double pr_y = pr_from_p(fy, p.y);
     if (WARP) {
-        // event.h:100-108
-        const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
-        const double qx = wp.c * rx - wp.s * ry;
-        const double qy = wp.s * rx + wp.c * ry;
-        const double nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
-        const double ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
-        // event.h:164-165: float kx = float(nx) / nz.  The double division rounded to float
-        // equals the correctly rounded f32 division (double has >= 2*24+2 digits).
-        const float kx = div_127((float)nx);
-        const float ky = div_127((float)ny);
-        const float ft = (float)t;   // round-to-nearest int -> f32, as float(sll t)
-        p.x = kx * ft;
-        p.y = ky * ft;
+        double nx, ny;
+        warp_products(wp, pr_x, pr_y, t, p, nx, ny);
         pr_x = pr_from_p(fx, p.x);
         pr_y = pr_from_p(fy, p.y);
-        if (WRITE_N && live) nxny[perm ? (long long)perm[slot] : slot] = make_double2(nx, ny);
+        if (WRITE_N && live) {
+            const long long o = perm ? (long long)perm[slot] : slot;
+            nxny[o] = make_double2(nx, ny);
+            if (uv) uv[o] = uv_from_n(make_double2(nx, ny));   // compute_uv fused into the final warp
+        }
     }
     if (SCATTER) {
         if (live && !noise) {
@@ -76,14 +79,22 @@ __device__ __forceinline__ void event_body(uint32_t xy, int32_t t, float2& p, bo
 
 template <bool WARP, bool SCATTER, bool WRITE_N, bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_warp_scatter(
-    const uint32_t* __restrict__ xy, const int32_t* __restrict__ t, float2* __restrict__ p,
-    const uint8_t* __restrict__ noise, double2* __restrict__ nxny, const uint32_t* __restrict__ perm,
+    const uint32_t* xy, const int32_t* t, float2* p,
+    const uint8_t* __restrict__ noise, double2* __restrict__ nxny, double2* __restrict__ uv,
+    const uint32_t* perm,
     unsigned long long* __restrict__ plane, uint32_t* __restrict__ cplane,
-    const DevState* __restrict__ st, long long n, int check_done) {
+    const DevState* __restrict__ st, long long n, int check_done, EvSets sets, int pick_set) {
     const HotState hs = st->hot;   // one burst of scalar loads, then the branch
-    if (check_done && hs.done) return;
+    // check_done 1: a loop kernel, idle once the loop is done; 2: the final warp enqueued ahead of the poll,
+    // runs only if the loop IS done
+    if (check_done == 1 && hs.done) return;
+    if (check_done == 2 && !hs.done) return;
     const long long base = ((long long)blockIdx.x * kThreads + threadIdx.x) * kEvPerThread;
     if (base >= n) return;
+    if (pick_set) {   // tile-binned loop: the device knows which set holds the (sorted) events
+        const EvSetPtrs e = (hs.cs ^ hs.flip) ? sets.s[1] : sets.s[0];
+        xy = e.xy; t = e.t; p = e.p; perm = e.perm;
+    }
     const WarpParams& wp = hs.wp;
     // arrays are padded to a multiple of kEvPerThread * kThreads elements
     const uint4 vxy = *reinterpret_cast<const uint4*>(xy + base);
@@ -97,13 +108,13 @@ __global__ __launch_bounds__(kThreads) void k_warp_scatter(
         const uchar4 vn = *reinterpret_cast<const uchar4*>(noise + base);
         z0 = vn.x; z1 = vn.y; z2 = vn.z; z3 = vn.w;
     }
-    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.x, vt.x, p0, base + 0 < n, z0, nxny, perm, base + 0,
+    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.x, vt.x, p0, base + 0 < n, z0, nxny, uv, perm, base + 0,
                                                plane, cplane, hs, wp);
-    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.y, vt.y, p1, base + 1 < n, z1, nxny, perm, base + 1,
+    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.y, vt.y, p1, base + 1 < n, z1, nxny, uv, perm, base + 1,
                                                plane, cplane, hs, wp);
-    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.z, vt.z, p2, base + 2 < n, z2, nxny, perm, base + 2,
+    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.z, vt.z, p2, base + 2 < n, z2, nxny, uv, perm, base + 2,
                                                plane, cplane, hs, wp);
-    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.w, vt.w, p3, base + 3 < n, z3, nxny, perm, base + 3,
+    event_body<WARP, SCATTER, WRITE_N, PACKED>(vxy.w, vt.w, p3, base + 3 < n, z3, nxny, uv, perm, base + 3,
                                                plane, cplane, hs, wp);
     if (WARP) {
         *reinterpret_cast<float4*>(p + base) = make_float4(p0.x, p0.y, p1.x, p1.y);
@@ -301,18 +312,11 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(DevState* st, const Part
     model_update(st, &s_state, t, trace, mode, cur);
 }
 
-// Event::compute_uv, event.h:135-142.
 __global__ __launch_bounds__(kThreads) void k_compute_uv(const double2* __restrict__ nxny,
                                                          double2* __restrict__ uv, long long n) {
     const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
-    const double2 v = nxny[i];
-    const double len = hypot(v.x, v.y);
-    const double speed = len / (127.0 / (double)(1000000000 / (1 * 10000)));
-    double2 o;
-    o.x = (len == 0) ? 0 : speed * v.x / len;
-    o.y = (len == 0) ? 0 : speed * v.y / len;
-    uv[i] = o;
+    uv[i] = uv_from_n(nxny[i]);
 }
 
 // pr / n read-back helper for writeout_events (accel_lib.h:310-329).
@@ -351,10 +355,10 @@ template <bool W, bool S, bool N>
 static void launch_ws(const WarpScatterArgs& a, hipStream_t s, dim3 grid) {
     if (a.packed)
         hipLaunchKernelGGL((k_warp_scatter<W, S, N, true>), grid, dim3(kThreads), 0, s, a.xy, a.t, a.p,
-                           a.noise, a.nxny, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done);
+                           a.noise, a.nxny, a.uv, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done, a.sets, a.pick_set);
     else
         hipLaunchKernelGGL((k_warp_scatter<W, S, N, false>), grid, dim3(kThreads), 0, s, a.xy, a.t, a.p,
-                           a.noise, a.nxny, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done);
+                           a.noise, a.nxny, a.uv, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done, a.sets, a.pick_set);
 }
 
 void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool write_n,

@@ -97,17 +97,8 @@ __device__ __forceinline__ void warp_scatter_one(const ScatterCtx& c, uint32_t v
     double pr_x = pr_from_p(fx, q.x);
     double pr_y = pr_from_p(fy, q.y);
     if (WARP) {
-        const WarpParams& wp = c.wp;
-        const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
-        const double qx = wp.c * rx - wp.s * ry;
-        const double qy = wp.s * rx + wp.c * ry;
-        const double nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
-        const double ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
-        const float kx = div_127((float)nx);
-        const float ky = div_127((float)ny);
-        const float ft = (float)ti;
-        q.x = kx * ft;
-        q.y = ky * ft;
+        double nx, ny;
+        warp_products(c.wp, pr_x, pr_y, ti, q, nx, ny);
         pr_x = pr_from_p(fx, q.x);
         pr_y = pr_from_p(fy, q.y);
     }

@@ -183,15 +183,8 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
             const uint32_t fx = v & 0xffffu, fy = v >> 16;
             double pr_x = pr_from_p(fx, q.x), pr_y = pr_from_p(fy, q.y);
             if (warp) {
-                const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
-                const double qx = wp.c * rx - wp.s * ry;
-                const double qy = wp.s * rx + wp.c * ry;
-                const double nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
-                const double ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
-                const float kx = div_127((float)nx), ky = div_127((float)ny);
-                const float ft = (float)ti;
-                q.x = kx * ft;
-                q.y = ky * ft;
+                double nx, ny;
+                warp_products(wp, pr_x, pr_y, ti, q, nx, ny);
                 a.p[i] = q;
                 pr_x = pr_from_p(fx, q.x);
                 pr_y = pr_from_p(fy, q.y);
@@ -275,14 +268,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
             const uint32_t v = a.xy[i];
             float2 q = a.p[i];
             const double pr_x = pr_from_p(v & 0xffffu, q.x), pr_y = pr_from_p(v >> 16, q.y);
-            const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
-            const double qx = wp.c * rx - wp.s * ry;
-            const double qy = wp.s * rx + wp.c * ry;
-            nx = ((-qx) * wp.div + (qx - rx)) + wp.dnx;
-            ny = ((-qy) * wp.div + (qy - ry)) + wp.dny;
-            const float ft = (float)a.t[i];
-            q.x = div_127((float)nx) * ft;
-            q.y = div_127((float)ny) * ft;
+            warp_products(wp, pr_x, pr_y, a.t[i], q, nx, ny);
             a.p[i] = q;
         }
         a.nxny[a.perm[i]] = make_double2(nx, ny);

@@ -218,6 +218,24 @@ def main():
         regimes["capped_max_iter_10"] = {"mevents_per_s": cev / dtc / 1e6, "iterations_per_slice": cit / (reps * B),
                                          "ms_per_slice_per_chain": 1e3 * dtc / reps, "chains_in_flight": B}
 
+        # one slice / one chain at a time: the latency view of the same three regimes
+        def single(nrep, warm, max_iter):
+            prev = step(0)[1] if warm else None
+            accs[0].synchronize()
+            t1 = time.perf_counter()
+            ev = it = 0
+            for k in range(nrep):
+                n, m, info = step(1 + k, warm_model=prev, max_iter=max_iter)
+                if warm:
+                    prev = m
+                ev += n
+                it += info.iterations
+            accs[0].synchronize()
+            dt1 = time.perf_counter() - t1
+            return {"mevents_per_s": ev / dt1 / 1e6, "ms_per_slice": 1e3 * dt1 / nrep, "iterations_per_slice": it / nrep}
+        regimes["one_context"] = {"cold": single(3, False, -1), "warm_stm": single(reps, True, -1),
+                                  "capped_max_iter_10": single(reps, False, 10)}
+
     # ---- roofline of the dominant kernel (warp+scatter), hipEvent-bracketed launches -----
     roofline = None
     if rank == 0:

@@ -51,6 +51,8 @@ def main():
                     help="independent slices in flight per GPU: one host thread + bf_ctx + HIP stream each "
                          "(the slice farm of SURVEY 8(e) applied inside one GPU; a step = this many slices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="bf_set_option knob for every context (experiments), e.g. --opt bin_threads=512")
     ap.add_argument("--cpu-iters", type=int, default=60)
     args = ap.parse_args()
 
@@ -83,6 +85,10 @@ def main():
     import threading
     B = max(1, args.concurrent)
     accs = [accel.Accel(device=device, max_events=nmax, max_rows=s * H + s, max_cols=s * W + s) for _ in range(B)]
+    for a_ in accs:
+        for kv in args.opt:
+            k_, v_ = kv.split("=")
+            a_.set_option(k_, int(v_))
     acc = accs[0]
     resident = []
     for sl in slices:

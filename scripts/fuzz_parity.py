@@ -1,0 +1,143 @@
+"""Randomised differential test: libbf_accel.so against the CPU oracle (and against itself across scatter /
+loop modes) on many small random slices.  Test infrastructure (imports the oracle); not part of the product.
+
+For each case: random sensor, scale, event count, time span, velocity, rotation / divergence, optional hot
+spots; then
+  * event-count image after a random warp: bit-exact vs the oracle; time image <= 1e-6 relative;
+  * a capped run (max_iter K): same return code; the first two traced models <= 3e-4 relative to the oracle's with
+    equal valid-pixel counts.  (Later iterations are not compared: integer input coordinates sit exactly on the
+    truncation boundary of accel_lib.h:154, so the sign of a 1e-9 difference in a near-zero rot / div term moves
+    events by a whole pixel -- the oracle's own f32 summation order is enough to change the path.  With identical
+    warp parameters the images ARE bit-identical, which is what the first bullet checks.);
+  * the same run with binned=0 / default / other tile size + margin / persist=1: bit-identical to each other.
+usage: fuzz_parity.py [cases] [seed]"""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle
+from better_flow_amd import accel
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def make_case():
+    H, W = int(rng.integers(24, 300)), int(rng.integers(24, 400))
+    n = int(rng.choice([0, 1, 5, 300, 2000, 9000, 40000, 120000], p=[.02, .02, .03, .1, .2, .25, .25, .13]))
+    T = float(rng.choice([0.002, 0.03, 0.2]))
+    npts = max(1, n // int(rng.choice([4, 16, 64])))
+    pr, pc = rng.uniform(0, H, npts), rng.uniform(0, W, npts)
+    v = rng.normal(0, 200, 2) * (H / 180.0)
+    rot, div = rng.normal(0, 2.0), rng.normal(0, 2.0)            # rad/s, 1/s about the centre
+    t = np.sort(rng.uniform(0, T, n))
+    pick = rng.integers(0, npts, n)
+    r0, c0 = pr[pick] - H / 2, pc[pick] - W / 2
+    row = pr[pick] + (v[0] + div * r0 - rot * c0) * t
+    col = pc[pick] + (v[1] + div * c0 + rot * r0) * t
+    if n and rng.random() < 0.3:                                   # a hot spot: thousands of events on a few pixels
+        k = rng.integers(0, n, n // 5)
+        row[k], col[k] = H * 0.3 + rng.integers(0, 2, len(k)), W * 0.6 + rng.integers(0, 2, len(k))
+    keep = (row >= 0) & (row < H) & (col >= 0) & (col < W)
+    t_ns = (t[keep] * 1e9).astype(np.int64) + int(rng.choice([0, 0, -3000000]))   # some slices start before t0
+    return dict(H=H, W=W, s=int(rng.choice([1, 3, 3, 3, 5, 7, 9])), fr_x=np.floor(row[keep]).astype(np.int32),
+                fr_y=np.floor(col[keep]).astype(np.int32), t=t_ns)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-4)
+
+
+def canon(d):
+    """Model dict -> bytes, so that NaN models (no valid pixel: 0 / 0, as in the reference) compare equal."""
+    return b"".join(np.float64(d[k]).tobytes() for k in sorted(d))
+
+
+bad = 0
+only = int(os.environ.get("FUZZ_ONLY", "-1"))
+
+
+def dump(ci, c, K):
+    od = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(od, exist_ok=True)
+    np.savez(os.path.join(od, "fuzz_case_%d.npz" % ci), H=c["H"], W=c["W"], s=c["s"], K=K, fr_x=c["fr_x"], fr_y=c["fr_y"], t=c["t"])
+
+
+for ci in range(cases):
+    c = make_case()
+    H, W, s, n = c["H"], c["W"], c["s"], len(c["t"])
+    tag = "case %d: %dx%d s=%d n=%d" % (ci, H, W, s, n)
+    oc = oracle.Cloud(c["fr_x"], c["fr_y"], c["t"])
+    ow = oc.set_cloud(s, H, W)
+    K = int(rng.integers(2, 40))
+    results = {}
+    modes = [("default", {}), ("atomics", {"binned": 0}), ("tile32", {"bin_tile": 32, "bin_margin": int(rng.choice([4, 8, 12]))}),
+             ("persist", {"persist": 1}), ("nopredict", {"bin_predict": 0, "bin_margin": 2})]
+    for name, kv in modes:
+        a = accel.Accel(max_events=max(n, 16), max_rows=s * H + s, max_cols=s * W + s)
+        for k_, v_ in kv.items():
+            a.set_option(k_, v_)
+        a.upload_events(c["fr_x"], c["fr_y"], c["t"])
+        gw = a.set_cloud(s, H, W)
+        if name == "default":
+            for f in ("x_min", "x_max", "y_min", "y_max", "scale_img_x", "scale_img_y", "x_shift", "y_shift"):
+                if getattr(gw, f) != getattr(ow, f):
+                    print(tag, "WINDOW", f, getattr(gw, f), getattr(ow, f)); bad += 1
+            if ow.scale_img_x > 0 and ow.scale_img_y > 0 and n > 0:
+                prm = (rng.normal(0, .3), rng.normal(0, .3), ow.x_min + rng.uniform(0, 50), ow.y_min + rng.uniform(0, 50),
+                       rng.normal(0, 1e-4), rng.normal(0, 3e-5))
+                oc.project_4param_reinit(*prm); a.project_4param_reinit(*prm)
+                ot, ocn = oc.get_time_img(ow); gt, gcn = a.get_time_img()
+                if not np.array_equal(gcn, ocn.astype(np.uint32)):
+                    print(tag, "COUNT IMAGE differs at", int((gcn != ocn).sum()), "pixels"); bad += 1
+                else:
+                    # the oracle (like the reference) adds f32 seconds one event at a time: its own rounding grows with the
+                    # pixel's event count (hot pixels: thousands), and mixed-sign times cancel -> per-pixel tolerance
+                    tol = (1e-6 + 1.2e-7 * gcn.astype(np.float64)) * np.maximum(np.abs(ot), float(np.abs(c["t"]).max()) * 1e-9)
+                    if np.any(np.abs(gt.astype(np.float64) - ot) > tol):
+                        print(tag, "TIME IMAGE worst excess", float(np.max(np.abs(gt - ot) / tol))); bad += 1
+                a.upload_events(c["fr_x"], c["fr_y"], c["t"]); a.set_cloud(s, H, W)
+                oc = oracle.Cloud(c["fr_x"], c["fr_y"], c["t"]); ow = oc.set_cloud(s, H, W)
+        o = a.default_opts()
+        o.res_x, o.res_y, o.max_iter, o.trace_cap, o.min_events = H, W, K, 64, 100
+        try:
+            rc, m, info = a.run(o)
+        except accel.BfError as e:
+            print(tag, name, "RUN ERROR", e); bad += 1; a.close(); continue
+        tr = [(t_.model.as_dict(), t_.x_divider, t_.rot_divider) for t_ in a.get_trace(64)]
+        uv = a.compute_uv() if rc == 0 else (np.zeros(0), np.zeros(0))
+        results[name] = (rc, info.iterations, canon(m.as_dict()), [(canon(x[0]), x[1], x[2]) for x in tr], uv[0].tobytes(),
+                         uv[1].tobytes(), tr)
+        a.close()
+    ref = results.get("default")
+    if any(results[nm][:6] != ref[:6] for nm in results):
+        od = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(od, exist_ok=True)
+        np.savez(os.path.join(od, "fuzz_case_%d.npz" % ci), H=H, W=W, s=s, K=K, fr_x=c["fr_x"], fr_y=c["fr_y"], t=c["t"],
+                 prm=np.array(prm if "prm" in dir() else [0] * 6, dtype=np.float64))
+    for name in results:
+        if results[name][:6] != ref[:6]:
+            what = [i for i in range(6) if results[name][i] != ref[i]]
+            if what == [6]:
+                continue
+            print(tag, "MODE", name, "differs from default in fields", what, results[name][:2], ref[:2]); bad += 1
+    om = oracle.Model()
+    orc, oloop, otr = oc.run(ow, om, max_iter=K, res_x=H, res_y=W, min_events=100, trace_cap=64)
+    if ref is None:
+        continue
+    if ref[0] != orc:
+        print(tag, "RUN rc", ref[0], orc, "K", K); bad += 1; dump(ci, c, K)
+    elif orc == 0:
+        strict = c["t"].min() >= 0   # with times around zero the validity test p > 1e-6 sits on rounding noise
+        for k in range(min(2, len(ref[6]), len(otr)) if strict else 0):
+            g, o_ = ref[6][k][0], otr[k].model
+            if g["cnt"] != o_.cnt and not np.isnan(o_.dx):
+                print(tag, "TRACE cnt at", k, g["cnt"], o_.cnt); bad += 1; dump(ci, c, K); break
+            worst = max((rel(g[f], getattr(o_, f)) for f in ("dx", "dy", "rot", "div", "total_dx", "total_dy", "total_rot", "total_div")
+                         if not np.isnan(getattr(o_, f))), default=0.0)
+            if worst > 3e-4:   # gradient noise of the oracle's own f32 time sums on small clouds
+                print(tag, "TRACE model at", k, "rel", worst); bad += 1; dump(ci, c, K); break
+    if ci % 10 == 9:
+        print("... %d cases, %d problems" % (ci + 1, bad), flush=True)
+print("fuzz: %d cases, %d problems" % (cases, bad))
+sys.exit(1 if bad else 0)

@@ -5,6 +5,8 @@ time image <= 1e-6 relative (the reference's own f32 accumulation-order noise) a
 bit-exact where a single event hit the pixel; moments <= 1e-9 relative; converged
 (u, v) <= 1e-4 relative or 0.02 px/s, iteration count within +-1.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -632,3 +634,16 @@ def test_local_run_same_trajectory(oracle_lib, accel_mod):
     with pytest.raises(accel_mod.BfError):
         acc.local_set_window(9)                      # the Gaussian is stated up to 7
     acc.close()
+
+
+def test_randomised_differential_fuzz():
+    """scripts/fuzz_parity.py, a short deterministic run: random sensors / scales / clouds (empty, tiny, hot spots,
+    negative times, rotation + divergence) -- event-count image bit-exact against the oracle, all scatter and loop modes
+    (global atomics, tile-binned with other tiles / margins, forced overflow path, single-launch loop) bit-identical."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "24", "5"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "fuzz: 24 cases, 0 problems" in out, out[-3000:]

@@ -9,6 +9,7 @@ spots; then
     truncation boundary of accel_lib.h:154, so the sign of a 1e-9 difference in a near-zero rot / div term moves
     events by a whole pixel -- the oracle's own f32 summation order is enough to change the path.  With identical
     warp parameters the images ARE bit-identical, which is what the first bullet checks.);
+  * OptimizerLocal: blurred 8-bit count image and score bit-exact for random (nx, ny), both window constructors;
   * the same run with binned=0 / default / other tile size + margin / persist=1: bit-identical to each other.
 usage: fuzz_parity.py [cases] [seed]"""
 import sys, os
@@ -108,6 +109,21 @@ for ci in range(cases):
         uv = a.compute_uv() if rc == 0 else (np.zeros(0), np.zeros(0))
         results[name] = (rc, info.iterations, canon(m.as_dict()), [(canon(x[0]), x[1], x[2]) for x in tr], uv[0].tobytes(),
                          uv[1].tobytes(), tr)
+        a.close()
+    # contrast-score path (OptimizerLocal): blurred 8-bit count image and score bit-exact, both window constructors
+    if s <= 7 and n > 0:
+        a = accel.Accel(max_events=max(n, 16), max_rows=s * max(H, 64) + s, max_cols=s * max(W, 64) + s)
+        a.upload_events(c["fr_x"], c["fr_y"], c["t"])
+        ol = oracle.Cloud(c["fr_x"], c["fr_y"], c["t"])
+        for center, wsz in ((None, 0), ((int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(0, 3e7))), int(rng.integers(4, 60)))):
+            lw = ol.local_window(s, center=center, wsz=wsz)
+            a.local_set_window(s, center=center, wsz=wsz)
+            for _ in range(2):
+                nx_, ny_ = rng.normal(0, 0.5, 2)
+                osc, oimg = ol.local_iteration_step(lw, nx_, ny_)
+                gsc, gimg = a.local_iteration_step(nx_, ny_, want_img=True)
+                if not np.array_equal(gimg, oimg) or np.float64(gsc).tobytes() != np.float64(osc).tobytes():
+                    print(tag, "LOCAL SCORE", center, wsz, gsc, osc, int((gimg != oimg).sum())); bad += 1
         a.close()
     ref = results.get("default")
     if any(results[nm][:6] != ref[:6] for nm in results):

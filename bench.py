@@ -242,18 +242,23 @@ def main():
         regimes["one_context"] = {"cold": single(3, False, -1), "warm_stm": single(reps, True, -1),
                                   "capped_max_iter_10": single(reps, False, 10)}
 
-    # ---- roofline of the dominant kernel (warp+scatter), hipEvent-bracketed launches -----
+    # ---- roofline of the dominant kernel (warp+scatter): HIP events carrying the kernel's own timestamps -----
     roofline = None
     if rank == 0:
         acc.profile_enable(1)
         acc.profile_reset()
         psteps = min(args.steps, 4)
+        live_ev_iters = live = 0
         for i in range(psteps):
-            step(i)
+            n_, _, info_ = step(i)
+            live += info_.iterations             # launches that really warped + scattered the slice
+            live_ev_iters += n_ * info_.iterations
         p = acc.profile_get()
         acc.profile_enable(0)
-        k1_s = p.warp_scatter_ms * 1e-3 / max(1, p.warp_scatter_launches)
-        ev_per_launch = p.warp_scatter_events / max(1, p.warp_scatter_launches)
+        # total time of ALL loop launches of K1 (the few early-exit launches after convergence included) over the
+        # launches that did the work: a slightly pessimistic per-launch duration
+        k1_s = p.warp_scatter_ms * 1e-3 / max(1, live)
+        ev_per_launch = live_ev_iters / max(1, live)
         achieved = K1_BYTES_PER_EVENT_ITER * ev_per_launch / k1_s / 1e9
         try:
             copy_gbps = acc.copy_bandwidth(1 << 30, 5)
@@ -271,15 +276,16 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": "k_bin_warp_scatter (warp + tile-binned LDS scatter)", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "avg_launch_us": k1_s * 1e6, "launches": int(p.warp_scatter_launches),
+            "avg_launch_us": k1_s * 1e6, "launches": int(live), "launches_incl_early_exit": int(p.warp_scatter_launches),
             "algorithmic_bytes_per_launch": K1_BYTES_PER_EVENT_ITER * ev_per_launch,
             "measured_copy_ceiling_gbps": copy_gbps,
             "per_kernel_us": {
-                "warp_scatter": 1e3 * p.warp_scatter_ms / max(1, p.warp_scatter_launches),
-                "stencil_moments_update": 1e3 * p.stencil_ms / max(1, p.stencil_launches),
+                "warp_scatter": 1e3 * p.warp_scatter_ms / max(1, live),
+                "stencil_moments_update": 1e3 * p.stencil_ms / max(1, live),
             },
-            "note": "durations are hipEvent-bracketed launches on the ctx stream (adds ~1.5 us per launch over "
-                    "rocprofv3's kernel time, see profiles/)",
+            "note": "durations are the kernels' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the "
+                    "ctx stream), summed over every loop launch and divided by the launches that did work; "
+                    "profiles/*kernel_stats.csv is rocprofv3's view of the same kernels",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------

@@ -174,10 +174,16 @@ struct ProfScope {
         r.cat = cat;
         r.nev = nev;
         (void)hipEventRecord(r.a, c->stream);
+        // the loop kernels' launchers pick these up and time the kernel itself (bf_kernels.h: LaunchTimer)
+        LaunchTimer& t = launch_timer();
+        t.start = r.a; t.stop = r.b; t.consumed = false;
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(r.b, c->stream);
+        LaunchTimer& t = launch_timer();
+        if (!t.consumed) (void)hipEventRecord(r.b, c->stream);
+        t.start = t.stop = nullptr;
+        t.consumed = false;
         c->prof_pending.push_back(r);
     }
 };
@@ -1225,7 +1231,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // final warp rides along with every batch, gated on `done` (check_done 2) and picking the event
             // set on the device: when the batch was enough -- the usual case -- nothing is left to launch
             // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
-            ProfScope ps(c, 0, c->n);
+            ProfScope ps(c, 3);
             WarpScatterArgs fa = ws_args(c, buf, 2);
             fa.pick_set = binned ? 1 : 0;
             if (o.want_uv) fa.uv = c->d_uv;
@@ -1270,7 +1276,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // final warp: the last project_4param_reinit of iteration_step (:340-344), kept so that
     // pr / nx / ny describe the converged model; n is written for compute_uv / writeout.
     if (!final_done) {
-        ProfScope ps(c, 0, c->n);
+        ProfScope ps(c, 3);
         WarpScatterArgs fa = ws_args(c, buf, 0);
         if (o.want_uv) fa.uv = c->d_uv;   // Event::compute_uv (event.h:135-142) in the same pass
         launch_warp_scatter(fa, true, false, true, c->stream);

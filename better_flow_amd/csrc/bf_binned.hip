@@ -20,6 +20,7 @@
 // All accumulators are integers (count << tbits | sum(t - tmin)), so the result is exactly
 // the reference's s x s splat (accel_lib.h:147-166) whatever the event order.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <limits.h>
 
 #include "bf_device.h"
@@ -469,13 +470,25 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
 }
 
+// Plain launch, or (profiling armed) an extended launch whose events carry the kernel's own timestamps.
+template <class K, class... A>
+static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
+    LaunchTimer& t = launch_timer();
+    if (t.start && !t.consumed) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, t.start, t.stop, 0, args...);
+        t.consumed = true;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+    }
+}
+
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
     switch (a.scale / 2) {
-        case 0: hipLaunchKernelGGL(k_stencil_binned<0>, grid, dim3(kThreads), 0, s, a); break;
-        case 1: hipLaunchKernelGGL(k_stencil_binned<1>, grid, dim3(kThreads), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_stencil_binned<2>, grid, dim3(kThreads), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(k_stencil_binned<3>, grid, dim3(kThreads), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_stencil_binned<4>, grid, dim3(kThreads), 0, s, a); break;
+        case 0: launch_timed(k_stencil_binned<0>, grid, dim3(kThreads), 0, s, a); break;
+        case 1: launch_timed(k_stencil_binned<1>, grid, dim3(kThreads), 0, s, a); break;
+        case 2: launch_timed(k_stencil_binned<2>, grid, dim3(kThreads), 0, s, a); break;
+        case 3: launch_timed(k_stencil_binned<3>, grid, dim3(kThreads), 0, s, a); break;
+        default: launch_timed(k_stencil_binned<4>, grid, dim3(kThreads), 0, s, a); break;
     }
 }
 
@@ -505,11 +518,11 @@ static void launch_bws(const EvSets& sets, const uint32_t* bin_start, unsigned l
                        int tl_launch, hipStream_t s) {
     const size_t lds = (size_t)g.L * g.L * sizeof(unsigned long long);
     if (warp)
-        hipLaunchKernelGGL((k_bin_warp_scatter<true, THREADS>), dim3(g.nbins), dim3(THREADS), lds, s, sets,
-                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
+        launch_timed(k_bin_warp_scatter<true, THREADS>, dim3(g.nbins), dim3(THREADS), lds, s, sets, bin_start, slabs,
+                     ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
     else
-        hipLaunchKernelGGL((k_bin_warp_scatter<false, THREADS>), dim3(g.nbins), dim3(THREADS), lds, s, sets,
-                           bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
+        launch_timed(k_bin_warp_scatter<false, THREADS>, dim3(g.nbins), dim3(THREADS), lds, s, sets, bin_start, slabs,
+                     ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
 }
 
 void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane,

@@ -62,6 +62,15 @@ struct StencilArgs {
     int cur;
 };
 
+// Profiling hook: when armed (by bf_accel.cpp's ProfScope), the next launch of a loop kernel goes through
+// hipExtLaunchKernelGGL with these events, which then carry the kernel's own begin / end timestamps (what
+// rocprofv3 reports) instead of bracketing the launch with two extra barrier packets (~1.5 us more).
+struct LaunchTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool consumed = false;
+};
+LaunchTimer& launch_timer();   // thread local
+
 void launch_set_state(DevState* st, const DevState& v, hipStream_t s);
 void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool write_n,
                          hipStream_t s);

@@ -347,6 +347,11 @@ __global__ void k_set_state(DevState* st, DevState v) {
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+LaunchTimer& launch_timer() {
+    static thread_local LaunchTimer t;
+    return t;
+}
+
 void launch_set_state(DevState* st, const DevState& v, hipStream_t s) {
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, s, st, v);
 }

@@ -49,6 +49,8 @@ struct bf_ctx {
     bool opt_binned = true;
     bool opt_bin_predict = true;
     int opt_bin_tile = 64, opt_bin_margin = 8, opt_bin_threads = 1024;
+    int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
+    int n_cus = 0;
     bool use_binned = false;         // decided per slice in bf_set_cloud
     // whole loop in one cooperative launch (bf_persist.hip)
     bool opt_persist = false;        // measured slower than the multi-kernel loop: opt-in
@@ -321,7 +323,7 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
         HIP_TRY(c, hipMemsetAsync(c->d_hist_ts, 0, nb * sizeof(unsigned long long), c->stream));
         c->bins_alloc = g.nbins;
     }
-    const size_t need = (size_t)g.nbins * (size_t)g.L * (size_t)g.L;
+    const size_t need = (size_t)g.nbins * (size_t)g.LR * (size_t)g.L;
     if (need > c->slabs_alloc) {
         if (c->d_slabs) HIP_TRY(c, hipFree(c->d_slabs));
         c->d_slabs = nullptr;
@@ -452,6 +454,7 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
     c->device = device;
     int rc = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
+        (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
         if (hip_stream) {
             c->stream = (hipStream_t)hip_stream;
         } else {
@@ -571,6 +574,13 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "persist_threads")) {
         if (value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "persist_threads must be 512 or 1024");
         c->opt_persist_threads = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_tile_rows")) {
+        // (>= 32: the stencil kernel relies on a 16-row tile plus its halo crossing at most one bin boundary)
+        if (value != 0 && (value < 32 || value > 128 || value % 16))
+            return fail(c, BF_ERR_ARG, "bin_tile_rows must be 0 (auto) or a multiple of 16 in [32, 128]");
+        c->opt_bin_tile_rows = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "bin_predict")) {
@@ -795,16 +805,35 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     {
         BinGrid g;
         g.TS = c->opt_bin_tile;
-        g.D = c->opt_bin_margin > g.TS / 2 ? g.TS / 2 : c->opt_bin_margin;   // <= 2 x 2 bins per pixel
-        g.L = g.TS + 2 * g.D;
         g.lg = 0;
         while ((1 << g.lg) < g.TS) ++g.lg;
-        g.pad = 0;
-        g.nbr = (w.scale_img_x + g.TS - 1) / g.TS;
         g.nbc = (w.scale_img_y + g.TS - 1) / g.TS;
+        // Tile height: one work-group per bin, so the bins should fill the CUs in as few waves of
+        // work-groups as possible with the smallest tiles that do it (the fullest tile sets the length of
+        // the scatter kernel).  Cost model: ceil(bins / CUs) x tile area; ties go to the larger tile (less
+        // margin overhead).  "bin_tile_rows" overrides.
+        g.TSR = c->opt_bin_tile_rows;
+        if (g.TSR <= 0) {
+            g.TSR = g.TS < 32 ? 32 : g.TS;
+            if (c->n_cus > 0 && !c->opt_persist) {   // (the single-launch loop is written for square 64 x 64 tiles)
+                long long best = -1;
+                for (int rows = 32; rows <= 128; rows += 16) {
+                    const int nb = ((w.scale_img_x + rows - 1) / rows) * g.nbc;
+                    const long long cost = (long long)((nb + c->n_cus - 1) / c->n_cus) * rows * g.TS;
+                    if ((size_t)(rows + 2 * c->opt_bin_margin) * (g.TS + 2 * c->opt_bin_margin) * 8 > 64 * 1024) continue;
+                    if (best < 0 || cost < best || (cost == best && rows > g.TSR)) { best = cost; g.TSR = rows; }
+                }
+            }
+        }
+        const int tmin_ = g.TS < g.TSR ? g.TS : g.TSR;
+        g.D = c->opt_bin_margin > tmin_ / 2 ? tmin_ / 2 : c->opt_bin_margin;   // <= 2 x 2 bins per pixel
+        g.L = g.TS + 2 * g.D;
+        g.LR = g.TSR + 2 * g.D;
+        g.mul_r = (uint32_t)(0x100000000ull / (unsigned)g.TSR) + 1u;
+        g.nbr = (w.scale_img_x + g.TSR - 1) / g.TSR;
         g.nbins = g.nbr * g.nbc;
         c->use_binned = c->opt_binned && c->packed && !c->has_noise && c->n > 0 && g.nbins <= 4096 &&
-                        (size_t)g.L * g.L * 8 <= 160 * 1024;
+                        (size_t)g.LR * g.L * 8 <= 160 * 1024 && w.scale_img_x < (1 << 20);
         if (c->use_binned) {
             int rc = ensure_cplanes(c);
             if (rc == BF_OK) rc = ensure_bin_buffers(c, g);
@@ -813,7 +842,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         }
         c->use_persist = false;
         if (c->use_binned && c->opt_persist) {
-            const int key[3] = {g.L, scale, c->opt_persist_threads};
+            const int key[3] = {g.L * 1024 + g.LR, scale, c->opt_persist_threads};
             if (memcmp(key, c->persist_key, sizeof(key)) != 0) {
                 c->persist_max = persist_max_groups(g, scale, c->opt_persist_threads, c->device);
                 memcpy(c->persist_key, key, sizeof(key));

@@ -30,6 +30,9 @@
 namespace bf {
 
 
+// Row -> bin row: exact division by the (not necessarily power-of-two) tile height.
+__device__ __forceinline__ int row_bin(int row, const BinGrid& g) { return (int)__umulhi((uint32_t)row, g.mul_r); }
+
 // Image tile of the current target of one event (clamped into the grid: events whose target
 // is outside the image are rejected by the scatter but still need a home bin).
 __device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs, const BinGrid& g) {
@@ -39,7 +42,7 @@ __device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs,
     int Y = trunc_x86(pr_y * (double)hs.scale + (double)hs.y_sh);
     X = min(max(X, 0), hs.R - 1);
     Y = min(max(Y, 0), hs.C - 1);
-    return (X >> g.lg) * g.nbc + (Y >> g.lg);
+    return row_bin(X, g) * g.nbc + (Y >> g.lg);
 }
 
 // The re-bin kernels are enqueued by the host at a fixed cadence and run only when the update
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     unsigned long long* __restrict__ ovf_plane, uint32_t* __restrict__ ovf_cplane, DevState* st,
     BinGrid g, int cur, int check_done, unsigned long long* tl, int tl_launch) {
     extern __shared__ unsigned long long s_tile[];
-    const int L = g.L, LL = g.L * g.L;
+    const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x;
     tl_stamp(tl, tl_launch, 0);
 #ifdef BF_TIMELINE
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     // everything the block needs from global memory is requested up front, in one burst
     const uint32_t beg = bin_start[b], end = bin_start[b + 1];
     const HotState hs = st->hot;
-    const int X0 = (b / g.nbc) * g.TS - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
+    const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
     {   // zero the LDS tile, 16 bytes per lane (overlaps the scalar loads above)
         ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
         for (int i = threadIdx.x; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
             if (!((X >= wsx + hsc) || (X < hsc) || (Y >= wsy + hsc) || (Y < hsc))) {
                 const unsigned long long dt = (unsigned long long)((long long)ti - tmin);
                 const int lx = X - X0, ly = Y - Y0;
-                if (lx >= 0 && lx < L && ly >= 0 && ly < L) {
-                    atomicAdd(&s_tile[lx * L + ly], (1ull << tbits) + dt);
+                if (lx >= 0 && lx < LR && ly >= 0 && ly < L) {
+                    atomicAdd(&s_tile[__mul24(lx, L) + ly], (1ull << tbits) + dt);
                 } else {   // drifted out of this bin's tile: exact, slow path
                     const size_t kk = (size_t)X * (size_t)C + (size_t)Y;
                     atomicAdd(&ovf_plane[kk], dt);
@@ -398,30 +401,45 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     const unsigned long long bm = (1ull << bt) - 1ull;
     // (static indices only: a runtime index would push the HotState copy into scratch memory)
     const bool ovf = (a.cur ? hs.ovf_cnt[1] : hs.ovf_cnt[0]) != 0;
-    const int LLi = g.L * g.L;
+    const int LLi = g.LR * g.L;
 
+    static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
+    // Row -> bin without a per-pixel division: the tile's rows (with halo) span TR + 2 H <= 32 <= TSR rows, so both
+    // gr - D and gr + D cross at most one bin boundary inside the tile.  The bin rows at the tile's first row,
+    // the boundary rows and the slab offsets of those bin rows are UNIFORM (scalar unit); a pixel only compares.
+    // (32-bit integer multiplies are quarter rate on the vector unit; the 24-bit ones used below are full rate.)
+    const int bl = row_bin(max(r0 - H - g.D, 0), g), bh = row_bin(max(r0 - H + g.D, 0), g);
+    const int bl_next = (bl + 1) * g.TSR, bh_next = (bh + 1) * g.TSR;
+    // element offset of pixel (gr, gc) in the slab of bin (br, bc): (br nbc + bc) LL + (gr - br TSR + D) L + (gc - bc TS + D)
+    //   = [br nbc LL - (br TSR - D) L]  +  gr L  +  [bc LL - bc TS + D + gc]
+    const int rb_l0 = bl * g.nbc * LLi - (bl * g.TSR - g.D) * g.L, rb_l1 = rb_l0 + g.nbc * LLi - g.TSR * g.L;
+    const int rb_h0 = bh * g.nbc * LLi - (bh * g.TSR - g.D) * g.L, rb_h1 = rb_h0 + g.nbc * LLi - g.TSR * g.L;
     unsigned long long w[NC][4];
     unsigned long long ov[NC];
     uint32_t oc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int idx = tid + c * kThreads;
-        const int pr = idx / PC, pc = idx - pr * PC;
+        const int pr = SmallDiv<PC, NC * kThreads>::div(idx), pc = idx - pr * PC;
         const int gr = r0 - H + pr, gc = c0 - H + pc;
         const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
-        // bin (br, bc) holds rows [br*TS - D, br*TS + TS + D)
-        const int brl = max(gr - g.D, 0) >> g.lg, brh = min((gr + g.D) >> g.lg, g.nbr - 1);
+        // bin (br, bc) holds rows [br*TSR - D, br*TSR + TSR + D)
+        const bool l_up = max(gr - g.D, 0) >= bl_next, h_up = gr + g.D >= bh_next;
+        const int brl = bl + (l_up ? 1 : 0), brh = min(bh + (h_up ? 1 : 0), g.nbr - 1);
         const int bcl = max(gc - g.D, 0) >> g.lg, bch = min((gc + g.D) >> g.lg, g.nbc - 1);
+        const int grL = __mul24(gr, g.L);
+        const int rowpart_l = (l_up ? rb_l1 : rb_l0) + grL;
+        const int rowpart_h = ((brh > bh) ? rb_h1 : rb_h0) + grL;
+        const int colpart_l = __mul24(bcl, LLi) - (bcl << g.lg) + g.D + gc;
+        const int colpart_h = __mul24(bch, LLi) - (bch << g.lg) + g.D + gc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int br = (q & 2) ? brh : brl, bc = (q & 1) ? bch : bcl;
             const bool use = in && (!(q & 2) || brh > brl) && (!(q & 1) || bch > bcl);
-            const int lx = gr - ((br << g.lg) - g.D), ly = gc - ((bc << g.lg) - g.D);
             // 32-bit element offsets (the slabs and planes are far below 2^32 bytes): base + offset addressing
-            w[c][q] = use ? a.slabs[(uint32_t)((br * g.nbc + bc) * LLi + lx * g.L + ly)] : 0ull;
+            w[c][q] = use ? a.slabs[(uint32_t)(((q & 2) ? rowpart_h : rowpart_l) + ((q & 1) ? colpart_h : colpart_l))] : 0ull;
         }
-        ov[c] = (in && ovf) ? a.plane[(uint32_t)(gr * C + gc)] : 0ull;
-        oc[c] = (in && ovf) ? a.cplane[(uint32_t)(gr * C + gc)] : 0u;
+        ov[c] = (in && ovf) ? a.plane[(uint32_t)(__mul24(gr, C) + gc)] : 0ull;
+        oc[c] = (in && ovf) ? a.cplane[(uint32_t)(__mul24(gr, C) + gc)] : 0u;
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
     for (int idx = tid; idx < TH * TW; idx += kThreads) {
-        const int tr = idx / TW, tc = idx - tr * TW;
+        const int tr = SmallDiv<TW, TH * TW + kThreads>::div(idx), tc = idx - tr * TW;
         const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
         float tv = 0.f;
         if (gr >= 0 && gr < R && gc >= 0 && gc < C) {
@@ -516,7 +534,7 @@ template <int THREADS>
 static void launch_bws(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane, uint32_t* ovf_cplane,
                        DevState* st, const BinGrid& g, int cur, bool warp, int check_done, unsigned long long* tl,
                        int tl_launch, hipStream_t s) {
-    const size_t lds = (size_t)g.L * g.L * sizeof(unsigned long long);
+    const size_t lds = (size_t)g.LR * g.L * sizeof(unsigned long long);
     if (warp)
         launch_timed(k_bin_warp_scatter<true, THREADS>, dim3(g.nbins), dim3(THREADS), lds, s, sets, bin_start, slabs,
                      ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);

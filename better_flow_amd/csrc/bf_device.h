@@ -48,11 +48,15 @@ struct Partial {
     double pad;
 };
 
-// Geometry of the tile-binned scatter (bf_binned.hip): image tiles of TS x TS scaled
-// pixels, LDS / slab tiles of L = TS + 2 D, nbr x nbc bins.
+// Geometry of the tile-binned scatter (bf_binned.hip): image tiles of TSR rows x TS columns of scaled
+// pixels, LDS / slab tiles of LR x L = (TSR + 2 D) x (TS + 2 D), nbr x nbc bins.  TS is a power of two
+// (column -> bin by a shift); TSR is any multiple of 16 (row -> bin by an exact multiply-high), chosen by the
+// host so that the number of bins fills the CUs (one work-group per bin).
 struct BinGrid {
     int32_t TS, D, L, nbr, nbc, nbins;
-    int32_t lg, pad;   // TS == 1 << lg; D <= TS / 2, so a pixel is covered by <= 2 x 2 bins
+    int32_t lg, TSR;   // TS == 1 << lg; D <= min(TS, TSR) / 2, so a pixel is covered by <= 2 x 2 bins
+    int32_t LR;        // TSR + 2 D
+    uint32_t mul_r;    // floor(2^32 / TSR) + 1: row / TSR == __umulhi(row, mul_r) for row < 2^20
 };
 
 // Fields every kernel of the loop reads.  They are contiguous so that a kernel issues ONE

@@ -52,6 +52,22 @@ __device__ __forceinline__ double div_1e9(double x) {
     return (x == 0.0 || isinf(x)) ? q0 : q;
 }
 
+// idx / D for a compile-time D and 0 <= idx < LIMIT, as one full-rate 24-bit multiply and a shift (the
+// compiler's own sequence for a constant divisor is a v_mul_hi_u32: quarter rate on the vector unit).
+// The magic number is checked for the whole range at compile time.
+template <int D, int LIMIT>
+struct SmallDiv {
+    static constexpr int kShift = 20;
+    static constexpr int kMul = ((1 << kShift) + D - 1) / D;
+    static constexpr bool ok() {
+        for (int i = 0; i < LIMIT; ++i)
+            if (((long long)i * kMul) >> kShift != i / D) return false;
+        return (long long)(LIMIT - 1) * kMul < (1ll << 31);
+    }
+    static_assert(ok(), "SmallDiv: magic does not cover the range");
+    __device__ static __forceinline__ int div(int idx) { return __mul24(idx, kMul) >> kShift; }
+};
+
 // Previous / new projected position from the stored f32 product (event.h:167-168):
 //   pr = float(fr) - (kx * float(t)) / 10000.0      (f32 product, f64 divide and subtract)
 __device__ __forceinline__ double pr_from_p(uint32_t fr, float prod) {
@@ -215,7 +231,8 @@ __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long 
 // seconds is the integer-ns sum rounded once, then the f32 divide by the count.
 __device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_biased, long long tmin) {
     if (cnt == 0) return 0.f;
-    const long long ts = tsum_biased + (long long)cnt * tmin;
+    // (tmin is a slice-local time that fits 32 bits: one v_mad_i64_i32 instead of a 64 x 64-bit multiply)
+    const long long ts = tsum_biased + (long long)(int)cnt * (long long)(int)tmin;
     const float sum_s = (float)div_1e9((double)ts);
     return sum_s / (float)cnt;
 }

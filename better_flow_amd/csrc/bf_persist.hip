@@ -435,7 +435,7 @@ static const void* persist_pick(int threads, int hs) {
 // Largest co-resident grid of the kernel for this geometry (0: cannot run), raising the dynamic
 // LDS limit on the way.
 int persist_max_groups(const BinGrid& g, int scale, int threads, int device) {
-    if (g.TS != kPTS || g.D < scale / 2 + 1 || g.D > g.TS / 2) return 0;
+    if (g.TS != kPTS || g.TSR != kPTS || g.D < scale / 2 + 1 || g.D > g.TS / 2) return 0;   // square 64 x 64 tiles only
     const size_t lds = persist_lds_bytes(g, scale, threads);
     if (lds > 160 * 1024) return 0;
     int coop = 0, cus = 0;

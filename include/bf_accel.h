@@ -141,6 +141,9 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "binned"       1 (default): tile-binned LDS scatter inside bf_run; 0: one global
  *                  atomic per event.  Results are identical.
  *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 64).
+ *   "bin_tile_rows"  tile HEIGHT (0 = default: chosen per slice among 32 .. 128 so that the bins -- one
+ *                  work-group each -- fill the CUs; else a multiple of 16 in [32, 128]).  "bin_tile" is the
+ *                  tile width.
  *   "bin_margin"   LDS margin around a bin's tile (even, default 8); events drifting
  *                  further take the exact overflow path and trigger a re-bin.
  *   "persist"      1: when the tile grid fits the GPU (one resident work-group per 64 x 64

@@ -406,8 +406,10 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
     // Row -> bin without a per-pixel division: the tile's rows (with halo) span TR + 2 H <= 32 <= TSR rows, so both
     // gr - D and gr + D cross at most one bin boundary inside the tile.  The bin rows at the tile's first row,
-    // the boundary rows and the slab offsets of those bin rows are UNIFORM (scalar unit); a pixel only compares.
-    // (32-bit integer multiplies are quarter rate on the vector unit; the 24-bit ones used below are full rate.)
+    // the boundary rows and the slab offsets of those bin rows are UNIFORM (scalar unit); a pixel only compares
+    // and adds.  (Measured, scripts/micro/rates.hip: every vector multiply -- 24-bit, 32-bit lo / hi -- and every
+    // f64 op or conversion issues at ~4.3 cycles per wave per SIMD, adds / logic at ~2.5; what counts is the
+    // instruction count per pixel, which this form halves for the address arithmetic.)
     const int bl = row_bin(max(r0 - H - g.D, 0), g), bh = row_bin(max(r0 - H + g.D, 0), g);
     const int bl_next = (bl + 1) * g.TSR, bh_next = (bh + 1) * g.TSR;
     // element offset of pixel (gr, gc) in the slab of bin (br, bc): (br nbc + bc) LL + (gr - br TSR + D) L + (gc - bc TS + D)
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int idx = tid + c * kThreads;
-        const int pr = SmallDiv<PC, NC * kThreads>::div(idx), pc = idx - pr * PC;
+        const int pr = idx / PC, pc = idx - pr * PC;
         const int gr = r0 - H + pr, gc = c0 - H + pc;
         const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
         // bin (br, bc) holds rows [br*TSR - D, br*TSR + TSR + D)
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
     for (int idx = tid; idx < TH * TW; idx += kThreads) {
-        const int tr = SmallDiv<TW, TH * TW + kThreads>::div(idx), tc = idx - tr * TW;
+        const int tr = idx / TW, tc = idx - tr * TW;
         const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
         float tv = 0.f;
         if (gr >= 0 && gr < R && gc >= 0 && gc < C) {

@@ -52,22 +52,6 @@ __device__ __forceinline__ double div_1e9(double x) {
     return (x == 0.0 || isinf(x)) ? q0 : q;
 }
 
-// idx / D for a compile-time D and 0 <= idx < LIMIT, as one full-rate 24-bit multiply and a shift (the
-// compiler's own sequence for a constant divisor is a v_mul_hi_u32: quarter rate on the vector unit).
-// The magic number is checked for the whole range at compile time.
-template <int D, int LIMIT>
-struct SmallDiv {
-    static constexpr int kShift = 20;
-    static constexpr int kMul = ((1 << kShift) + D - 1) / D;
-    static constexpr bool ok() {
-        for (int i = 0; i < LIMIT; ++i)
-            if (((long long)i * kMul) >> kShift != i / D) return false;
-        return (long long)(LIMIT - 1) * kMul < (1ll << 31);
-    }
-    static_assert(ok(), "SmallDiv: magic does not cover the range");
-    __device__ static __forceinline__ int div(int idx) { return __mul24(idx, kMul) >> kShift; }
-};
-
 // Previous / new projected position from the stored f32 product (event.h:167-168):
 //   pr = float(fr) - (kx * float(t)) / 10000.0      (f32 product, f64 divide and subtract)
 __device__ __forceinline__ double pr_from_p(uint32_t fr, float prod) {

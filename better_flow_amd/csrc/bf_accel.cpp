@@ -62,7 +62,6 @@ struct bf_ctx {
     BinGrid grid;
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
-    unsigned long long* d_hist_ts = nullptr;
     uint32_t* d_armed = nullptr;
     unsigned long long* d_slabs = nullptr;
     int bins_alloc = 0;
@@ -311,16 +310,14 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
         HIP_TRY(c, hipMalloc(&c->set[1].p, (size_t)c->cap_events * sizeof(float2)));
     }
     if (g.nbins > c->bins_alloc) {
-        void* old[] = {c->d_hist_cnt, c->d_hist_ts, c->d_bin_start, c->d_cursor};
+        void* old[] = {c->d_hist_cnt, c->d_bin_start, c->d_cursor};
         for (void* o : old) if (o) HIP_TRY(c, hipFree(o));
-        c->d_hist_cnt = nullptr; c->d_hist_ts = nullptr; c->d_bin_start = nullptr; c->d_cursor = nullptr;
+        c->d_hist_cnt = nullptr; c->d_bin_start = nullptr; c->d_cursor = nullptr;
         const size_t nb = (size_t)g.nbins + 1;
         HIP_TRY(c, hipMalloc(&c->d_hist_cnt, nb * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_hist_ts, nb * sizeof(unsigned long long)));
         HIP_TRY(c, hipMalloc(&c->d_bin_start, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_cursor, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMemsetAsync(c->d_hist_cnt, 0, nb * sizeof(uint32_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_hist_ts, 0, nb * sizeof(unsigned long long), c->stream));
         c->bins_alloc = g.nbins;
     }
     const size_t need = (size_t)g.nbins * (size_t)g.LR * (size_t)g.L;
@@ -339,7 +336,7 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
 int enqueue_rebin(bf_ctx* c, bool has_perm_at_start, const WarpParams* prewarp = nullptr) {
     ProfScope ps(c, 3);
     launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, c->d_state, c->grid, c->d_binid, c->d_hist_cnt,
-                 c->d_hist_ts, c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->stream);
+                 c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->stream);
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -534,7 +531,7 @@ void bf_destroy(bf_ctx* c) {
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
-                    c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_hist_ts, c->d_bin_start,
+                    c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,

@@ -48,7 +48,7 @@ __device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs,
 // The re-bin kernels are enqueued by the host at a fixed cadence and run only when the update
 // asked for it (hot.need_rebin): no host round trip sits between "drifted" and "re-sorted".
 //
-// R1: per-bin event count and sum(t - tmin); remembers each event's bin.  PREWARP: the warm-start warp
+// R1: per-bin event count; remembers each event's bin.  PREWARP: the warm-start warp
 // of OptimizerRolling::set_model (optimizer_rolling.h:294-298) is applied on the way (the events must be
 // sorted by where that warp puts them), saving a pass over the events.  A launch that has nothing to do
 // also disarms the scatter kernel (see k_bin_scatter).
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n
                                                         const DevState* __restrict__ st, BinGrid g,
                                                         uint16_t* __restrict__ binid,
                                                         uint32_t* __restrict__ hist_cnt,
-                                                        unsigned long long* __restrict__ hist_ts,
                                                         uint32_t* __restrict__ armed, WarpParams prewarp) {
     const HotState hs = st->hot;
     if (!hs.need_rebin || hs.done) {
@@ -65,10 +64,8 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n
         return;
     }
     const EvSetPtrs e = sets.s[hs.cs ^ hs.flip];
-    extern __shared__ unsigned long long s_mem[];
-    unsigned long long* s_ts = s_mem;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_mem + g.nbins);
-    for (int i = threadIdx.x; i < g.nbins; i += kThreads) { s_ts[i] = 0; s_cnt[i] = 0; }
+    extern __shared__ uint32_t s_cnt[];
+    for (int i = threadIdx.x; i < g.nbins; i += kThreads) s_cnt[i] = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
          i += (long long)gridDim.x * kThreads) {
@@ -83,50 +80,33 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n
         const int b = bin_of(v, q, hs, g);
         binid[i] = (uint16_t)b;
         atomicAdd(&s_cnt[b], 1u);
-        atomicAdd(&s_ts[b], (unsigned long long)((long long)ti - hs.tmin));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < g.nbins; i += kThreads) {
-        if (s_cnt[i]) {
-            atomicAdd(&hist_cnt[i], s_cnt[i]);
-            atomicAdd(&hist_ts[i], s_ts[i]);
-        }
+        if (s_cnt[i]) atomicAdd(&hist_cnt[i], s_cnt[i]);
     }
 }
 
-// R2: exclusive scan of the counts -> bin_start; accumulator packing for this binning:
-// tbits = bits(max_b sum_b(t - tmin)), and it is usable iff tbits + bits(max_b count_b) <= 64.
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_cnt,
-                                                   unsigned long long* __restrict__ hist_ts, int nbins,
+// R2: exclusive scan of the counts -> bin_start.
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_cnt, int nbins,
                                                    uint32_t* __restrict__ bin_start,
                                                    uint32_t* __restrict__ cursor, DevState* st,
                                                    uint32_t* __restrict__ armed) {
     if (!st->hot.need_rebin || st->hot.done) return;
     __shared__ uint32_t s_sum[1024];
-    __shared__ uint32_t s_maxc[1024];
-    __shared__ unsigned long long s_maxt[1024];
     const int tid = threadIdx.x;
     const int per = (nbins + 1023) / 1024;
-    uint32_t local = 0, maxc = 0;
-    unsigned long long maxt = 0;
+    uint32_t local = 0;
     for (int k = 0; k < per; ++k) {
         const int b = tid * per + k;
-        if (b < nbins) {
-            local += hist_cnt[b];
-            maxc = max(maxc, hist_cnt[b]);
-            maxt = max(maxt, hist_ts[b]);
-        }
+        if (b < nbins) local += hist_cnt[b];
     }
-    s_sum[tid] = local; s_maxc[tid] = maxc; s_maxt[tid] = maxt;
+    s_sum[tid] = local;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
         uint32_t v = (tid >= off) ? s_sum[tid - off] : 0u;
-        uint32_t mc = (tid >= off) ? s_maxc[tid - off] : 0u;
-        unsigned long long mt = (tid >= off) ? s_maxt[tid - off] : 0ull;
         __syncthreads();
         s_sum[tid] += v;
-        s_maxc[tid] = max(s_maxc[tid], mc);
-        s_maxt[tid] = max(s_maxt[tid], mt);
         __syncthreads();
     }
     uint32_t run = s_sum[tid] - local;   // exclusive prefix of this thread's first bin
@@ -137,18 +117,14 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_c
             run += hist_cnt[b];
             cursor[b] = 0;
             hist_cnt[b] = 0;   // ready for the next re-bin
-            hist_ts[b] = 0;
         }
     }
     if (tid == 1023) {
         bin_start[nbins] = s_sum[1023];
-        int tbits = 1, cbits = 0;
-        for (unsigned long long v = s_maxt[1023]; v; v >>= 1) ++tbits;
-        for (uint32_t v = s_maxc[1023]; v; v >>= 1) ++cbits;
-        tbits -= 1;
-        if (tbits < 1) tbits = 1;
-        st->hot.bin_tbits = tbits;
-        st->bin_ok = (tbits + cbits <= 64) ? 1 : 0;
+        // packing of the per-bin tiles: the slice-wide one (set_cloud made sure it fits), so that slabs can be
+        // merged and box-summed without unpacking
+        st->hot.bin_tbits = st->hot.tbits;
+        st->bin_ok = 1;
         st->hot.need_rebin = 0;
         st->hot.flip = 1;            // k_bin_scatter (next kernel) moves the events to set cs^1
         st->hot.rebins += 1;
@@ -389,8 +365,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
     constexpr int PR = TR + 2 * H, PC = TC + 2 * H;
     constexpr int TH = TR + 2, TW = TC + 2;
     constexpr int NC = (PR * PC + kThreads - 1) / kThreads;
-    __shared__ unsigned long long s_ts[PR * PC];
-    __shared__ uint32_t s_cnt[PR * PC];
+    __shared__ unsigned long long s_acc[PR * PC];
     __shared__ float s_time[TH * TW];
     __shared__ Sums s_red[kThreads / 64];
     const int R = a.R, C = a.C;
@@ -443,20 +418,15 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
         ov[c] = (in && ovf) ? a.plane[(uint32_t)(__mul24(gr, C) + gc)] : 0ull;
         oc[c] = (in && ovf) ? a.cplane[(uint32_t)(__mul24(gr, C) + gc)] : 0u;
     }
+    // The accumulators stay PACKED (count << tbits | time sum) through the merge and the box sum: both
+    // fields were sized for the whole slice (tbits = bits of the sum over ALL events, the rest holds the
+    // event count), so no sum over any set of events -- up to 2 x 2 slabs, the overflow planes, the s x s
+    // box -- can carry from one field into the other.  One 64-bit add per contribution, one unpack per pixel.
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int idx = tid + c * kThreads;
-        if (idx < PR * PC) {
-            unsigned long long ts = ov[c];
-            uint32_t cn = oc[c];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ts += w[c][q] & bm;
-                cn += (uint32_t)(w[c][q] >> bt);
-            }
-            s_ts[idx] = ts;
-            s_cnt[idx] = cn;
-        }
+        if (idx < PR * PC)
+            s_acc[idx] = ((w[c][0] + w[c][1]) + (w[c][2] + w[c][3])) + (ov[c] + ((unsigned long long)oc[c] << bt));
     }
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
@@ -467,15 +437,13 @@ __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
         float tv = 0.f;
         if (gr >= 0 && gr < R && gc >= 0 && gc < C) {
             // s x s box sum == the s x s splat of accel_lib.h:160-165 on integer planes
-            unsigned long long acc = 0;
-            uint32_t cacc = 0;
+            unsigned long long pk = 0;
 #pragma unroll
             for (int da = 0; da <= 2 * HS; ++da)
 #pragma unroll
-                for (int db = 0; db <= 2 * HS; ++db) {
-                    acc += s_ts[(tr + da) * PC + (tc + db)];
-                    cacc += s_cnt[(tr + da) * PC + (tc + db)];
-                }
+                for (int db = 0; db <= 2 * HS; ++db) pk += s_acc[(tr + da) * PC + (tc + db)];
+            const unsigned long long acc = pk & bm;
+            const uint32_t cacc = (uint32_t)(pk >> bt);
             tv = time_from_sums(cacc, (long long)acc, a.tmin);
             if (tr >= 1 && tr <= TR && tc >= 1 && tc <= TC) {
                 if (a.time_out) a.time_out[(size_t)gr * C + gc] = tv;
@@ -514,18 +482,18 @@ void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
-                  uint16_t* binid, uint32_t* hist_cnt, unsigned long long* hist_ts, uint32_t* bin_start,
+                  uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
                   uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, hipStream_t s) {
     if (n <= 0) return;
     long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
     if (blocks > 1024) blocks = 1024;
     if (prewarp)
-        hipLaunchKernelGGL(k_bin_count<true>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 12, s, sets, n,
-                           st, g, binid, hist_cnt, hist_ts, armed, *prewarp);
+        hipLaunchKernelGGL(k_bin_count<true>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 4, s, sets, n,
+                           st, g, binid, hist_cnt, armed, *prewarp);
     else
-        hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 12, s, sets, n,
-                           st, g, binid, hist_cnt, hist_ts, armed, WarpParams{});
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, hist_cnt, hist_ts, g.nbins, bin_start, cursor,
+        hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 4, s, sets, n,
+                           st, g, binid, hist_cnt, armed, WarpParams{});
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, hist_cnt, g.nbins, bin_start, cursor,
                        st, armed);
     const size_t lds = ((size_t)g.nbins * 2 + (g.nbins & 1)) * 4 + (size_t)kBsEvents * (4 + 4 + 4 + 2 + 8);
     hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBsEvents - 1) / kBsEvents)), dim3(kThreads), lds, s, sets,

@@ -361,18 +361,22 @@ __device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int 
                          valid_px(t01) && valid_px(t21) && valid_px(t02) &&
                          valid_px(t12) && valid_px(t22);
         if (all) {
+            // The reference adds all nine weight * tap products in this order, including the weights that are 0.
+            // Those terms are dropped here without changing a bit: every tap passed valid_px, so it is a finite
+            // positive number and tap * 0.f == +0.f; the running sum is never -0.f (it starts as 0.f + a positive
+            // product, and a sum of non-zero terms can only cancel to +0.f in round-to-nearest), and x + (+0.f) == x
+            // for every x other than -0.f.
             float dx = 0.f, dy = 0.f;
             // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
             dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
-            dx = dx + t10 * 0.f;   dy = dy + t10 * 10.f;
+            /* t10 * 0.f */        dy = dy + t10 * 10.f;
             dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
-            // k = 1 (column c)
-            dx = dx + t01 * 10.f;  dy = dy + t01 * 0.f;
-            dx = dx + ctr * 0.f;   dy = dy + ctr * 0.f;
-            dx = dx + t21 * -10.f; dy = dy + t21 * 0.f;
+            // k = 1 (column c): dy's three weights are 0, dx's centre weight is 0
+            dx = dx + t01 * 10.f;
+            dx = dx + t21 * -10.f;
             // k = 2 (column c+1)
             dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
-            dx = dx + t12 * 0.f;   dy = dy + t12 * -10.f;
+            /* t12 * 0.f */        dy = dy + t12 * -10.f;
             dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
             gx = dx;
             gy = dy;

@@ -244,11 +244,14 @@ __device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, 
         st->model = m;
         return;
     }
-    // object_model.h:48-53 via optimizer_rolling.h:328
-    m.total_rot += m.rot / (double)st->rot_div;
-    m.total_div += m.div / (double)st->div_div;
-    m.total_dx += m.dx / (double)st->x_div;
-    m.total_dy += m.dy / (double)st->y_div;
+    // object_model.h:48-53 via optimizer_rolling.h:328.  The four quotients are kept: the convergence test
+    // below needs the same ratios against dividers that are either unchanged or exactly doubled.
+    const double q_rot = m.rot / (double)st->rot_div, q_div = m.div / (double)st->div_div;
+    const double q_dx = m.dx / (double)st->x_div, q_dy = m.dy / (double)st->y_div;
+    m.total_rot += q_rot;
+    m.total_div += q_div;
+    m.total_dx += q_dx;
+    m.total_dy += q_dy;
     // optimizer_rolling.h:330-331,340-346
     const double cxs = (m.cx - st->x_shift) / (double)st->hot.scale;
     const double cys = (m.cy - st->y_shift) / (double)st->hot.scale;
@@ -257,8 +260,7 @@ __device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, 
     wp.cx = cxs; wp.cy = cys;
     wp.div = m.total_div;
     const double crl = -m.total_rot;
-    wp.c = cos(crl);
-    wp.s = sin(crl);
+    sincos(crl, &wp.s, &wp.c);   // one argument reduction for both (same values as sin() and cos())
     m.cx = cxs;
     m.cy = cys;
     st->hot.wp = wp;
@@ -294,15 +296,18 @@ __device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, 
     const int it = st->hot.it + 1;
     st->hot.it = it;
     float xd = st->x_div, yd = st->y_div, rd = st->rot_div, dd = st->div_div;
+    // m.dx / xd of the convergence test (:81-84) == q_dx when the divider is unchanged and q_dx / 2 when it was
+    // just doubled: a / (2 b) rounds to exactly RN(a / b) / 2 (no underflow at these magnitudes)
+    double hx = 1.0, hy = 1.0, hr = 1.0, hd = 1.0;
     int done = 0, rc = 0;
     if (it > 1) {
         if (st->max_iter > 0 && it > st->max_iter) {   // :94-96 (before the sign flips)
             done = 1;
         } else {                                       // :98-101
-            if (m.dx * (double)st->old_dx < 0) xd *= 2;
-            if (m.dy * (double)st->old_dy < 0) yd *= 2;
-            if (m.rot * (double)st->old_rot < 0) rd *= 2;
-            if (m.div * (double)st->old_div < 0) dd *= 2;
+            if (m.dx * (double)st->old_dx < 0) { xd *= 2; hx = 0.5; }
+            if (m.dy * (double)st->old_dy < 0) { yd *= 2; hy = 0.5; }
+            if (m.rot * (double)st->old_rot < 0) { rd *= 2; hr = 0.5; }
+            if (m.div * (double)st->old_div < 0) { dd *= 2; hd = 0.5; }
             st->x_div = xd; st->y_div = yd; st->rot_div = rd; st->div_div = dd;
             if (st->hard_cap > 0 && it >= st->hard_cap) { done = 1; rc = BF_ERR_NOCONV; }
         }
@@ -316,8 +321,8 @@ __device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, 
     if (!done) {
         if (!(xd < 32 * 10 || yd < 32 * 10 || rd < 32 * 1000 || dd < 32 * 1000)) {   // :76-79
             done = 1;
-        } else if (fabs(m.dx / (double)xd) < 1e-5 && fabs(m.dy / (double)yd) < 1e-5 &&
-                   fabs(m.rot / (double)rd) < 1e-4 && fabs(m.div / (double)dd) < 1e-1) {   // :81-84
+        } else if (fabs(q_dx * hx) < 1e-5 && fabs(q_dy * hy) < 1e-5 &&
+                   fabs(q_rot * hr) < 1e-4 && fabs(q_div * hd) < 1e-1) {   // :81-84
             done = 1;
         } else {                                                                         // :86-89
             st->old_dx = (float)m.dx; st->old_dy = (float)m.dy;

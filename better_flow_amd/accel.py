@@ -114,6 +114,7 @@ EXPORTS = [
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
     "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
+    "bf_upload_ring_async", "bf_wait_uploads",
 ]
 
 _lib = None

@@ -77,6 +77,9 @@ struct bf_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2] = {nullptr, nullptr};
     long long pending_n[2] = {0, 0};
+    bool pending_ts64[2] = {false, false};       // slot holds absolute 64-bit timestamps (ring hand-off)
+    unsigned long long pending_t0[2] = {0, 0};
+    unsigned long long* d_in_ts[2] = {nullptr, nullptr};
     int pend_head = 0, pend_count = 0;   // FIFO of pending async uploads (slot = index & 1)
     double2 *d_nxny = nullptr, *d_uv = nullptr;
     unsigned long long* d_plane[2] = {nullptr, nullptr};
@@ -530,6 +533,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
+    for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
@@ -681,7 +685,51 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
     HIP_TRY(c, hipMemcpyAsync(dt, t_ns, nb, hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
     c->pending_n[slot] = n;
+    c->pending_ts64[slot] = false;
     c->pend_count++;
+    return BF_OK;
+}
+
+// The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays ring in pinned
+// memory: up to two contiguous pieces per array, no repacking on the host.
+int bf_upload_ring_async(bf_ctx* c, const int32_t* ring_x, const int32_t* ring_y, const uint64_t* ring_ts, int64_t cap,
+                         int64_t first, int64_t n, uint64_t t0) {
+    if (!c) return BF_ERR_ARG;
+    if (n <= 0 || cap <= 0 || first < 0 || first >= cap || n > cap || !ring_x || !ring_y || !ring_ts)
+        return fail(c, BF_ERR_ARG, "bad ring slice (cap %lld, first %lld, n %lld)", (long long)cap, (long long)first, (long long)n);
+    if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
+    if (c->pend_count >= 2) return fail(c, BF_ERR_STATE, "two uploads are already pending");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    }
+    const int slot = (c->pend_head + c->pend_count) & 1;
+    if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
+    int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
+    int32_t* dy = slot ? c->d_in2[1] : c->d_in_y;
+    const int64_t n0 = (first + n <= cap) ? n : cap - first, n1 = n - n0;   // [first, first + n0) then [0, n1)
+    HIP_TRY(c, hipMemcpyAsync(dx, ring_x + first, (size_t)n0 * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(dy, ring_y + first, (size_t)n0 * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot], ring_ts + first, (size_t)n0 * 8, hipMemcpyHostToDevice, c->copy_stream));
+    if (n1 > 0) {
+        HIP_TRY(c, hipMemcpyAsync(dx + n0, ring_x, (size_t)n1 * 4, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(dy + n0, ring_y, (size_t)n1 * 4, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot] + n0, ring_ts, (size_t)n1 * 8, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
+    c->pending_n[slot] = n;
+    c->pending_ts64[slot] = true;
+    c->pending_t0[slot] = t0;
+    c->pend_count++;
+    return BF_OK;
+}
+
+int bf_wait_uploads(bf_ctx* c) {
+    if (!c) return BF_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     return BF_OK;
 }
 
@@ -693,6 +741,8 @@ int bf_commit_upload(bf_ctx* c) {
     // the staging kernel (compute stream) waits for the copy; nothing blocks on the host
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[slot], 0));
     c->has_noise = false;
+    if (c->pending_ts64[slot])   // absolute timestamps -> slice-local 32-bit times (Event::set_local_time)
+        launch_local_time(c->d_in_ts[slot], c->pending_t0[slot], slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot], c->stream);
     int rc = stage_common(c, slot ? c->d_in2[0] : c->d_in_x, slot ? c->d_in2[1] : c->d_in_y,
                           slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot]);
     c->pend_head++;
@@ -727,6 +777,8 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     // optimizer_rolling.h:252-260: min seeded with RES, max with 0
     w.x_min = res_x; w.y_min = res_y; w.x_max = 0; w.y_max = 0;
     if (c->n > 0) {
+        if (s.tmin == INT_MIN)
+            return fail(c, BF_ERR_ARG, "a slice-local event time does not fit 32 bits (slice longer than 2.1 s?)");
         if (s.xmin < 0 || s.ymin < 0 || s.xmax > 65535 || s.ymax > 65535)
             return fail(c, BF_ERR_ARG, "event coordinates outside [0, 65535]");
         if (s.xmax > w.x_max) w.x_max = s.xmax;

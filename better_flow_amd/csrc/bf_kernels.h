@@ -77,6 +77,7 @@ void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool
 void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_in, uint32_t* xy,
                     int32_t* t_out, float2* p, long long n, long long n_pad, SliceStats* stats,
                     hipStream_t s);
+void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s);
 void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
 void launch_update(DevState* st, const Partial* partials, int nblocks, bf_trace_rec* trace, int mode,

@@ -344,9 +344,27 @@ __global__ void k_set_state(DevState* st, DevState v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *st = v;
 }
 
+// Event::set_local_time (event.h:61-63) for a slice handed over with absolute 64-bit timestamps:
+// t = ts > t0 ? ts - t0 : -(t0 - ts), as the 32-bit slice-local time of the device layout.  A time that does
+// not fit is stored as INT32_MIN, which bf_set_cloud reports (the host front end rejects such slices too).
+__global__ __launch_bounds__(kThreads) void k_local_time(const unsigned long long* __restrict__ ts,
+                                                         unsigned long long t0, int32_t* __restrict__ t_out,
+                                                         long long n) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = ts[i];
+    const long long t = v > t0 ? (long long)(v - t0) : -(long long)(t0 - v);
+    t_out[i] = (t > (long long)INT_MAX || t <= (long long)INT_MIN) ? INT_MIN : (int32_t)t;
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_local_time, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, ts, t0, t_out, n);
+}
+
 LaunchTimer& launch_timer() {
     static thread_local LaunchTimer t;
     return t;

@@ -259,6 +259,19 @@ int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
 
 /* ---- raw device buffers ----------------------------------------------------------- */
 
+/* The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays event ring kept
+ * in pinned memory (bf_host_alloc) -- no AoS -> SoA repack (accel_lib.h:91-99) and no per-slice allocation on
+ * the host.  The slice is the n events starting at ring index `first` (wrapping at `cap`), stored oldest ->
+ * newest; Event::set_local_time(t0) (event.h:61-63) is applied on the device.  Asynchronous like
+ * bf_upload_events_async (same two staging slots; bf_commit_upload makes the slice current).  The ring slots
+ * may be overwritten once bf_wait_uploads has returned. */
+int bf_upload_ring_async(bf_ctx *ctx, const int32_t *ring_fr_x, const int32_t *ring_fr_y,
+                         const uint64_t *ring_timestamp_ns, int64_t cap, int64_t first, int64_t n,
+                         uint64_t t0_ns);
+
+/* Block until the host-to-device copies of every pending asynchronous upload have finished. */
+int bf_wait_uploads(bf_ctx *ctx);
+
 /* ---- contrast-score optimiser: OptimizerLocal (optimizer_sampler.h:12-68) ------------------
  * The secondary score of the path: saturating 8-bit event-count image, Gaussian blur, mean of
  * the non-zero pixels, coordinate descent on (nx, ny).  The blur is this build's own stated

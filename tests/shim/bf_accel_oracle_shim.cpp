@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/bf_accel.h"
@@ -22,6 +23,9 @@ struct bf_ctx {
     bfo_window win;
     bfo_model model;
     bool have_window = false;
+    bool reversed = false;   // events of a ring slice are held newest -> oldest, the order the reference iterates in
+    std::vector<int32_t> pend_x, pend_y;
+    std::vector<int64_t> pend_t;
     bfo_local_window lwin;
     std::vector<float> time_img;
     char err[128] = "";
@@ -70,6 +74,7 @@ int bf_upload_events(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, const 
     c->pr_x.assign(n, 0); c->pr_y.assign(n, 0); c->nx.assign(n, 0); c->ny.assign(n, 0);
     c->bind();
     c->have_window = false;
+    c->reversed = false;
     return BF_OK;
 }
 
@@ -134,6 +139,9 @@ int bf_compute_uv(bf_ctx *c, double *u, double *v) {
     const size_t n = c->fx.size();
     std::vector<double> uu(n), vv(n);
     bfo_compute_uv(c->nx.data(), c->ny.data(), (int64_t)n, uu.data(), vv.data());
+    if (c->reversed) {   // a ring slice is held newest -> oldest; its outputs go back oldest -> newest
+        for (size_t i = 0; i < n / 2; ++i) { std::swap(uu[i], uu[n - 1 - i]); std::swap(vv[i], vv[n - 1 - i]); }
+    }
     if (u) memcpy(u, uu.data(), n * 8);
     if (v) memcpy(v, vv.data(), n * 8);
     return BF_OK;
@@ -193,6 +201,35 @@ int bf_local_run(bf_ctx *c, int32_t res_x, int32_t res_y, int64_t max_evaluation
     out->nx = st.nx; out->ny = st.ny; out->last_score = st.last_score;
     out->dnx = st.dnx; out->dny = st.dny; out->dn_th = st.dn_th; out->evaluations = st.evaluations;
     return rc == -2 ? BF_ERR_NOCONV : rc;
+}
+
+
+// ---- structure-of-arrays ring hand-off (better_flow/stream_flow.h) ----
+int bf_host_alloc(bf_ctx *, int64_t bytes, void **out) { *out = std::malloc((size_t)bytes); return *out ? BF_OK : BF_ERR_HIP; }
+int bf_host_free(bf_ctx *, void *ptr) { std::free(ptr); return BF_OK; }
+int bf_synchronize(bf_ctx *) { return BF_OK; }
+int bf_wait_uploads(bf_ctx *) { return BF_OK; }
+
+int bf_upload_ring_async(bf_ctx *c, const int32_t *rx, const int32_t *ry, const uint64_t *rts, int64_t cap, int64_t first,
+                         int64_t n, uint64_t t0) {
+    c->pend_x.resize(n); c->pend_y.resize(n); c->pend_t.resize(n);
+    for (int64_t i = 0; i < n; ++i) {   // newest -> oldest, like `for (auto &e : ev_buffer)` (dvs_flow.h:195-197)
+        const int64_t k = (first + (n - 1 - i)) % cap;
+        c->pend_x[i] = rx[k]; c->pend_y[i] = ry[k];
+        c->pend_t[i] = rts[k] > t0 ? (int64_t)(rts[k] - t0) : -(int64_t)(t0 - rts[k]);   // event.h:61-63
+    }
+    return BF_OK;
+}
+
+int bf_commit_upload(bf_ctx *c) {
+    const int64_t n = (int64_t)c->pend_x.size();
+    c->fx = c->pend_x; c->fy = c->pend_y; c->t = c->pend_t;
+    c->noise.assign(n, 0);
+    c->pr_x.assign(n, 0); c->pr_y.assign(n, 0); c->nx.assign(n, 0); c->ny.assign(n, 0);
+    c->bind();
+    c->have_window = false;
+    c->reversed = true;
+    return BF_OK;
 }
 
 }  // extern "C"

@@ -1625,6 +1625,42 @@ int bf_local_run(bf_ctx* c, int32_t res_x, int32_t res_y, int64_t max_evaluation
     return BF_OK;
 }
 
+int bf_projection_img(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final, uint8_t* img_out) {
+    if (!c || !img_out) return BF_ERR_ARG;
+    if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_projection_img before bf_upload_events");
+    if (scale < 1 || scale % 2 == 0 || scale > 7) return fail(c, BF_ERR_ARG, "scale must be odd and <= 7 (got %d)", scale);
+    if (res_x < 2 || res_y < 2) return fail(c, BF_ERR_ARG, "bad sensor size");
+    const size_t px = (size_t)res_x * scale * (size_t)res_y * scale;
+    if (px > c->cap_px) return fail(c, BF_ERR_CAPACITY, "image %d x %d exceeds the image capacity", res_x * scale, res_y * scale);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);   // a pending bf_set_model warp moves the events first
+    if (rc != BF_OK) return rc;
+    if (!c->d_lplane[0]) {
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMalloc(&c->d_lplane[i], c->cap_px * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_lscore, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_limg, c->cap_px));
+        HIP_TRY(c, hipHostMalloc(&c->h_lscore, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    // the point planes are shared with the contrast-score path: lay them out afresh for this geometry
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMemsetAsync(c->d_lplane[i], 0, c->cap_px * sizeof(uint32_t), c->stream));
+    c->have_lwin = false;
+    c->lcur = 0;
+    HIP_TRY(c, hipMemsetAsync(c->d_lscore, 0, 2 * sizeof(unsigned long long), c->stream));
+    const bf_ctx::EvSet& e = c->set[c->cs];
+    launch_proj_count(e.xy, e.p, c->has_noise ? c->d_noise : nullptr, c->n, scale, res_x, res_y, show_final ? 1 : 0,
+                      c->d_lplane[0], c->stream);
+    LocalGeom g;
+    memset(&g, 0, sizeof(g));
+    g.scale = scale; g.R = res_x * scale; g.C = res_y * scale;
+    if (launch_local_blur_score(c->d_lplane[0], c->d_lplane[1], g, c->d_lscore, c->d_limg, c->stream) != 0)
+        return fail(c, BF_ERR_ARG, "unsupported scale %d", scale);
+    launch_proj_scale(c->d_limg, (long long)px, c->d_lscore, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(img_out, c->d_limg, px, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
 int bf_get_trace(bf_ctx* c, bf_trace_rec* out, int32_t cap, int32_t* written) {
     if (!c || !out || cap < 0) return BF_ERR_ARG;
     int n = c->trace_valid < cap ? c->trace_valid : cap;

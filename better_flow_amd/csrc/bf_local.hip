@@ -146,4 +146,57 @@ int launch_local_blur_score(const uint32_t* plane, uint32_t* zero_plane, const L
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// EventFile::projection_img (event_file.h:460-515): the motion-compensated event image on the full sensor.
+// P1 point scatter at pr * scale (current projected positions) or fr * scale; then k_local_blur_score (box sum ==
+// the clamped splat: with x < scale (RES - 1) the box never leaves the image, saturation, Gaussian, non-zero sum /
+// count); P2 cv::convertScaleAbs with alpha = 127 / nonzero average: saturate_u8(rint((float)v * (float)alpha)).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_proj_count(const uint32_t* __restrict__ xy, const float2* __restrict__ p,
+                                                         const uint8_t* __restrict__ noise, long long n, int scale,
+                                                         int res_x, int res_y, int show_final,
+                                                         uint32_t* __restrict__ plane) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    if (noise && noise[i]) return;                                        // :472
+    const uint32_t v = xy[i];
+    const uint32_t fx = v & 0xffffu, fy = v >> 16;
+    int X, Y;
+    if (show_final) {                                                     // :485-488
+        X = (int)fx * scale;
+        Y = (int)fy * scale;
+    } else {                                                              // :482-483
+        const float2 q = p[i];
+        X = trunc_x86(pr_from_p(fx, q.x) * (double)scale);
+        Y = trunc_x86(pr_from_p(fy, q.y) * (double)scale);
+    }
+    if ((X >= scale * (res_x - 1)) || (X < 0) || (Y >= scale * (res_y - 1)) || (Y < 0)) return;   // :490
+    X += scale / 2;
+    Y += scale / 2;
+    atomicAdd(&plane[(size_t)X * (size_t)(res_y * scale) + (size_t)Y], 1u);
+}
+
+__global__ __launch_bounds__(kThreads) void k_proj_scale(uint8_t* __restrict__ img, long long n,
+                                                         const unsigned long long* __restrict__ score) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    // EventFile::nonzero_average (event_file.cpp:282-294) and img_scale = 127.0 / it (:512)
+    const double avg = score[1] == 0 ? 0.0 : (double)score[0] / (double)score[1];
+    const float a = (float)(127.0 / avg);
+    const float v = fabsf((float)img[i] * a);
+    img[i] = (uint8_t)((v != v) ? 0 : (v >= 255.0f ? 255 : (int)rintf(v)));   // cvRound + saturate_cast<uchar>
+}
+
+void launch_proj_count(const uint32_t* xy, const float2* p, const uint8_t* noise, long long n, int scale, int res_x,
+                       int res_y, int show_final, uint32_t* plane, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_proj_count, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, xy, p, noise, n,
+                       scale, res_x, res_y, show_final, plane);
+}
+
+void launch_proj_scale(uint8_t* img, long long n, const unsigned long long* score, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_proj_scale, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, img, n, score);
+}
+
 }  // namespace bf

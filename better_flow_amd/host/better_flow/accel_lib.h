@@ -203,6 +203,14 @@ public:
         check(bf_set_model(ctx, &a), "set_model");
     }
 
+    // EventFile::projection_img (event_file.h:460-515) of the staged slice: the 8-bit event image at the current
+    // projected positions (motion compensated once run() has converged) or, show_final, at the sensor positions.
+    bf::Image2D<uint8_t> projection_img(int scale, bool show_final) {
+        bf::Image2D<uint8_t> img(RES_X * scale, RES_Y * scale);
+        check(bf_projection_img(ctx, scale, RES_X, RES_Y, show_final ? 1 : 0, img.ptr(0)), "projection_img");
+        return img;
+    }
+
     // OptimizerLocal on the device (optimizer_sampler.h:29-48; optimizer_sampler.cpp:4-38,120-153)
     void local_set_window(int scale, int wsz, int c_fr_x, int c_fr_y, long long c_t, bf_local_window *w) {
         check(bf_local_set_window(ctx, scale, wsz, c_fr_x, c_fr_y, c_t, w), "local_set_window");

@@ -3,7 +3,8 @@
 // slice warm-started from the previous model ("STM"), accumulation of processed events.
 // Same public interface; the optimizer it drives runs on the MI355X.
 //
-// Not reproduced: the --img / --video rendering branch (dvs_flow.h:256-335, OpenCV drawing) and
+// --img writes one PGM per slice with the reference's two projection images (events as recorded | motion
+// compensated); not reproduced: the colour / arrow composition and --video (dvs_flow.h:256-335, OpenCV drawing) and
 // the unbounded `motion_memory` copies of every slice (:239-242): only the per-slice summary
 // the reference prints (:245-252) is kept.
 #ifndef BF_HOST_DVS_FLOW_H
@@ -46,6 +47,7 @@ protected:
     bool stm_disable;
     bool quiet;
     ull slices_done, slices_skipped, iterations_total;
+    ull frame_count = 0;
 
 public:
     DVS_flow(ull on_ev_change_, ull on_time_change_, ull start_time = 0)
@@ -70,7 +72,6 @@ public:
     void set_generate_pictures(bool val = true, std::string img_prefix_ = "./") {
         this->generate_pictures = val;
         this->img_prefix = img_prefix_;
-        if (val) std::cerr << "--img: frame rendering is outside the motion-compensation path of this build\n";
     }
     void set_stm_disable(bool val = true) { this->stm_disable = val; }
     void set_quiet(bool val = true) { this->quiet = val; }   // the reference parses --quiet but ignores it
@@ -130,6 +131,23 @@ template <size_t MAX_SZ, sll SPAN> void DVS_flow<MAX_SZ, SPAN>::recompute() {   
         this->last_model = optimizer.get_model();
         // :233-235 "compute the actual u and v after minimizations are done" (on the device)
         optimizer.fetch_uv();
+        if (this->generate_pictures) {
+            // dvs_flow.h:256-259,324-326: one frame per slice from EventFile::projection_img(ev_buffer, 3, ...).  The
+            // reference composes those with colour-coded time images and flow arrows into a JPEG through OpenCV; here
+            // the two grey images -- events as recorded | motion compensated -- are written side by side as a PGM.
+            bf::Image2D<uint8_t> raw = optimizer.get_projection_img(3, true), comp = optimizer.get_projection_img(3, false);
+            const std::string fname = this->img_prefix + "/frame_" + std::to_string(this->frame_count++) + ".pgm";
+            if (FILE *f = std::fopen(fname.c_str(), "wb")) {
+                std::fprintf(f, "P5\n%d %d\n255\n", raw.cols + comp.cols, raw.rows);
+                for (int r = 0; r < raw.rows; ++r) {
+                    std::fwrite(raw.ptr(r), 1, (size_t)raw.cols, f);
+                    std::fwrite(comp.ptr(r), 1, (size_t)comp.cols, f);
+                }
+                std::fclose(f);
+            } else if (!this->quiet) {
+                std::cerr << "cannot write " << fname << "\n";
+            }
+        }
         slices_done++;
         if (rc != 0) slices_skipped++;
         iterations_total += optimizer.get_run_info().iterations;

@@ -111,6 +111,12 @@ public:
         return accel.get_count_img(metric_wsizex, metric_wsizey, scale);
     }
 
+    // EventFile::projection_img of this optimizer's events (event_file.h:460-515)
+    bf::Image2D<uint8_t> get_projection_img(int sc, bool show_final) {
+        this->stage();
+        return accel.projection_img(sc, show_final);
+    }
+
     const bf_run_info &get_run_info() const { return last_info; }
     int get_scale_img_x() { this->stage(); return scale_img_x; }
     int get_scale_img_y() { this->stage(); return scale_img_y; }

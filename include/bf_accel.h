@@ -259,6 +259,15 @@ int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
 
 /* ---- raw device buffers ----------------------------------------------------------- */
 
+/* EventFile::projection_img(events, scale, show_final) (event_file.h:460-515): the 8-bit image of the
+ * non-noise events on the full sensor, (res_x * scale) x (res_y * scale) -- at their current projected
+ * positions pr (the motion-compensated image once bf_run has converged) or, with show_final != 0, at their
+ * sensor positions.  Saturating count, this build's 8-bit Gaussian for scale > 1 (see above; the reference's
+ * cv::GaussianBlur is unpinned), brightness normalised to a non-zero mean of 127 (cv::convertScaleAbs:
+ * round-half-even of the float product, saturated).  img_out: host buffer of that many bytes. */
+int bf_projection_img(bf_ctx *ctx, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
+                      uint8_t *img_out);
+
 /* The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays event ring kept
  * in pinned memory (bf_host_alloc) -- no AoS -> SoA repack (accel_lib.h:91-99) and no per-slice allocation on
  * the host.  The slice is the n events starting at ring index `first` (wrapping at `cap`), stored oldest ->

@@ -522,3 +522,37 @@ int bfo_local_run(bfo_cloud *ev, const bfo_local_window *w, int32_t res_x, int32
     }
     return 0;
 }
+
+
+/* ===================== EventFile::projection_img (event_file.h:460-515) ===================== */
+void bfo_projection_img(const bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
+                        uint8_t *img, uint8_t *scratch) {
+    const int32_t R = res_x * scale, C = res_y * scale;   /* :463-464 */
+    memset(img, 0, (size_t)R * (size_t)C);
+    for (int64_t i = 0; i < ev->n; ++i) {
+        if (ev->noise[i]) continue;                        /* :472 */
+        int32_t x = trunc_to_int_x86(ev->pr_x[i] * scale); /* :482-483 */
+        int32_t y = trunc_to_int_x86(ev->pr_y[i] * scale);
+        if (show_final) {                                  /* :485-488 */
+            x = ev->fr_x[i] * scale;
+            y = ev->fr_y[i] * scale;
+        }
+        if ((x >= scale * (res_x - 1)) || (x < 0) || (y >= scale * (res_y - 1)) || (y < 0)) continue;   /* :490 */
+        x += scale / 2;
+        y += scale / 2;
+        const int32_t lx = x - scale / 2 > 0 ? x - scale / 2 : 0, ly = y - scale / 2 > 0 ? y - scale / 2 : 0;   /* :498 */
+        const int32_t rx = x + scale / 2 < R ? x + scale / 2 : R, ry = y + scale / 2 < C ? y + scale / 2 : C;   /* :499 */
+        for (int32_t jx = lx; jx <= rx; ++jx)
+            for (int32_t jy = ly; jy <= ry; ++jy)
+                if (img[(size_t)jx * C + jy] < 255) img[(size_t)jx * C + jy]++;   /* :502-503 */
+    }
+    if (scale > 1) bfo_gauss_u8(img, R, C, scale, scratch);   /* :508-510 */
+    const double avg = bfo_nonzero_average(img, (int64_t)R * C);
+    const double img_scale = 127.0 / avg;                      /* :512; avg == 0 -> +inf, 0 * inf = NaN -> 0 below */
+    const float a = (float)img_scale;
+    for (size_t k = 0; k < (size_t)R * (size_t)C; ++k) {
+        const float v = fabsf((float)img[k] * a);
+        int r = (v != v) ? 0 : (v >= 255.0f ? 255 : (int)lrintf(v));   /* cvRound + saturate_cast<uchar>; NaN -> 0 */
+        img[k] = (uint8_t)r;
+    }
+}

@@ -171,6 +171,17 @@ typedef struct {
 int bfo_local_run(bfo_cloud *ev, const bfo_local_window *w, int32_t res_x, int32_t res_y, int64_t max_evaluations,
                   bfo_local_state *out, uint8_t *img, uint8_t *scratch);
 
+
+/* ---- Motion-compensated event image: EventFile::projection_img (event_file.h:460-515) ----
+ * Saturating 8-bit count image of the non-noise events at pr * scale (or fr * scale when show_final) on the
+ * full sensor (res_x * scale) x (res_y * scale), Gaussian blur for scale > 1 (bfo_gauss_u8: PARITY UNPINNED,
+ * see above), then cv::convertScaleAbs(img, img, 127.0 / nonzero_average, 0), restated as
+ * saturate_u8(round-half-even((float)v * (float)alpha)) -- OpenCV's 8-bit path computes in float and rounds
+ * with cvRound.  The min_t / max_t window of the reference (:463-478) is not used by its callers with
+ * non-default values and is not restated.  img: res_x*scale x res_y*scale bytes; scratch same size. */
+void bfo_projection_img(const bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
+                        uint8_t *img, uint8_t *scratch);
+
 #ifdef __cplusplus
 }
 #endif

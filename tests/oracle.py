@@ -193,6 +193,14 @@ class Cloud:
                                  C.c_int64(max_evaluations), C.byref(st), _p(img, C.c_uint8), _p(scratch, C.c_uint8))
         return rc, st, img
 
+    # EventFile::projection_img (event_file.h:460-515)
+    def projection_img(self, scale, res_x, res_y, show_final=False):
+        img = np.empty((res_x * scale, res_y * scale), dtype=np.uint8)
+        scratch = np.empty_like(img)
+        lib().bfo_projection_img(C.byref(self.c), C.c_int32(scale), C.c_int32(res_x), C.c_int32(res_y),
+                                 C.c_int32(1 if show_final else 0), _p(img, C.c_uint8), _p(scratch, C.c_uint8))
+        return img
+
     def compute_uv(self):
         u = np.empty(self.n)
         v = np.empty(self.n)

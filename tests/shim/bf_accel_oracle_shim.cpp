@@ -232,4 +232,11 @@ int bf_commit_upload(bf_ctx *c) {
     return BF_OK;
 }
 
+
+int bf_projection_img(bf_ctx *c, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final, uint8_t *img_out) {
+    std::vector<uint8_t> scratch((size_t)res_x * scale * (size_t)res_y * scale);
+    bfo_projection_img(&c->cloud, scale, res_x, res_y, show_final, img_out, scratch.data());
+    return BF_OK;
+}
+
 }  // extern "C"

@@ -647,3 +647,35 @@ def test_randomised_differential_fuzz():
                        stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0 and "fuzz: 24 cases, 0 problems" in out, out[-3000:]
+
+
+def test_projection_img_bit_exact(oracle_lib, accel_mod):
+    """EventFile::projection_img on the device: raw and motion-compensated 8-bit event image, bit-exact against the
+    oracle after identical warps (scales 1-7, with a noise mask), and sharper after compensation."""
+    H, W = 180, 240
+    sl = synth.make_slice(50000, H, W, 0.05, seed=42)
+    noise = (np.arange(len(sl["t"])) % 11 == 0).astype(np.uint8)
+    for s in (1, 3, 5, 7):
+        for nz in (None, noise):
+            oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3, noise=nz)
+            if s > 3:   # the ctx of make_pair is sized for scale 3: a bigger image needs a bigger ctx
+                acc.close()
+                acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+                acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"], nz)
+                acc.set_cloud(3, H, W)
+            assert np.array_equal(acc.projection_img(s, H, W, show_final=True), oc.projection_img(s, H, W, show_final=True))
+            for prm in ((0.15, -0.3, 90.0, 120.0, 1e-4, 2e-5), (0.19, -0.38, 90.0, 120.0, 0.0, 0.0)):
+                oc.project_4param_reinit(*prm)
+                acc.project_4param_reinit(*prm)
+                assert np.array_equal(acc.projection_img(s, H, W), oc.projection_img(s, H, W)), (s, prm)
+            acc.close()
+    # after a converged run the compensated image is sharper: fewer lit pixels than the raw one
+    acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=3 * H + 3, max_cols=3 * W + 3)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    acc.set_cloud(3, H, W)
+    o = acc.default_opts()
+    o.res_x, o.res_y = H, W
+    acc.run(o)
+    raw, comp = acc.projection_img(3, H, W, show_final=True), acc.projection_img(3, H, W)
+    assert (comp > 0).sum() < 0.6 * (raw > 0).sum()
+    acc.close()

@@ -261,3 +261,27 @@ def test_local_run_sharpens_the_image(oracle_lib):
     tiny = oracle_lib.Cloud(np.array([5, 6], np.int32), np.array([5, 7], np.int32), np.array([0, 10], np.int64))
     rc2, st2, _ = tiny.local_run(tiny.local_window(3), res_x=H, res_y=W)
     assert rc2 == 1 and st2.evaluations == 0
+
+
+def test_projection_img_against_numpy(oracle_lib):
+    """EventFile::projection_img at show_final (sensor positions): saturating splat, Gaussian, brightness scaling --
+    restated independently in numpy."""
+    H, W = 60, 80
+    sl = synth.make_slice(9000, H, W, 0.05, seed=41)
+    for s in (1, 3, 5):
+        c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+        c.noise[::7] = 1
+        img = c.projection_img(s, H, W, show_final=True)
+        keep = c.noise == 0
+        X, Y = sl["fr_x"][keep].astype(np.int64) * s, sl["fr_y"][keep].astype(np.int64) * s
+        ok = (X < s * (H - 1)) & (Y < s * (W - 1))
+        cnt = np.zeros((H * s, W * s), dtype=np.int64)
+        for da in range(s):
+            for db in range(s):
+                np.add.at(cnt, (X[ok] + da, Y[ok] + db), 1)
+        ref = _np_gauss(np.minimum(cnt, 255).astype(np.uint8), s)
+        nz = ref[ref > 0].astype(np.float64)
+        a = np.float32(127.0 / (nz.sum() / len(nz)))
+        want = np.minimum(np.rint(ref.astype(np.float32) * a), 255).astype(np.uint8)
+        assert np.array_equal(img, want), s
+        assert abs(float(img[img > 0].mean()) - 127.0) < 8.0

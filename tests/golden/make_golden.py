@@ -26,6 +26,10 @@ WARPS = [
 ]
 
 
+LOCAL_N = [[0.0, 0.0], [0.19, -0.38], [-0.4, 0.7]]
+LOCAL_CENTER, LOCAL_WSZ = (40, 70, 20000000), 30
+
+
 def main():
     sl = synth.make_slice(6000, H, W, 0.05, seed=21)
     c = oracle.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
@@ -61,8 +65,32 @@ def main():
         "iterations": int(loop.itercount), "rc": rc,
         "final_model": m2.as_dict(),
     }
+    # ---- second fixture: contrast-score path (OptimizerLocal) and EventFile::projection_img, same slice ----
+    c3 = oracle.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    c3.set_cloud(S, H, W)
+    extra, local = {}, {"candidates": LOCAL_N, "scores_cloud": [], "scores_window": []}
+    lw = c3.local_window(S)
+    lw2 = c3.local_window(S, center=LOCAL_CENTER, wsz=LOCAL_WSZ)
+    for k, (nx, ny) in enumerate(LOCAL_N):
+        sc, img = c3.local_iteration_step(lw, nx, ny)
+        extra["local_cloud_%d" % k] = img
+        local["scores_cloud"].append(sc)
+        sc2, img2 = c3.local_iteration_step(lw2, nx, ny)
+        extra["local_window_%d" % k] = img2
+        local["scores_window"].append(sc2)
+    rcl, st, _ = c3.local_run(lw, res_x=H, res_y=W)
+    local["run"] = {"rc": rcl, "nx": st.nx, "ny": st.ny, "last_score": st.last_score, "evaluations": int(st.evaluations)}
+    local["center"], local["wsz"] = list(LOCAL_CENTER), LOCAL_WSZ
+    c4 = oracle.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    c4.set_cloud(S, H, W)
+    extra["proj_raw"] = c4.projection_img(S, H, W, show_final=True)
+    c4.project_4param_reinit(*WARPS[2])
+    extra["proj_warp2"] = c4.projection_img(S, H, W)
+    np.savez_compressed(os.path.join(HERE, "slice_6k_120x90_images.npz"), **extra)
+    man["images_file"] = "slice_6k_120x90_images.npz"
+    man["local"] = local
     json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
-    print("wrote", man["file"], "iterations", loop.itercount, "events", len(sl["t"]))
+    print("wrote", man["file"], man["images_file"], "iterations", loop.itercount, "events", len(sl["t"]))
 
 
 if __name__ == "__main__":

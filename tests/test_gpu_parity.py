@@ -315,6 +315,31 @@ def test_golden_vectors_gpu(accel_mod):
     acc.close()
 
 
+def test_golden_images_gpu(accel_mod):
+    """Second fixture (no oracle build needed): contrast-score images, scores and descent result, projection images
+    -- all integer work, bit-exact."""
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    man = json.load(open(os.path.join(gold, "manifest.json")))
+    z, zi = np.load(os.path.join(gold, man["file"])), np.load(os.path.join(gold, man["images_file"]))
+    H, W, s, loc = man["height"], man["width"], man["scale"], man["local"]
+    acc = accel_mod.Accel(max_events=len(z["t"]), max_rows=s * H + s, max_cols=s * W + s)
+    acc.upload_events(z["fr_x"], z["fr_y"], z["t"])
+    for tag, center, wsz in (("cloud", None, 0), ("window", tuple(loc["center"]), loc["wsz"])):
+        acc.local_set_window(s, center=center, wsz=wsz)
+        for k, (nx, ny) in enumerate(loc["candidates"]):
+            sc, img = acc.local_iteration_step(nx, ny, want_img=True)
+            assert sc == loc["scores_" + tag][k] and np.array_equal(img, zi["local_%s_%d" % (tag, k)])
+    acc.local_set_window(s)
+    rc, st = acc.local_run(H, W)
+    assert [rc, st.nx, st.ny, st.last_score, st.evaluations] == [loc["run"][k] for k in ("rc", "nx", "ny", "last_score", "evaluations")]
+    acc.set_cloud(s, H, W)
+    assert np.array_equal(acc.projection_img(s, H, W, show_final=True), zi["proj_raw"])
+    acc.project_4param_reinit(*man["warps"][2])
+    assert np.array_equal(acc.projection_img(s, H, W), zi["proj_warp2"])
+    acc.close()
+
+
 def _run_mode(accel_mod, sl, H, W, scale, trace_cap=0, warm=None, **options):
     acc = accel_mod.Accel(max_events=max(len(sl["t"]), 8192), max_rows=scale * H + scale,
                           max_cols=scale * W + scale)

@@ -189,6 +189,28 @@ def test_golden_vectors(oracle_lib):
     assert np.array_equal(got, z["trajectory"])
 
 
+def test_golden_images(oracle_lib):
+    """Second fixture: contrast-score images / scores / descent result and the projection images."""
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))
+    z, zi = np.load(os.path.join(GOLD, man["file"])), np.load(os.path.join(GOLD, man["images_file"]))
+    H, W, s, loc = man["height"], man["width"], man["scale"], man["local"]
+    c = oracle_lib.Cloud(z["fr_x"], z["fr_y"], z["t"])
+    c.set_cloud(s, H, W)
+    lw, lw2 = c.local_window(s), c.local_window(s, center=tuple(loc["center"]), wsz=loc["wsz"])
+    for k, (nx, ny) in enumerate(loc["candidates"]):
+        sc, img = c.local_iteration_step(lw, nx, ny)
+        assert sc == loc["scores_cloud"][k] and np.array_equal(img, zi["local_cloud_%d" % k])
+        sc2, img2 = c.local_iteration_step(lw2, nx, ny)
+        assert sc2 == loc["scores_window"][k] and np.array_equal(img2, zi["local_window_%d" % k])
+    rc, st, _ = c.local_run(lw, res_x=H, res_y=W)
+    assert [rc, st.nx, st.ny, st.last_score, st.evaluations] == [loc["run"][k] for k in ("rc", "nx", "ny", "last_score", "evaluations")]
+    c2 = oracle_lib.Cloud(z["fr_x"], z["fr_y"], z["t"])
+    c2.set_cloud(s, H, W)
+    assert np.array_equal(c2.projection_img(s, H, W, show_final=True), zi["proj_raw"])
+    c2.project_4param_reinit(*man["warps"][2])
+    assert np.array_equal(c2.projection_img(s, H, W), zi["proj_warp2"])
+
+
 # ---- OptimizerLocal: the contrast-score optimiser (optimizer_sampler.cpp) ----
 
 def _np_gauss(img, k):

@@ -86,6 +86,8 @@ def main():
     B = max(1, args.concurrent)
     accs = [accel.Accel(device=device, max_events=nmax, max_rows=s * H + s, max_cols=s * W + s) for _ in range(B)]
     for a_ in accs:
+        if B > 1:
+            a_.set_option("co_schedule", 1)   # several slice contexts share this GPU (include/bf_accel.h)
         for kv in args.opt:
             k_, v_ = kv.split("=")
             a_.set_option(k_, int(v_))
@@ -225,6 +227,8 @@ def main():
                                          "ms_per_slice_per_chain": 1e3 * dtc / reps, "chains_in_flight": B}
 
         # one slice / one chain at a time: the latency view of the same three regimes
+        accs[0].set_option("co_schedule", 0)   # one context alone: the latency build of the stencil kernel
+
         def single(nrep, warm, max_iter):
             prev = step(0)[1] if warm else None
             accs[0].synchronize()

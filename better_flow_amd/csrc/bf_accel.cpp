@@ -49,6 +49,7 @@ struct bf_ctx {
     bool opt_binned = true;
     bool opt_bin_predict = true;
     int opt_bin_tile = 64, opt_bin_margin = 8, opt_bin_threads = 1024;
+    bool opt_co_schedule = false;    // several slice contexts share the GPU: favour co-residency over single-slice speed
     int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
     int n_cus = 0;
     bool use_binned = false;         // decided per slice in bf_set_cloud
@@ -270,6 +271,7 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.slabs = c->d_slabs;
     a.g = c->grid;
     a.cur = buf;
+    a.co_schedule = c->opt_co_schedule ? 1 : 0;
     return a;
 }
 
@@ -575,6 +577,10 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "persist_threads")) {
         if (value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "persist_threads must be 512 or 1024");
         c->opt_persist_threads = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "co_schedule")) {
+        c->opt_co_schedule = value != 0;
         return BF_OK;
     }
     if (!strcmp(key, "bin_tile_rows")) {

@@ -60,6 +60,7 @@ struct StencilArgs {
     const unsigned long long* slabs;
     BinGrid g;
     int cur;
+    int co_schedule;                   // use the register-capped build of the binned stencil kernel
 };
 
 // Profiling hook: when armed (by bf_accel.cpp's ProfScope), the next launch of a loop kernel goes through

@@ -152,6 +152,9 @@ def load():
         L.bf_local_iteration_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p]
         L.bf_local_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(LocalState)]
         L.bf_projection_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.bf_upload_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_uint64]
+        L.bf_wait_uploads.argtypes = [C.c_void_p]
         L.bf_project_4param_reinit.argtypes = [C.c_void_p] + [C.c_double] * 6
         L.bf_get_time_img.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bf_sobel.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -368,6 +371,14 @@ class Accel:
     def upload_events_async(self, fr_x, fr_y, t_ns, n):
         """fr_x / fr_y / t_ns: pinned int32 arrays (pinned_int32); returns immediately."""
         self._chk(self.L.bf_upload_events_async(self.h, _ptr(fr_x), _ptr(fr_y), _ptr(t_ns), int(n)))
+        self._pending_n = getattr(self, "_pending_n", []) + [int(n)]
+
+    def upload_ring_async(self, ring_x, ring_y, ring_ts, first, n, t0):
+        """Slice = n events from ring index `first` (wrapping) of int32 / int32 / uint64 ring arrays (pinned for a
+        true DMA; pageable arrays work too); times become ts - t0 on the device (bf_upload_ring_async)."""
+        assert ring_x.dtype == np.int32 and ring_y.dtype == np.int32 and ring_ts.dtype == np.uint64
+        self._chk(self.L.bf_upload_ring_async(self.h, _ptr(ring_x), _ptr(ring_y), _ptr(ring_ts), int(len(ring_ts)),
+                                              int(first), int(n), int(t0)))
         self._pending_n = getattr(self, "_pending_n", []) + [int(n)]
 
     def commit_upload(self):

@@ -1204,7 +1204,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     bf_trace_rec* trace = o.trace_cap > 0 ? c->d_trace : nullptr;
     int launched_iters = 0;
     DevState fin;
-    if (c->use_persist) {
+    const bool persist = c->use_persist && binned;
+    if (persist) {
         // The whole loop in one cooperative launch; it comes back when the loop is done or the
         // update wants the events re-sorted (the device-gated re-bin kernels that follow do it).
         int gx, gy;
@@ -1261,7 +1262,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     bool want_rebin = false;
     bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
-    for (int batch = 0; !c->use_persist; ++batch) {
+    for (int batch = 0; !persist; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
         // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
         // when a polled snapshot shows the update asking for one.  The request is predictive
@@ -1484,7 +1485,8 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     c->pending_warp = false;
     c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
     c->degenerate = false;
-    c->use_binned = false;
+    c->use_binned = false;    // the events are now sorted by sensor tile, not by image tile
+    c->use_persist = false;
     return BF_OK;
 }
 

@@ -704,3 +704,18 @@ def test_projection_img_bit_exact(oracle_lib, accel_mod):
     raw, comp = acc.projection_img(3, H, W, show_final=True), acc.projection_img(3, H, W)
     assert (comp > 0).sum() < 0.6 * (raw > 0).sum()
     acc.close()
+
+
+def test_context_reuse_fuzz():
+    """scripts/fuzz_reuse.py, a short deterministic run: a long-lived context executing a random mix of uploads (plain,
+    asynchronous, ring), windows, warps, images, cold / warm runs in every scatter / loop mode, tile grids, contrast-score
+    evaluations and projection images gives, after every observable operation, the bits a fresh context gives for the
+    operations since the last upload (no stale state).  Seed 5 is the sequence that exposed a single-launch loop running
+    on stale bins after bf_run_tiles."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "scripts", "fuzz_reuse.py"), "80", "5"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "0 mismatches" in out.splitlines()[-1], out[-3000:]

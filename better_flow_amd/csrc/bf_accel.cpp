@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "bf_device.h"
@@ -123,6 +124,8 @@ struct bf_ctx {
     bool n_valid = false;            // d_nxny holds the n of the last warp
     int warm_iters_hint = 6;         // iterations the previous warm-started run needed
     bool p_clean = false;            // p is all zero (Event::reset state): set by the upload, cleared by any warp
+    bool out_sorted = false;         // d_nxny (and d_uv) are in slot order: un-permute with set[cs].perm before reading back
+    double2* d_out_tmp = nullptr;    // second buffer for that un-permutation
     bool uv_valid = false;           // d_uv holds compute_uv of that n (fused into bf_run's final warp)
     int cur = 0;                     // plane buffer that is guaranteed all-zero
     bool planes_unknown = true;      // both buffers must be cleared before use
@@ -252,6 +255,7 @@ WarpScatterArgs ws_args(bf_ctx* c, int buf, int check_done) {
     a.packed = c->packed;
     a.sets = ev_sets(c);
     a.pick_set = 0;
+    a.sorted_out = 0;
     return a;
 }
 
@@ -358,6 +362,7 @@ int flush_pending(bf_ctx* c) {
     c->p_clean = false;
     c->n_valid = true;
     c->uv_valid = false;
+    c->out_sorted = false;
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -403,6 +408,7 @@ int after_upload(bf_ctx* c, long long n) {
     c->pending_warp = false;
     c->n_valid = false;
     c->uv_valid = false;
+    c->out_sorted = false;
     return BF_OK;
 }
 
@@ -538,7 +544,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
@@ -855,6 +861,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     c->p_clean = true;
     c->n_valid = false;
     c->uv_valid = false;
+    c->out_sorted = false;
     // Tile-binned scatter: usable when the packed accumulator can hold the whole slice (then
     // it can hold any bin), there is no noise mask, and the bin grid fits the kernels' LDS.
     {
@@ -947,6 +954,7 @@ int bf_project_4param_reinit(bf_ctx* c, double dnx_, double dny_, double cx, dou
     c->p_clean = false;
     c->n_valid = true;
     c->uv_valid = false;
+    c->out_sorted = false;
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -1051,6 +1059,25 @@ int bf_fast_model(bf_ctx* c, const float* img, int32_t rows, int32_t cols, bf_mo
     return BF_OK;
 }
 
+// The final warp of bf_run writes its per-event outputs in slot (tile-sorted) order -- coalesced stores instead of
+// 16-byte stores scattered through perm[] (31 -> 10 us per 1M events) -- and they are put back into upload order only
+// when somebody reads them.
+static int materialize_outputs(bf_ctx* c) {
+    if (!c->out_sorted) return BF_OK;
+    c->out_sorted = false;
+    if (!c->has_perm || c->n == 0) return BF_OK;
+    if (!c->d_out_tmp) HIP_TRY(c, hipMalloc(&c->d_out_tmp, (size_t)c->cap_events * sizeof(double2)));
+    const uint32_t* perm = c->set[c->cs].perm;
+    launch_unpermute(c->d_nxny, perm, c->d_out_tmp, c->n, c->stream);
+    std::swap(c->d_nxny, c->d_out_tmp);
+    if (c->uv_valid) {
+        launch_unpermute(c->d_uv, perm, c->d_out_tmp, c->n, c->stream);
+        std::swap(c->d_uv, c->d_out_tmp);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return BF_OK;
+}
+
 static int copy_pairs(bf_ctx* c, const double2* d_src, double* a, double* b) {
     std::vector<double2> tmp((size_t)c->n);
     HIP_TRY(c, hipMemcpyAsync(tmp.data(), d_src, (size_t)c->n * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
@@ -1070,7 +1097,10 @@ int bf_writeout_events(bf_ctx* c, double* pr_x, double* pr_y, double* nx, double
     int rc = flush_pending(c);
     if (rc != BF_OK) return rc;
     if (c->n == 0) return BF_OK;
+    rc = materialize_outputs(c);
+    if (rc != BF_OK) return rc;
     if (pr_x || pr_y) {
+        c->uv_valid = false;   // d_uv is the staging buffer of the expanded positions below
         {
             ProfScope ps(c, 3);
             launch_expand_pr(c->set[c->cs].xy, c->set[c->cs].p, c->has_perm ? c->set[c->cs].perm : nullptr,
@@ -1109,6 +1139,8 @@ int bf_compute_uv(bf_ctx* c, double* u, double* v) {
         }
         return BF_OK;
     }
+    rc = materialize_outputs(c);
+    if (rc != BF_OK) return rc;
     if (!c->uv_valid) {   // (bf_run with want_uv already produced it in its final warp)
         ProfScope ps(c, 3);
         launch_compute_uv(c->d_nxny, c->d_uv, c->n, c->stream);
@@ -1319,6 +1351,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             ProfScope ps(c, 3);
             WarpScatterArgs fa = ws_args(c, buf, 2);
             fa.pick_set = binned ? 1 : 0;
+            fa.sorted_out = 1;
             if (o.want_uv) fa.uv = c->d_uv;
             launch_warp_scatter(fa, true, false, true, c->stream);
             inf.launches++;
@@ -1363,6 +1396,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (!final_done) {
         ProfScope ps(c, 3);
         WarpScatterArgs fa = ws_args(c, buf, 0);
+        fa.sorted_out = 1;
         if (o.want_uv) fa.uv = c->d_uv;   // Event::compute_uv (event.h:135-142) in the same pass
         launch_warp_scatter(fa, true, false, true, c->stream);
         inf.launches++;
@@ -1370,6 +1404,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (warm_start) c->warm_iters_hint = fin.hot.it;
     c->n_valid = true;
     c->uv_valid = o.want_uv != 0;
+    c->out_sorted = true;
     HIP_TRY(c, hipGetLastError());
     if (o.want_uv) HIP_TRY(c, hipStreamSynchronize(c->stream));
 
@@ -1482,6 +1517,7 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     c->p_clean = false;
     c->n_valid = true;
     c->uv_valid = false;
+    c->out_sorted = false;
     c->pending_warp = false;
     c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
     c->degenerate = false;

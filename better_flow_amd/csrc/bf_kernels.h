@@ -31,6 +31,7 @@ struct WarpScatterArgs {
     int check_done;                // 1 inside the fused loop: return at once if st->done; 2: run only if done
     EvSets sets;                   // pick_set: take xy / t / p / perm from sets.s[hot.cs ^ hot.flip] instead
     int pick_set;
+    int sorted_out;                // write nxny / uv at the slot index (coalesced) instead of perm[slot]
     bool packed;
 };
 
@@ -84,6 +85,7 @@ void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
 void launch_update(DevState* st, const Partial* partials, int nblocks, bf_trace_rec* trace, int mode,
                    int cur, hipStream_t s);
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s);
+void launch_unpermute(const double2* src, const uint32_t* perm, double2* dst, long long n, hipStream_t s);
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,
                       hipStream_t s);
 

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void k_warp_scatter(
     const uint8_t* __restrict__ noise, double2* __restrict__ nxny, double2* __restrict__ uv,
     const uint32_t* perm,
     unsigned long long* __restrict__ plane, uint32_t* __restrict__ cplane,
-    const DevState* __restrict__ st, long long n, int check_done, EvSets sets, int pick_set) {
+    const DevState* __restrict__ st, long long n, int check_done, EvSets sets, int pick_set, int sorted_out) {
     const HotState hs = st->hot;   // one burst of scalar loads, then the branch
     // check_done 1: a loop kernel, idle once the loop is done; 2: the final warp enqueued ahead of the poll,
     // runs only if the loop IS done
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(kThreads) void k_warp_scatter(
         const EvSetPtrs e = (hs.cs ^ hs.flip) ? sets.s[1] : sets.s[0];
         xy = e.xy; t = e.t; p = e.p; perm = e.perm;
     }
+    if (sorted_out) perm = nullptr;   // outputs in slot order (coalesced); the host un-permutes them when they are read back
     const WarpParams& wp = hs.wp;
     // arrays are padded to a multiple of kEvPerThread * kThreads elements
     const uint4 vxy = *reinterpret_cast<const uint4*>(xy + base);
@@ -319,6 +320,13 @@ __global__ __launch_bounds__(kThreads) void k_compute_uv(const double2* __restri
     uv[i] = uv_from_n(nxny[i]);
 }
 
+// Per-event outputs written in slot (tile-sorted) order -> upload order: dst[perm[i]] = src[i].
+__global__ __launch_bounds__(kThreads) void k_unpermute(const double2* __restrict__ src, const uint32_t* __restrict__ perm,
+                                                        double2* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) dst[perm[i]] = src[i];
+}
+
 // pr / n read-back helper for writeout_events (accel_lib.h:310-329).
 __global__ __launch_bounds__(kThreads) void k_expand_pr(const uint32_t* __restrict__ xy,
                                                         const float2* __restrict__ p,
@@ -378,10 +386,10 @@ template <bool W, bool S, bool N>
 static void launch_ws(const WarpScatterArgs& a, hipStream_t s, dim3 grid) {
     if (a.packed)
         hipLaunchKernelGGL((k_warp_scatter<W, S, N, true>), grid, dim3(kThreads), 0, s, a.xy, a.t, a.p,
-                           a.noise, a.nxny, a.uv, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done, a.sets, a.pick_set);
+                           a.noise, a.nxny, a.uv, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done, a.sets, a.pick_set, a.sorted_out);
     else
         hipLaunchKernelGGL((k_warp_scatter<W, S, N, false>), grid, dim3(kThreads), 0, s, a.xy, a.t, a.p,
-                           a.noise, a.nxny, a.uv, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done, a.sets, a.pick_set);
+                           a.noise, a.nxny, a.uv, a.perm, a.plane, a.cplane, a.st, a.n, a.check_done, a.sets, a.pick_set, a.sorted_out);
 }
 
 void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool write_n,
@@ -427,6 +435,11 @@ void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_
     if (n <= 0) return;
     hipLaunchKernelGGL(k_compute_uv, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                        s, nxny, uv, n);
+}
+
+void launch_unpermute(const double2* src, const uint32_t* perm, double2* dst, long long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, src, perm, dst, n);
 }
 
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,

@@ -719,3 +719,36 @@ def test_context_reuse_fuzz():
                        stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0 and "0 mismatches" in out.splitlines()[-1], out[-3000:]
+
+
+def test_readback_order_and_buffer_reuse(oracle_lib, accel_mod):
+    """Per-event outputs after a tile-binned run are produced in tile-sorted order and un-permuted on read-back; the
+    position read-back borrows the flow buffer.  Every read-back order must give the same, correctly ordered, data."""
+    H, W, s = 180, 240, 3
+    sl = synth.make_slice(40000, H, W, 0.04, seed=77)
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, s)
+    o = acc.default_opts()
+    o.res_x, o.res_y, o.want_uv = H, W, 1
+    acc.run(o)
+    u1, v1 = acc.compute_uv()
+    pr_x, pr_y, nx, ny = acc.writeout_events()          # uses the flow buffer as staging for pr
+    u2, v2 = acc.compute_uv()
+    assert np.array_equal(u1, u2) and np.array_equal(v1, v2)
+    # (u, v) == n * 1e5 / 127 element by element (event.h:135-142), i.e. flow and n are in the same (upload) order
+    ou, ov = oracle_lib.lib(), None
+    uu = np.empty_like(nx); vv = np.empty_like(ny)
+    import ctypes as C
+    oracle_lib.lib().bfo_compute_uv(nx.ctypes.data_as(C.POINTER(C.c_double)), ny.ctypes.data_as(C.POINTER(C.c_double)),
+                                    C.c_int64(len(nx)), uu.ctypes.data_as(C.POINTER(C.c_double)), vv.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.allclose(u1, uu, rtol=1e-12, atol=1e-12) and np.allclose(v1, vv, rtol=1e-12, atol=1e-12)
+    # pr belongs to the same event as fr: the compensated position moved by n / 127 * t / 1e4 from the sensor position
+    exp_x = sl["fr_x"] - (nx / 127.0) * sl["t"] / 1e4
+    assert np.max(np.abs(pr_x - exp_x)) < 1e-3
+    # same data when the order of read-backs is different, and without the fused flow
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]); acc.set_cloud(s, H, W)
+    o.want_uv = 0
+    acc.run(o)
+    pr_x3, pr_y3, nx3, ny3 = acc.writeout_events()
+    u3, v3 = acc.compute_uv()
+    assert np.array_equal(nx3, nx) and np.array_equal(pr_x3, pr_x) and np.array_equal(u3, u1) and np.array_equal(v3, v1)
+    acc.close()

@@ -283,6 +283,14 @@ def main():
             "avg_launch_us": k1_s * 1e6, "launches": int(live), "launches_incl_early_exit": int(p.warp_scatter_launches),
             "algorithmic_bytes_per_launch": K1_BYTES_PER_EVENT_ITER * ev_per_launch,
             "measured_copy_ceiling_gbps": copy_gbps,
+            # the other loop kernel, by the same rule: SURVEY 8(d) prices the image side of an iteration at 24 B / pixel
+            "stencil_kernel": {
+                "kernel": "k_stencil_binned (slab merge + box sum + time image + Scharr + moments + fused update)",
+                "algorithmic_bytes_per_launch": 24.0 * (s * (H - 1) + s) * (s * (W - 1) + s),
+                "achieved": 24.0 * (s * (H - 1) + s) * (s * (W - 1) + s) / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9,
+                "frac": 24.0 * (s * (H - 1) + s) * (s * (W - 1) + s) / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS,
+                "note": "instruction-issue bound, not bandwidth bound: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
+            },
             "per_kernel_us": {
                 "warp_scatter": 1e3 * p.warp_scatter_ms / max(1, live),
                 "stencil_moments_update": 1e3 * p.stencil_ms / max(1, live),

@@ -259,6 +259,10 @@ def main():
             live_ev_iters += n_ * info_.iterations
         p = acc.profile_get()
         acc.profile_enable(0)
+        dx_, dy_, dt_, n__ = resident[0]
+        acc.upload_events_device(dx_, dy_, dt_, n__)
+        win_ = acc.set_cloud(s, H, W)
+        img_px = float(win_.scale_img_x) * float(win_.scale_img_y)   # P of SURVEY 8(d): the slice's image
         # total time of ALL loop launches of K1 (the few early-exit launches after convergence included) over the
         # launches that did the work: a slightly pessimistic per-launch duration
         k1_s = p.warp_scatter_ms * 1e-3 / max(1, live)
@@ -286,9 +290,9 @@ def main():
             # the other loop kernel, by the same rule: SURVEY 8(d) prices the image side of an iteration at 24 B / pixel
             "stencil_kernel": {
                 "kernel": "k_stencil_binned (slab merge + box sum + time image + Scharr + moments + fused update)",
-                "algorithmic_bytes_per_launch": 24.0 * (s * (H - 1) + s) * (s * (W - 1) + s),
-                "achieved": 24.0 * (s * (H - 1) + s) * (s * (W - 1) + s) / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9,
-                "frac": 24.0 * (s * (H - 1) + s) * (s * (W - 1) + s) / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_launch": 24.0 * img_px,
+                "achieved": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9,
+                "frac": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS,
                 "note": "instruction-issue bound, not bandwidth bound: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
             },
             "per_kernel_us": {

@@ -51,6 +51,7 @@ struct bf_ctx {
     bool opt_bin_predict = true;
     int opt_bin_tile = 64, opt_bin_margin = 8, opt_bin_threads = 1024;
     bool opt_co_schedule = false;    // several slice contexts share the GPU: favour co-residency over single-slice speed
+    int opt_bin_pack_limit = 64;     // bits available to the per-bin packing (lower only to test the fallback)
     int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
     int n_cus = 0;
     bool use_binned = false;         // decided per slice in bf_set_cloud
@@ -345,7 +346,7 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
 int enqueue_rebin(bf_ctx* c, bool has_perm_at_start, const WarpParams* prewarp = nullptr) {
     ProfScope ps(c, 3);
     launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, c->d_state, c->grid, c->d_binid, c->d_hist_cnt,
-                 c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->stream);
+                 c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->opt_bin_pack_limit, c->stream);
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -583,6 +584,11 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "persist_threads")) {
         if (value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "persist_threads must be 512 or 1024");
         c->opt_persist_threads = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_pack_limit")) {
+        if (value < 1 || value > 64) return fail(c, BF_ERR_ARG, "bin_pack_limit must be in [1, 64]");
+        c->opt_bin_pack_limit = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "co_schedule")) {
@@ -862,8 +868,8 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     c->n_valid = false;
     c->uv_valid = false;
     c->out_sorted = false;
-    // Tile-binned scatter: usable when the packed accumulator can hold the whole slice (then
-    // it can hold any bin), there is no noise mask, and the bin grid fits the kernels' LDS.
+    // Tile-binned scatter: usable when there is no noise mask and the bin grid fits the kernels' LDS.  Its own
+    // per-bin packing is decided on the device by the counting sort (k_bin_scan), with the overflow path as fallback.
     {
         BinGrid g;
         g.TS = c->opt_bin_tile;
@@ -894,7 +900,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         g.mul_r = (uint32_t)(0x100000000ull / (unsigned)g.TSR) + 1u;
         g.nbr = (w.scale_img_x + g.TSR - 1) / g.TSR;
         g.nbins = g.nbr * g.nbc;
-        c->use_binned = c->opt_binned && c->packed && !c->has_noise && c->n > 0 && g.nbins <= 4096 &&
+        c->use_binned = c->opt_binned && !c->force_split && !c->has_noise && c->n > 0 && g.nbins <= 4096 &&
                         (size_t)g.LR * g.L * 8 <= 160 * 1024 && w.scale_img_x < (1 << 20);
         if (c->use_binned) {
             int rc = ensure_cplanes(c);
@@ -914,8 +920,9 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         }
         h.hot.binned = c->use_binned ? 1 : 0;
         h.n_events = (uint32_t)c->n;
-        h.hot.bin_tbits = tbits; h.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
+        h.hot.bin_tbits = tbits > 62 ? 62 : tbits; h.hot.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
         h.hot.flip = 0;
+        h.t_span = (c->n > 0) ? (long long)s.tmax - (long long)s.tmin : 0;
         h.t_abs_max = (c->n > 0) ? std::fmax(std::fabs((double)s.tmin), std::fabs((double)s.tmax)) : 0.0;
         h.r_max = std::hypot((double)(w.x_max - w.x_min), (double)(w.y_max - w.y_min)) + 64.0;
         h.drift_limit = c->opt_bin_predict ? 0.6 * (double)c->grid.D : 1e300;

@@ -91,22 +91,25 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_cnt, int nbins,
                                                    uint32_t* __restrict__ bin_start,
                                                    uint32_t* __restrict__ cursor, DevState* st,
-                                                   uint32_t* __restrict__ armed) {
+                                                   uint32_t* __restrict__ armed, int pack_limit) {
     if (!st->hot.need_rebin || st->hot.done) return;
     __shared__ uint32_t s_sum[1024];
+    __shared__ uint32_t s_maxc[1024];
     const int tid = threadIdx.x;
     const int per = (nbins + 1023) / 1024;
-    uint32_t local = 0;
+    uint32_t local = 0, maxc = 0;
     for (int k = 0; k < per; ++k) {
         const int b = tid * per + k;
-        if (b < nbins) local += hist_cnt[b];
+        if (b < nbins) { local += hist_cnt[b]; maxc = max(maxc, hist_cnt[b]); }
     }
-    s_sum[tid] = local;
+    s_sum[tid] = local; s_maxc[tid] = maxc;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan (sum) / running maximum
         uint32_t v = (tid >= off) ? s_sum[tid - off] : 0u;
+        uint32_t mc = (tid >= off) ? s_maxc[tid - off] : 0u;
         __syncthreads();
         s_sum[tid] += v;
+        s_maxc[tid] = max(s_maxc[tid], mc);
         __syncthreads();
     }
     uint32_t run = s_sum[tid] - local;   // exclusive prefix of this thread's first bin
@@ -121,10 +124,23 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_c
     }
     if (tid == 1023) {
         bin_start[nbins] = s_sum[1023];
-        // packing of the per-bin tiles: the slice-wide one (set_cloud made sure it fits), so that slabs can be
-        // merged and box-summed without unpacking
-        st->hot.bin_tbits = st->hot.tbits;
-        st->bin_ok = 1;
+        // Packing of the per-bin tiles (count << tbits | time sum).  Whatever is summed in packed form downstream -- a
+        // tile pixel, the <= 2 x 2 slabs merged at a pixel, the s x s box around it -- is a sum over events of at most
+        // four bins, each adding 1 and at most t_span: the fields need bits(4 maxc) and bits(4 maxc t_span), with maxc
+        // the fullest bin.  (A slice-wide bound -- bits(N) + bits(sum of all times) -- stops fitting 64 bits just above
+        // 1M events x 30 ms.)  If even this does not fit (nearly all events in one bin), bin_ok = 0 sends every event
+        // down the exact overflow path (unpacked u64 + u32 planes).
+        const unsigned long long m4 = 4ull * (unsigned long long)s_maxc[1023];
+        int cb = 0, tb = 0;
+        for (unsigned long long v = m4; v; v >>= 1) ++cb;
+        const unsigned long long span = (unsigned long long)(st->t_span > 0 ? st->t_span : 1);
+        // bits(m4 * span) without overflowing 64 bits: bits(a b) <= bits(a) + bits(b)
+        int sb = 0;
+        for (unsigned long long v = span; v; v >>= 1) ++sb;
+        tb = cb + sb;
+        if (tb < 1) tb = 1;
+        st->hot.bin_tbits = tb;
+        st->hot.bin_ok = (tb + cb <= pack_limit) ? 1 : 0;   // (pack_limit: 64; lower only to test the fallback)
         st->hot.need_rebin = 0;
         st->hot.flip = 1;            // k_bin_scatter (next kernel) moves the events to set cs^1
         st->hot.rebins += 1;
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
     const WarpParams& wp = hs.wp;
     const int s = hs.scale, x_sh = hs.x_sh, y_sh = hs.y_sh, hsc = hs.scale / 2;
     const int wsx = hs.wsx, wsy = hs.wsy, C = hs.C, tbits = hs.bin_tbits;
+    const bool bin_ok = hs.bin_ok != 0;
     const long long tmin = hs.tmin;
     uint32_t n_ovf = 0;
     __syncthreads();
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
             if (!((X >= wsx + hsc) || (X < hsc) || (Y >= wsy + hsc) || (Y < hsc))) {
                 const unsigned long long dt = (unsigned long long)((long long)ti - tmin);
                 const int lx = X - X0, ly = Y - Y0;
-                if (lx >= 0 && lx < LR && ly >= 0 && ly < L) {
+                if (bin_ok && lx >= 0 && lx < LR && ly >= 0 && ly < L) {
                     atomicAdd(&s_tile[__mul24(lx, L) + ly], (1ull << tbits) + dt);
                 } else {   // drifted out of this bin's tile: exact, slow path
                     const size_t kk = (size_t)X * (size_t)C + (size_t)Y;
@@ -392,8 +409,6 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     const int rb_l0 = bl * g.nbc * LLi - (bl * g.TSR - g.D) * g.L, rb_l1 = rb_l0 + g.nbc * LLi - g.TSR * g.L;
     const int rb_h0 = bh * g.nbc * LLi - (bh * g.TSR - g.D) * g.L, rb_h1 = rb_h0 + g.nbc * LLi - g.TSR * g.L;
     unsigned long long w[NC][4];
-    unsigned long long ov[NC];
-    uint32_t oc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int idx = tid + c * kThreads;
@@ -415,18 +430,15 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
             // 32-bit element offsets (the slabs and planes are far below 2^32 bytes): base + offset addressing
             w[c][q] = use ? a.slabs[(uint32_t)(((q & 2) ? rowpart_h : rowpart_l) + ((q & 1) ? colpart_h : colpart_l))] : 0ull;
         }
-        ov[c] = (in && ovf) ? a.plane[(uint32_t)(__mul24(gr, C) + gc)] : 0ull;
-        oc[c] = (in && ovf) ? a.cplane[(uint32_t)(__mul24(gr, C) + gc)] : 0u;
     }
-    // The accumulators stay PACKED (count << tbits | time sum) through the merge and the box sum: both
-    // fields were sized for the whole slice (tbits = bits of the sum over ALL events, the rest holds the
-    // event count), so no sum over any set of events -- up to 2 x 2 slabs, the overflow planes, the s x s
-    // box -- can carry from one field into the other.  One 64-bit add per contribution, one unpack per pixel.
+    // The slab accumulators stay PACKED (count << tbits | time sum) through the merge and the box sum: k_bin_scan sized
+    // the fields for any sum over the events of up to four bins, which covers the <= 2 x 2 slabs at a pixel and the
+    // s x s box around it.  One 64-bit add per contribution, one unpack per pixel.  Events that took the overflow path
+    // are outside that bound (they come from any bin): their planes are read unpacked below, only when there are any.
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int idx = tid + c * kThreads;
-        if (idx < PR * PC)
-            s_acc[idx] = ((w[c][0] + w[c][1]) + (w[c][2] + w[c][3])) + (ov[c] + ((unsigned long long)oc[c] << bt));
+        if (idx < PR * PC) s_acc[idx] = (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
     }
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
@@ -442,8 +454,20 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
             for (int da = 0; da <= 2 * HS; ++da)
 #pragma unroll
                 for (int db = 0; db <= 2 * HS; ++db) pk += s_acc[(tr + da) * PC + (tc + db)];
-            const unsigned long long acc = pk & bm;
-            const uint32_t cacc = (uint32_t)(pk >> bt);
+            unsigned long long acc = pk & bm;
+            uint32_t cacc = (uint32_t)(pk >> bt);
+            if (ovf) {   // rare: the overflow planes (u64 time sums, u32 counts) straight from memory, box by box
+#pragma unroll
+                for (int da = -HS; da <= HS; ++da)
+#pragma unroll
+                    for (int db = -HS; db <= HS; ++db) {
+                        const int pr_ = gr + da, pc_ = gc + db;
+                        if (pr_ >= 0 && pr_ < R && pc_ >= 0 && pc_ < C) {
+                            acc += a.plane[(uint32_t)(__mul24(pr_, C) + pc_)];
+                            cacc += a.cplane[(uint32_t)(__mul24(pr_, C) + pc_)];
+                        }
+                    }
+            }
             tv = time_from_sums(cacc, (long long)acc, a.tmin);
             if (tr >= 1 && tr <= TR && tc >= 1 && tc <= TC) {
                 if (a.time_out) a.time_out[(size_t)gr * C + gc] = tv;
@@ -500,7 +524,7 @@ void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
 // ---------------------------------------------------------------------------------------
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
                   uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
-                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, hipStream_t s) {
+                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s) {
     if (n <= 0) return;
     long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
     if (blocks > 1024) blocks = 1024;
@@ -511,7 +535,7 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
         hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 4, s, sets, n,
                            st, g, binid, hist_cnt, armed, WarpParams{});
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, hist_cnt, g.nbins, bin_start, cursor,
-                       st, armed);
+                       st, armed, pack_limit);
     const size_t lds = ((size_t)g.nbins * 2 + (g.nbins & 1)) * 4 + (size_t)kBsEvents * (4 + 4 + 4 + 2 + 8);
     hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBsEvents - 1) / kBsEvents)), dim3(kThreads), lds, s, sets,
                        has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);

@@ -66,7 +66,8 @@ struct HotState {
     int32_t done, it, binned, bin_tbits;
     uint32_t ovf_cnt[2];      // events that took the overflow path into plane buffer [i]
     int32_t need_rebin, rebins;
-    int32_t cs, flip, pad0, pad1;   // live event set; flip = a re-bin moved the events to set cs^1
+    int32_t cs, flip, bin_ok, pad1;   // live event set; flip = a re-bin moved the events to set cs^1;
+                                      // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)
                                     // (committed by the next update)
     // window (host-written at set_cloud)
     int32_t scale, R, C, wsx, wsy, x_sh, y_sh, tbits;
@@ -80,12 +81,13 @@ struct DevState {
     // --- loop control (optimizer_rolling.h:36,59-63) ---
     float x_div, y_div, rot_div, div_div;
     float old_dx, old_dy, old_rot, old_div;
-    int32_t max_iter, hard_cap, rc, trace_cap, nblocks, bin_ok;
+    int32_t max_iter, hard_cap, rc, trace_cap, nblocks, pad2;
     uint32_t ovf_total, n_events;
     // --- drift tracking of the tile-binned scatter: warp parameters at the last re-bin, and
     //     the largest |t| (ns) and lever arm (sensor px) an event of this slice can have ---
     WarpParams ref_wp;
     double t_abs_max, r_max, drift_limit;
+    long long t_span;                 // tmax - tmin of the slice (ns): bound of one event's time addend
     // --- model ---
     bf_model model;
 };

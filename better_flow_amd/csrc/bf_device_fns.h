@@ -284,9 +284,11 @@ __device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, 
                           2.0 * st->r_max * (fabs(wp.div - r.div) + fabs(wp.s - r.s)) +
                           (fabs(wp.div) + fabs(wp.s)) * (fabs(wp.cx - r.cx) + fabs(wp.cy - r.cy));
         const double drift = (double)st->hot.scale * dn / 127.0 * st->t_abs_max / 10000.0;
-        if (drift > st->drift_limit) st->hot.need_rebin = 1;
-        // safety net: whatever the bound missed shows up as overflow events
-        if ((unsigned long long)oc * 64ull > (unsigned long long)st->n_events) st->hot.need_rebin = 1;
+        if (st->hot.bin_ok) {   // (bin_ok == 0: every event takes the overflow path by design, nothing to re-sort)
+            if (drift > st->drift_limit) st->hot.need_rebin = 1;
+            // safety net: whatever the bound missed shows up as overflow events
+            if ((unsigned long long)oc * 64ull > (unsigned long long)st->n_events) st->hot.need_rebin = 1;
+        }
     } else {
         st->hot.ovf_cnt[cur] = 1;
     }

@@ -114,7 +114,7 @@ int bin_kernel_setup();
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
                   uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
-                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, hipStream_t s);
+                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s);
 void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs,
                              unsigned long long* ovf_plane, uint32_t* ovf_cplane, DevState* st,
                              const BinGrid& g, int cur, bool warp, int check_done, int threads,

@@ -84,7 +84,7 @@ __device__ __forceinline__ void tlp(unsigned long long* tl, int it, int wg, int 
 struct ScatterCtx {
     WarpParams wp;
     long long tmin;
-    int s, x_sh, y_sh, hsc, wsx, wsy, C, tbits, X0, Y0, L;
+    int s, x_sh, y_sh, hsc, wsx, wsy, C, tbits, X0, Y0, L, bin_ok;
 };
 
 // Warp (event.h:100-108,164-168) + scatter (accel_lib.h:154-158) of one event -- the arithmetic
@@ -107,7 +107,7 @@ __device__ __forceinline__ void warp_scatter_one(const ScatterCtx& c, uint32_t v
     if (!((X >= c.wsx + c.hsc) || (X < c.hsc) || (Y >= c.wsy + c.hsc) || (Y < c.hsc))) {
         const unsigned long long dt = (unsigned long long)((long long)ti - c.tmin);
         const int lx = X - c.X0, ly = Y - c.Y0;
-        if (lx >= 0 && lx < c.L && ly >= 0 && ly < c.L) {
+        if (c.bin_ok && lx >= 0 && lx < c.L && ly >= 0 && ly < c.L) {
             atomicAdd(&s_tile[lx * c.L + ly], (1ull << c.tbits) + dt);
         } else {   // drifted out of this bin's tile: exact, slow path
             const size_t kk = (size_t)X * (size_t)c.C + (size_t)Y;
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(THREADS) void k_persist(PersistArgs a) {
         }
         sc.wp = s_state->hot.wp;
         sc.tbits = s_state->hot.bin_tbits;
+        sc.bin_ok = s_state->hot.bin_ok;
         // (static indices only: a runtime index would push the argument struct into scratch memory)
         unsigned long long* ovf_plane = cur ? a.ovf_plane[1] : a.ovf_plane[0];
         uint32_t* ovf_cplane = cur ? a.ovf_cplane[1] : a.ovf_cplane[0];

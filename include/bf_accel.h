@@ -141,6 +141,9 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "binned"       1 (default): tile-binned LDS scatter inside bf_run; 0: one global
  *                  atomic per event.  Results are identical.
  *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 64).
+ *   "bin_pack_limit"  bits the per-bin accumulator packing may use (default 64).  The counting sort sizes the
+ *                  packed count / time-sum fields from the fullest bin; if they do not fit, every event takes the
+ *                  exact unpacked path.  Lower values only serve to exercise that fallback in tests.
  *   "co_schedule"  1: this context shares the GPU with other slice contexts (threads / streams): use the
  *                  register-capped build of the stencil kernel, which co-resides with other contexts'
  *                  scatter kernels (+8 % aggregate throughput at 4 contexts, -3 % for a context alone).

@@ -752,3 +752,29 @@ def test_readback_order_and_buffer_reuse(oracle_lib, accel_mod):
     u3, v3 = acc.compute_uv()
     assert np.array_equal(nx3, nx) and np.array_equal(pr_x3, pr_x) and np.array_equal(u3, u1) and np.array_equal(v3, v1)
     acc.close()
+
+
+def test_large_slices_stay_on_the_binned_path(accel_mod):
+    """Slices beyond ~1.05M events x 30 ms no longer fit a slice-wide packed accumulator; the tile-binned scatter packs
+    per bin (fields sized from the fullest bin) and must stay bit-identical to the global-atomic split path -- also
+    when the packing is forced not to fit and every event takes the overflow path."""
+    H, W, s = 260, 346, 3
+    sl = synth.make_slice(1600000, H, W, 0.030, seed=3)
+    runs = {}
+    for name, opts in (("binned", {}), ("atomics", {"binned": 0}), ("fallback", {"bin_pack_limit": 8}), ("single", {"persist": 1})):
+        a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+        for k, v in opts.items():
+            a.set_option(k, v)
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        a.set_cloud(s, H, W)
+        o = a.default_opts()
+        o.res_x, o.res_y, o.max_iter, o.trace_cap = H, W, 6, 8
+        rc, m, info = a.run(o)
+        runs[name] = (rc, info.iterations, m.as_dict(), [t_.model.as_dict() for t_ in a.get_trace(8)], a.compute_uv()[0].tobytes())
+        if name == "binned":
+            assert info.overflow_events == 0 and info.rebins >= 1
+        if name == "fallback":
+            assert info.overflow_events > len(sl["t"])      # every event, every iteration
+        a.close()
+    assert runs["binned"] == runs["atomics"] == runs["fallback"] == runs["single"]
+    assert runs["binned"][2]["cnt"] > 500000

@@ -72,9 +72,11 @@ for ci in range(cases):
     ow = oc.set_cloud(s, H, W)
     K = int(rng.integers(2, 40))
     results = {}
-    modes = [("default", {}), ("atomics", {"binned": 0}), ("tile32", {"bin_tile": 32, "bin_margin": int(rng.choice([4, 8, 12]))}),
-             ("persist", {"persist": 1}), ("nopredict", {"bin_predict": 0, "bin_margin": 2}), ("co", {"co_schedule": 1}), ("fallback", {"bin_pack_limit": int(rng.choice([1, 20, 40]))}),
-             ("rows", {"bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))})]
+    modes = [("default", {}), ("atomics", {"binned": 0}), ("binned", {"binned": 2}),
+             ("tile32", {"binned": 2, "bin_tile": 32, "bin_margin": int(rng.choice([4, 8, 12]))}),
+             ("persist", {"binned": 2, "persist": 1}), ("nopredict", {"binned": 2, "bin_predict": 0, "bin_margin": 2}),
+             ("co", {"binned": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
+             ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))})]
     for name, kv in modes:
         a = accel.Accel(max_events=max(n, 16), max_rows=s * H + s, max_cols=s * W + s)
         for k_, v_ in kv.items():

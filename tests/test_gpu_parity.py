@@ -368,8 +368,8 @@ def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
     sl = synth.make_slice(60000, H, W, 0.05, seed=17)
     ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=0)
     assert ref[2].rebins == 0
-    for opts in (dict(binned=1), dict(binned=1, bin_tile=32, bin_margin=2),
-                 dict(binned=1, bin_tile=16, bin_margin=4), dict(binned=1, bin_tile=128, bin_margin=6)):
+    for opts in (dict(binned=2), dict(binned=2, bin_tile=32, bin_margin=2),
+                 dict(binned=2, bin_tile=16, bin_margin=4), dict(binned=2, bin_tile=128, bin_margin=6)):
         got = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, **opts)
         assert got[0] == ref[0] and got[2].iterations == ref[2].iterations, opts
         assert got[2].rebins >= 1
@@ -381,7 +381,7 @@ def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
         assert np.array_equal(got[5], ref[5]) and np.array_equal(got[6], ref[6]), opts
     # without the drift prediction the re-bin is triggered by observed overflow only: the exact
     # global-atomic overflow path must give the same bits
-    tiny = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=1, bin_tile=32, bin_margin=2,
+    tiny = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=2, bin_tile=32, bin_margin=2,
                      bin_predict=0)
     assert tiny[2].overflow_events > 0 and tiny[2].rebins > 1, "margin 2 must exercise overflow + re-bin"
     assert tiny[1].as_dict() == ref[1].as_dict() and tiny[2].iterations == ref[2].iterations
@@ -395,7 +395,7 @@ def test_binned_warm_start_bit_identical(accel_mod):
     b = synth.make_slice(40000, H, W, 0.05, seed=32)
     cold = _run_mode(accel_mod, a, H, W, 3, binned=0)
     w0 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=0)
-    w1 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=1)
+    w1 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=2)
     assert w0[2].iterations == w1[2].iterations and w0[1].as_dict() == w1[1].as_dict()
     for x, y in zip(w0[4], w1[4]):
         assert np.array_equal(x, y)
@@ -510,7 +510,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
     om = oracle_lib.Model()
     orc, oloop, otr = oc2.run(ow2, om, max_iter=K, res_x=H, res_y=W, trace_cap=K + 1)
     runs = {}
-    for name, opts in (("binned", dict(binned=1)), ("atomics", dict(binned=0)), ("binned2", dict(binned=1))):
+    for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2))):
         a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         for k, v in opts.items():
             a2.set_option(k, v)

@@ -49,7 +49,7 @@ struct bf_ctx {
     // tile-binned scatter
     int opt_binned = 1;              // 0 never, 1 when it pays (dense enough), 2 whenever possible
     bool opt_bin_predict = true;
-    int opt_bin_tile = 64, opt_bin_margin = 8, opt_bin_threads = 1024;
+    int opt_bin_tile = 0, opt_bin_margin = 8, opt_bin_threads = 1024;   // bin_tile 0: chosen per slice
     bool opt_co_schedule = false;    // several slice contexts share the GPU: favour co-residency over single-slice speed
     int opt_bin_pack_limit = 64;     // bits available to the per-bin packing (lower only to test the fallback)
     int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
@@ -573,8 +573,8 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         return BF_OK;
     }
     if (!strcmp(key, "bin_tile")) {
-        if (value != 16 && value != 32 && value != 64 && value != 128)
-            return fail(c, BF_ERR_ARG, "bin_tile must be 16, 32, 64 or 128");
+        if (value != 0 && value != 16 && value != 32 && value != 64 && value != 128)
+            return fail(c, BF_ERR_ARG, "bin_tile must be 0 (auto), 16, 32, 64 or 128");
         c->opt_bin_tile = (int)value;
         return BF_OK;
     }
@@ -873,27 +873,38 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     // per-bin packing is decided on the device by the counting sort (k_bin_scan), with the overflow path as fallback.
     {
         BinGrid g;
-        g.TS = c->opt_bin_tile;
-        g.lg = 0;
-        while ((1 << g.lg) < g.TS) ++g.lg;
-        g.nbc = (w.scale_img_y + g.TS - 1) / g.TS;
-        // Tile height: one work-group per bin, so the bins should fill the CUs in as few waves of
-        // work-groups as possible with the smallest tiles that do it (the fullest tile sets the length of
-        // the scatter kernel).  Cost model: ceil(bins / CUs) x tile area; ties go to the larger tile (less
-        // margin overhead).  "bin_tile_rows" overrides.
-        g.TSR = c->opt_bin_tile_rows;
-        if (g.TSR <= 0) {
-            g.TSR = g.TS < 32 ? 32 : g.TS;
-            if (c->n_cus > 0 && !c->opt_persist) {   // (the single-launch loop is written for square 64 x 64 tiles)
-                long long best = -1;
+        // Tile shape: one work-group per bin.  Cost model of one iteration (calibrated on config 2, in us):
+        //   waves of work-groups x events per tile x 1.7 ns   (the fullest CU sets the length of the scatter kernel)
+        // + slab pixels x 2.3 ps                               (every slab pixel is written and re-read)
+        // over widths {16, 32, 64} (a power of two) and heights {32 .. 128}; ties go to the larger tile.  Small dense
+        // images get small tiles (enough bins to fill the CUs), large images large ones (less margin overhead).
+        // "bin_tile" / "bin_tile_rows" override.
+        g.TS = c->opt_bin_tile > 0 ? c->opt_bin_tile : 64;
+        g.TSR = c->opt_bin_tile_rows > 0 ? c->opt_bin_tile_rows : (g.TS < 32 ? 32 : g.TS);
+        if (c->n_cus > 0 && !c->opt_persist && (c->opt_bin_tile <= 0 || c->opt_bin_tile_rows <= 0)) {
+            // (the single-launch loop is written for square 64 x 64 tiles: no search with "persist")
+            const double density = (double)c->n / ((double)w.scale_img_x * (double)w.scale_img_y);
+            double best = -1.0;
+            int best_area = 0;
+            for (int cols = 16; cols <= 64; cols *= 2) {
+                if (c->opt_bin_tile > 0 && cols != c->opt_bin_tile) continue;
                 for (int rows = 32; rows <= 128; rows += 16) {
-                    const int nb = ((w.scale_img_x + rows - 1) / rows) * g.nbc;
-                    const long long cost = (long long)((nb + c->n_cus - 1) / c->n_cus) * rows * g.TS;
-                    if ((size_t)(rows + 2 * c->opt_bin_margin) * (g.TS + 2 * c->opt_bin_margin) * 8 > 64 * 1024) continue;
-                    if (best < 0 || cost < best || (cost == best && rows > g.TSR)) { best = cost; g.TSR = rows; }
+                    if (c->opt_bin_tile_rows > 0 && rows != c->opt_bin_tile_rows) continue;
+                    const int d = c->opt_bin_margin > cols / 2 ? cols / 2 : c->opt_bin_margin;
+                    if ((size_t)(rows + 2 * d) * (cols + 2 * d) * 8 > 64 * 1024) continue;
+                    const int nb = ((w.scale_img_x + rows - 1) / rows) * ((w.scale_img_y + cols - 1) / cols);
+                    if (nb > 8192) continue;
+                    const double cost = (double)((nb + c->n_cus - 1) / c->n_cus) * rows * cols * density * 1.7e-3 +
+                                        (double)nb * (rows + 2 * d) * (cols + 2 * d) * 2.3e-6;
+                    if (best < 0 || cost < best * 0.999 || (cost <= best * 1.001 && rows * cols > best_area)) {
+                        best = cost; best_area = rows * cols; g.TS = cols; g.TSR = rows;
+                    }
                 }
             }
         }
+        g.lg = 0;
+        while ((1 << g.lg) < g.TS) ++g.lg;
+        g.nbc = (w.scale_img_y + g.TS - 1) / g.TS;
         const int tmin_ = g.TS < g.TSR ? g.TS : g.TSR;
         g.D = c->opt_bin_margin > tmin_ / 2 ? tmin_ / 2 : c->opt_bin_margin;   // <= 2 x 2 bins per pixel
         g.L = g.TS + 2 * g.D;

@@ -141,7 +141,8 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "binned"       tile-binned LDS scatter inside bf_run: 1 (default) when the slice is dense enough to pay
  *                  for it (fewer than ~12 image pixels per event), 2 whenever possible, 0 never (one
  *                  global atomic per event).  Results are identical.
- *   "bin_tile"     image-tile edge of the binned scatter (16, 32, 64 or 128; default 64).
+ *   "bin_tile"     tile WIDTH of the binned scatter (0 = default: chosen per slice with the height; or 16, 32,
+ *                  64, 128).
  *   "bin_pack_limit"  bits the per-bin accumulator packing may use (default 64).  The counting sort sizes the
  *                  packed count / time-sum fields from the fullest bin; if they do not fit, every event takes the
  *                  exact unpacked path.  Lower values only serve to exercise that fallback in tests.

@@ -778,3 +778,40 @@ def test_large_slices_stay_on_the_binned_path(accel_mod):
         a.close()
     assert runs["binned"] == runs["atomics"] == runs["fallback"] == runs["single"]
     assert runs["binned"][2]["cnt"] > 500000
+
+
+def test_run_to_convergence_with_rotation_and_divergence(oracle_lib, accel_mod):
+    """Scenes with rotation and divergence about the sensor centre, cold start to the loop's own termination: same
+    iteration count as the oracle (+-1) and per-event flow within the SURVEY 8(d) bar (1e-4 relative or 0.02 px/s)."""
+    rng = np.random.default_rng(7)
+    H, W, s = 180, 240, 3
+
+    def scene(n, T, v, rot, div):
+        npts = n // 16
+        pr, pc = rng.uniform(10, H - 10, npts), rng.uniform(10, W - 10, npts)
+        t = np.sort(rng.uniform(0, T, n))
+        pick = rng.integers(0, npts, n)
+        r0, c0 = pr[pick] - H / 2, pc[pick] - W / 2
+        row = pr[pick] + (v[0] + div * r0 - rot * c0) * t
+        col = pc[pick] + (v[1] + div * c0 + rot * r0) * t
+        keep = (row >= 0) & (row < H) & (col >= 0) & (col < W)
+        return dict(fr_x=np.floor(row[keep]).astype(np.int32), fr_y=np.floor(col[keep]).astype(np.int32),
+                    t=(t[keep] * 1e9).astype(np.int64), height=H, width=W)
+
+    for v, rot, div in (((-80.0, 120.0), 3.0, 0.0), ((60.0, -40.0), 0.0, 2.5), ((-50.0, 90.0), -2.0, 1.5)):
+        sl = scene(100000, 0.03, v, rot, div)
+        oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, s)
+        om = oracle_lib.Model()
+        orc, oloop, _ = oc.run(ow, om, res_x=H, res_y=W)
+        o = acc.default_opts()
+        o.res_x, o.res_y = H, W
+        rc, m, info = acc.run(o)
+        assert rc == orc == 0 and abs(info.iterations - oloop.itercount) <= 1
+        u, vv = acc.compute_uv()
+        ou, ov = oc.compute_uv()
+        assert _flow_close(u, ou) and _flow_close(vv, ov), (v, rot, div)
+        if rot:
+            assert abs(m.total_rot - om.total_rot) <= 1e-6 * abs(om.total_rot) + 1e-9 and abs(m.total_rot) > 1e-4
+        if div:
+            assert abs(m.total_div - om.total_div) <= 1e-6 * abs(om.total_div) + 1e-9 and abs(m.total_div) > 1e-4
+        acc.close()

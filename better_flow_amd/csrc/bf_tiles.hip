@@ -111,7 +111,6 @@ __global__ __launch_bounds__(kThreads) void k_tile_scatter(const uint32_t* __res
 __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
     extern __shared__ unsigned long long s_dyn[];
     __shared__ DevState s_st;
-    __shared__ Sums s_red[kThreads / 64];
     __shared__ int s_box[4];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
@@ -167,8 +166,27 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
     __syncthreads();
     const int R = s_st.hot.R, C = s_st.hot.C, P = R * C;
     const int s = a.scale, hsc = s / 2;
+    // A tile's events live in registers for the whole loop (up to kTileUR per thread; a fuller tile streams the rest
+    // from global memory as before): the loop body then touches global memory only to stream that rest.
+    constexpr int kTileUR = 8;
+    uint32_t rxy[kTileUR];
+    int32_t rt[kTileUR];
+    float2 rp[kTileUR];
+#pragma unroll
+    for (int k = 0; k < kTileUR; ++k) {
+        uint32_t i = beg + (uint32_t)(k * kThreads + tid);
+        i = i < end ? i : (end > beg ? beg : 0u);
+        rxy[k] = (end > beg) ? a.xy[i] : 0u;
+        rt[k] = (end > beg) ? a.t[i] : 0;
+        rp[k] = (end > beg) ? a.p[i] : make_float2(0.f, 0.f);
+    }
+    const uint32_t stream_beg = beg + (uint32_t)(kTileUR * kThreads);
+    __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
     const int x_sh = s_st.hot.x_sh, y_sh = s_st.hot.y_sh, wsx = s_st.hot.wsx, wsy = s_st.hot.wsy;
     const int hR = R / 2, hC = C / 2;
+    // pixel index -> row by one multiply: (i + 0.5) / C is at least 0.5 / C away from an integer, the f32 error of
+    // (i + 0.5) * (1 / C) is below 1e-5 for the image sizes that fit the LDS (i < 10^4, C < 10^3)
+    const float rC = 1.0f / (float)(C > 0 ? C : 1);
 
     while (!s_st.hot.done) {
         const WarpParams wp = s_st.hot.wp;
@@ -176,16 +194,12 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
         for (int i = tid; i < P; i += kThreads) { s_ts[i] = 0; s_cnt[i] = 0; }
         __syncthreads();
         // ---- warp (event.h:99-110,164-168) + point scatter (accel_lib.h:151-166) ----
-        for (uint32_t i = beg + tid; i < end; i += kThreads) {
-            const uint32_t v = a.xy[i];
-            const int32_t ti = a.t[i];
-            float2 q = a.p[i];
+        auto one_event = [&](uint32_t v, int32_t ti, float2& q) {
             const uint32_t fx = v & 0xffffu, fy = v >> 16;
             double pr_x = pr_from_p(fx, q.x), pr_y = pr_from_p(fy, q.y);
             if (warp) {
                 double nx, ny;
                 warp_products(wp, pr_x, pr_y, ti, q, nx, ny);
-                a.p[i] = q;
                 pr_x = pr_from_p(fx, q.x);
                 pr_y = pr_from_p(fy, q.y);
             }
@@ -195,11 +209,22 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
                 atomicAdd(&s_ts[X * C + Y], (unsigned long long)(long long)ti);
                 atomicAdd(&s_cnt[X * C + Y], 1u);
             }
+        };
+        // (opaque per iteration: keeps the compiler from hoisting per-event conversions out of the loop into registers)
+#pragma unroll
+        for (int k = 0; k < kTileUR; ++k) asm volatile("" : "+v"(rxy[k]), "+v"(rt[k]));
+#pragma unroll
+        for (int k = 0; k < kTileUR; ++k)
+            if (beg + (uint32_t)(k * kThreads + tid) < end) one_event(rxy[k], rt[k], rp[k]);
+        for (uint32_t i = stream_beg + tid; i < end; i += kThreads) {
+            float2 q = a.p[i];
+            one_event(a.xy[i], a.t[i], q);
+            if (warp) a.p[i] = q;
         }
         __syncthreads();
         // ---- s x s box sum + normalise (accel_lib.h:160-175) ----
         for (int i = tid; i < P; i += kThreads) {
-            const int r = i / C, c = i - r * C;
+            const int r = (int)(((float)i + 0.5f) * rC), c = i - r * C;   // exact: see rC
             long long ts = 0;
             uint32_t cn = 0;
             for (int dr = -hsc; dr <= hsc; ++dr)
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
         Sums sm;
         sums_zero(sm);
         for (int i = tid; i < P; i += kThreads) {
-            const int r = i / C, c = i - r * C;
+            const int r = (int)(((float)i + 0.5f) * rC), c = i - r * C;   // exact: see rC
             const float ctr = s_time[i];
             if (!valid_px(ctr)) continue;
             float gx = 0.f, gy = 0.f;
@@ -249,30 +274,29 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
             sm.sigx += (double)ci * gxd; sm.sigy += (double)ci * gyd;
             sm.sjgx += (double)cj * gxd; sm.sjgy += (double)cj * gyd;
         }
-        sums_wave_reduce(sm);
-        if ((tid & 63) == 0) s_red[tid >> 6] = sm;
-        __syncthreads();
-        if (tid == 0) {
-            Sums t = s_red[0];
-            for (int w = 1; w < kThreads / 64; ++w) sums_add(t, s_red[w]);
-            model_update_local(&s_st, t, nullptr, 1, 0);   // update_accumulators + iteration_step glue + run() control (state in LDS)
-        }
+        const Sums tot = block_reduce_sums<kThreads>(sm, s_rpart, tid);   // DPP wave totals + one LDS hop
+        if (tid == 0)
+            model_update_local(&s_st, tot, nullptr, 1, 0);   // update_accumulators + iteration_step glue + run() control (state in LDS)
         __syncthreads();
     }
     // ---- final state: the last project_4param_reinit of the loop, n for compute_uv ----
     const WarpParams wp = s_st.hot.wp;
     const bool ran = s_st.rc == 0 && s_st.hot.it > 0;
-    for (uint32_t i = beg + tid; i < end; i += kThreads) {
+    auto final_event = [&](uint32_t i, uint32_t v, int32_t ti, float2 q) {
         double nx = 0.0, ny = 0.0;
         if (ran) {
-            const uint32_t v = a.xy[i];
-            float2 q = a.p[i];
             const double pr_x = pr_from_p(v & 0xffffu, q.x), pr_y = pr_from_p(v >> 16, q.y);
-            warp_products(wp, pr_x, pr_y, a.t[i], q, nx, ny);
-            a.p[i] = q;
+            warp_products(wp, pr_x, pr_y, ti, q, nx, ny);
         }
+        a.p[i] = q;
         a.nxny[a.perm[i]] = make_double2(nx, ny);
+    };
+#pragma unroll
+    for (int k = 0; k < kTileUR; ++k) {
+        const uint32_t i = beg + (uint32_t)(k * kThreads + tid);
+        if (i < end) final_event(i, rxy[k], rt[k], rp[k]);
     }
+    for (uint32_t i = stream_beg + tid; i < end; i += kThreads) final_event(i, a.xy[i], a.t[i], a.p[i]);
     if (tid == 0) a.states[tile] = s_st;
 }
 

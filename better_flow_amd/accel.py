@@ -114,7 +114,7 @@ EXPORTS = [
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
     "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
-    "bf_upload_ring_async", "bf_wait_uploads", "bf_projection_img",
+    "bf_upload_ring_async", "bf_wait_uploads", "bf_projection_img", "bf_color_time_img",
 ]
 
 _lib = None
@@ -152,6 +152,7 @@ def load():
         L.bf_local_iteration_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p]
         L.bf_local_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(LocalState)]
         L.bf_projection_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.bf_color_time_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.bf_upload_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                            C.c_uint64]
         L.bf_wait_uploads.argtypes = [C.c_void_p]
@@ -308,6 +309,13 @@ class Accel:
         """EventFile::projection_img (event_file.h:460-515): the (motion-compensated) 8-bit event image."""
         img = np.empty((res_x * scale, res_y * scale), dtype=np.uint8)
         self._chk(self.L.bf_projection_img(self.h, scale, res_x, res_y, 1 if show_final else 0, _ptr(img)))
+        return img
+
+    def color_time_img(self, scale, res_x, res_y, show_final=False):
+        """EventFile::color_time_img (event_file.h:649-747): B, G, R colour-coded time image of the slice."""
+        sc = scale if scale else 11
+        img = np.empty((res_x * sc + sc, res_y * sc + sc, 3), dtype=np.uint8)
+        self._chk(self.L.bf_color_time_img(self.h, scale, res_x, res_y, 1 if show_final else 0, _ptr(img)))
         return img
 
     def local_run(self, res_x=180, res_y=240, max_evaluations=100000):

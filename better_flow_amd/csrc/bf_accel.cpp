@@ -103,6 +103,8 @@ struct bf_ctx {
     uint32_t* d_lplane[2] = {nullptr, nullptr};   // point planes, double buffered
     unsigned long long* d_lscore = nullptr;       // non-zero sum / count of the blurred image
     uint8_t* d_limg = nullptr;                    // project_img
+    void* d_col_planes = nullptr;                 // colour time image: sum cos, sum sin (i64), count (u32) point planes
+    uint8_t* d_col_img = nullptr;                    // ... and its B, G, R bytes
     unsigned long long* h_lscore = nullptr;       // pinned
     bf_local_window lwin;
     bool have_lwin = false;
@@ -545,7 +547,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
@@ -1725,6 +1727,45 @@ int bf_projection_img(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, in
     launch_proj_scale(c->d_limg, (long long)px, c->d_lscore, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(img_out, c->d_limg, px, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+int bf_color_time_img(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final, uint8_t* bgr_out) {
+    if (!c || !bgr_out) return BF_ERR_ARG;
+    if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_color_time_img before bf_upload_events");
+    if (scale == 0) scale = 11;   // event_file.h:650
+    if (scale < 1 || scale > 15) return fail(c, BF_ERR_ARG, "scale must be in 1..15 (got %d)", scale);
+    if (res_x < 1 || res_y < 1) return fail(c, BF_ERR_ARG, "bad sensor size");
+    ColorGeom g;
+    memset(&g, 0, sizeof(g));
+    g.scale = scale; g.show_final = show_final ? 1 : 0;
+    g.mx = scale * res_x; g.my = scale * res_y;
+    g.R = g.mx + scale; g.C = g.my + scale;
+    const size_t px = (size_t)g.R * (size_t)g.C;
+    if (px > c->cap_px) return fail(c, BF_ERR_CAPACITY, "image %d x %d exceeds the image capacity", g.R, g.C);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);   // a pending bf_set_model warp moves the events first
+    if (rc != BF_OK) return rc;
+    if (c->n > 0) {
+        rc = fold_stats(c);
+        if (rc != BF_OK) return rc;
+        g.t_min = c->stats.tmin;                                             // :659-662: t_max starts at 0
+        g.t_range = std::max<long long>(c->stats.tmax, 0) - g.t_min;
+    }
+    g.x_shift = -double(res_x / 2) * double(scale) + double(g.mx) / 2.0;     // :677-678 with x_min = 0, x_max = RES_X
+    g.y_shift = -double(res_y / 2) * double(scale) + double(g.my) / 2.0;
+    if (!c->d_col_planes) {
+        HIP_TRY(c, hipMalloc(&c->d_col_planes, c->cap_px * 20));   // 2 x i64 sums + u32 count per pixel
+        HIP_TRY(c, hipMalloc(&c->d_col_img, c->cap_px * 3));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_col_planes, 0, px * 20, c->stream));
+    const bf_ctx::EvSet& e = c->set[c->cs];
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(c->d_col_planes);
+    launch_color_time(e.xy, e.t, e.p, c->has_noise ? c->d_noise : nullptr, c->n, g,
+                      reinterpret_cast<uint32_t*>(sums + 2 * px), sums, sums + px, c->d_col_img, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(bgr_out, c->d_col_img, px * 3, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BF_OK;
 }

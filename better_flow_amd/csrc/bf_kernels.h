@@ -158,6 +158,16 @@ void launch_proj_count(const uint32_t* xy, const float2* p, const uint8_t* noise
                        int res_y, int show_final, uint32_t* plane, hipStream_t s);
 void launch_proj_scale(uint8_t* img, long long n, const unsigned long long* score, hipStream_t s);
 
+// EventFile::color_time_img (event_file.h:649-747)
+struct ColorGeom {
+    int32_t scale, show_final, mx, my, R, C;   // mx = scale * res_x (:668-669), R = mx + scale (:670-671)
+    long long t_min, t_range;                  // min t; max(t_max, 0) - t_min (:659-662)
+    double x_shift, y_shift;                   // :677-678
+};
+void launch_color_time(const uint32_t* xy, const int32_t* t, const float2* p, const uint8_t* noise, long long n,
+                       const ColorGeom& g, uint32_t* cnt, unsigned long long* pc, unsigned long long* ps, uint8_t* bgr,
+                       hipStream_t s);
+
 void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 
 }  // namespace bf

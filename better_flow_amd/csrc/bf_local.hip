@@ -199,4 +199,124 @@ void launch_proj_scale(uint8_t* img, long long n, const unsigned long long* scor
     hipLaunchKernelGGL(k_proj_scale, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, img, n, score);
 }
 
+// ---------------------------------------------------------------------------------------
+// EventFile::color_time_img (event_file.h:649-747): the colour-coded time image on the full sensor -- hue = mean
+// phase of the events' time within the slice, saturation = coherence of that phase, value = 255.
+// C1 point scatter of (1, cos, sin) at pr * scale + shift (or fr * scale + shift); the reference adds the f32
+// cos / sin in event order, here they are 2^-32 fixed point in 64-bit integer planes, so the image does not depend on
+// the order of the events.  C2 gathers the scale x scale box (== the splat :699-705), forms hue / saturation
+// (:712-723) and converts HSV -> BGR (the 8-bit convention of cv::cvtColor, stated in include/bf_accel.h).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_color_point(const uint32_t* __restrict__ xy, const int32_t* __restrict__ t,
+                                                          const float2* __restrict__ p, const uint8_t* __restrict__ noise,
+                                                          long long n, ColorGeom g, uint32_t* __restrict__ cnt,
+                                                          unsigned long long* __restrict__ pc,
+                                                          unsigned long long* __restrict__ ps) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    if (noise && noise[i]) return;                                        // :679
+    const uint32_t v = xy[i];
+    const uint32_t fx = v & 0xffffu, fy = v >> 16;
+    int X, Y;
+    if (g.show_final) {                                                   // :684-687
+        X = trunc_x86((double)(fx * (uint32_t)g.scale) + g.x_shift);
+        Y = trunc_x86((double)(fy * (uint32_t)g.scale) + g.y_shift);
+    } else {                                                              // :681-682
+        const float2 q = p[i];
+        X = trunc_x86(pr_from_p(fx, q.x) * (double)g.scale + g.x_shift);
+        Y = trunc_x86(pr_from_p(fy, q.y) * (double)g.scale + g.y_shift);
+    }
+    if ((X >= g.mx) || (X < 0) || (Y >= g.my) || (Y < 0)) return;         // :689-692
+    // :694 float angle = 2 * 3.14 * (double(e.t - t_min) / double(t_max - t_min))
+    const double num = (double)((long long)t[i] - g.t_min);
+    const double ratio = g.t_range > 0 ? num / (double)g.t_range : 0.0;
+    const float angle = (float)(2 * 3.14 * ratio);
+    const size_t at = (size_t)X * (size_t)g.C + (size_t)Y;
+    atomicAdd(&cnt[at], 1u);
+    atomicAdd(&pc[at], (unsigned long long)llrint(cos((double)angle) * 4294967296.0));   // two's complement sums
+    atomicAdd(&ps[at], (unsigned long long)llrint(sin((double)angle) * 4294967296.0));
+}
+
+__device__ __forceinline__ uint8_t unit_to_u8(float x) {
+    const float v = x * 255.0f;
+    return (uint8_t)(v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (int)rintf(v)));
+}
+
+// HSV (H in [0, 180), S, V in [0, 255]) -> B, G, R; float32, no contraction.
+__device__ __forceinline__ void hsv_to_bgr_u8(int H, int S, int V, uint8_t* bgr) {
+    const float s = (float)S * (1.0f / 255.0f), v = (float)V * (1.0f / 255.0f);
+    float h = (float)H * (6.0f / 180.0f);
+    int sector = (int)floorf(h);
+    h -= (float)sector;
+    sector = ((sector % 6) + 6) % 6;
+    float tab[4];
+    tab[0] = v;
+    tab[1] = v * (1.0f - s);
+    tab[2] = v * (1.0f - s * h);
+    tab[3] = v * (1.0f - s * (1.0f - h));
+    int ib, ig, ir;
+    switch (sector) {
+        case 0: ib = 1; ig = 3; ir = 0; break;
+        case 1: ib = 1; ig = 0; ir = 2; break;
+        case 2: ib = 3; ig = 0; ir = 1; break;
+        case 3: ib = 0; ig = 2; ir = 1; break;
+        case 4: ib = 0; ig = 1; ir = 3; break;
+        default: ib = 2; ig = 1; ir = 0; break;
+    }
+    float b = tab[0], gg = tab[0], r = tab[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        b = ib == k ? tab[k] : b;
+        gg = ig == k ? tab[k] : gg;
+        r = ir == k ? tab[k] : r;
+    }
+    bgr[0] = unit_to_u8(b); bgr[1] = unit_to_u8(gg); bgr[2] = unit_to_u8(r);
+}
+
+__global__ __launch_bounds__(kThreads) void k_color_final(const uint32_t* __restrict__ cnt,
+                                                          const unsigned long long* __restrict__ pc,
+                                                          const unsigned long long* __restrict__ ps, ColorGeom g,
+                                                          uint8_t* __restrict__ bgr) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= (long long)g.R * g.C) return;
+    const int jx = (int)(i / g.C), jy = (int)(i % g.C);
+    // a point at (X, Y) covers rows X .. X + 2 (scale / 2), so pixel (jx, jy) gathers the box ending at itself
+    const int bw = 2 * (g.scale / 2) + 1;
+    unsigned int c = 0;
+    long long sc = 0, ss = 0;
+    for (int a = jx - bw + 1; a <= jx; ++a) {
+        if (a < 0) continue;
+        for (int b = jy - bw + 1; b <= jy; ++b) {
+            if (b < 0) continue;
+            const size_t at = (size_t)a * (size_t)g.C + (size_t)b;
+            c += cnt[at]; sc += (long long)pc[at]; ss += (long long)ps[at];
+        }
+    }
+    uint8_t out[3] = {0, 0, 0};                                           // HSV (0, 0, 0) -> black
+    if (c >= 1) {                                                         // :710
+        const float fc = (float)c;
+        const float vx = (float)((double)sc * (1.0 / 4294967296.0)) / fc;   // :712-713
+        const float vy = (float)((double)ss * (1.0 / 4294967296.0)) / fc;
+        const double speed = hypot((double)vx, (double)vy);               // :715
+        double angle = 0;
+        if (speed != 0) angle = (atan2((double)vy, (double)vx) + 3.1416) * 180 / 3.1416;   // :717-718
+        const int H = (int)(unsigned char)trunc_x86(angle / 2);           // :720-722 (double -> uchar)
+        const int S = (int)(unsigned char)trunc_x86(speed * 255);
+        hsv_to_bgr_u8(H, S, 255, out);
+    }
+    bgr[3 * i + 0] = out[0]; bgr[3 * i + 1] = out[1]; bgr[3 * i + 2] = out[2];
+}
+
+void launch_color_time(const uint32_t* xy, const int32_t* t, const float2* p, const uint8_t* noise, long long n,
+                       const ColorGeom& g, uint32_t* cnt, unsigned long long* pc, unsigned long long* ps, uint8_t* bgr,
+                       hipStream_t s) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_color_point, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, xy, t, p,
+                           noise, n, g, cnt, pc, ps);
+    const long long px = (long long)g.R * g.C;
+    hipLaunchKernelGGL(k_color_final, dim3((unsigned)((px + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, cnt, pc, ps, g,
+                       bgr);
+}
+
+
 }  // namespace bf

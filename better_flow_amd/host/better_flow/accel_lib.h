@@ -211,6 +211,16 @@ public:
         return img;
     }
 
+    // EventFile::color_time_img (event_file.h:649-747) of the staged slice: B, G, R bytes, (RES_X * scale + scale) x
+    // (RES_Y * scale + scale) pixels; hue = phase of the events' time in the slice
+    std::vector<uint8_t> color_time_img(int scale, bool show_final, int *rows, int *cols) {
+        const int sc = scale ? scale : 11;
+        *rows = RES_X * sc + sc; *cols = RES_Y * sc + sc;
+        std::vector<uint8_t> img((size_t)*rows * (size_t)*cols * 3);
+        check(bf_color_time_img(ctx, scale, RES_X, RES_Y, show_final ? 1 : 0, img.data()), "color_time_img");
+        return img;
+    }
+
     // OptimizerLocal on the device (optimizer_sampler.h:29-48; optimizer_sampler.cpp:4-38,120-153)
     void local_set_window(int scale, int wsz, int c_fr_x, int c_fr_y, long long c_t, bf_local_window *w) {
         check(bf_local_set_window(ctx, scale, wsz, c_fr_x, c_fr_y, c_t, w), "local_set_window");

@@ -3,19 +3,28 @@
 // slice warm-started from the previous model ("STM"), accumulation of processed events.
 // Same public interface; the optimizer it drives runs on the MI355X.
 //
-// --img writes one PGM per slice with the reference's two projection images (events as recorded | motion
-// compensated); not reproduced: the colour / arrow composition and --video (dvs_flow.h:256-335, OpenCV drawing) and
-// the unbounded `motion_memory` copies of every slice (:239-242): only the per-slice summary
-// the reference prints (:245-252) is kept.
+// --img / --video render the reference's per-slice frame (dvs_flow.h:256-335): the 2 x 2 mosaic of the projection
+// images and colour-coded time images, raw on top, motion compensated below -- the four tiles are computed on the
+// device, composition and containers are in better_flow/frame_writer.h (PPM / uncompressed AVI, statistics in a
+// side-car text file instead of cv::putText).  Not reproduced: the unbounded `motion_memory` copies of every slice
+// (:239-242): only the per-slice summary the reference prints (:245-252) is kept.
 #ifndef BF_HOST_DVS_FLOW_H
 #define BF_HOST_DVS_FLOW_H
 
 #include <better_flow/common.h>
 #include <better_flow/event.h>
 #include <better_flow/event_file.h>
+#include <better_flow/frame_writer.h>
 #include <better_flow/optimizer_rolling.h>
 
 #include <queue>
+
+inline std::string f2str(double v) {   // dvs_flow.h:14-19, as written ("1.05" prints as "1.5")
+    int base = int(v * 100);
+    std::string ret = std::to_string(base / 100) + ".";
+    ret += std::to_string(std::abs(base) % 100);
+    return ret;
+}
 
 template <size_t MAX_SZ, sll SPAN> class DVS_flow {
 public:
@@ -42,6 +51,8 @@ protected:
     int scale;
     bool generate_video;
     int video_fps;
+    std::string video_name;
+    bf::AviWriter outputvideo;
     bool generate_pictures;
     std::string img_prefix;
     bool stm_disable;
@@ -64,10 +75,10 @@ public:
     void set_manual_mode(bool val = true) { this->manual_mode = val; }
     void set_max_iter(int val = -1) { this->max_iter = val; }
     void set_scale(int val = 3) { this->scale = val; }
-    void set_generate_video(bool val = true, std::string = "out.avi", int framerate = 30) {
+    void set_generate_video(bool val = true, std::string name = "out.avi", int framerate = 30) {   // :115-129
         this->video_fps = framerate;
         this->generate_video = val;
-        if (val) std::cerr << "--video: frame rendering is outside the motion-compensation path of this build\n";
+        this->video_name = name;   // opened with the first frame, at the size of the mosaic
     }
     void set_generate_pictures(bool val = true, std::string img_prefix_ = "./") {
         this->generate_pictures = val;
@@ -113,6 +124,9 @@ template <size_t MAX_SZ, sll SPAN> void DVS_flow<MAX_SZ, SPAN>::recompute() {   
         slice_start_time = (this->current_slice_time > (ull)SPAN) ? this->current_slice_time - SPAN : 0;
     }
 
+    if (this->generate_video || this->generate_pictures)   // the frames are rendered at scale 3 whatever `scale` is
+        (void)bf::DeviceContext::get((long long)MAX_SZ, 3 * RES_X + 3, 3 * RES_Y + 3);
+
     LinearEventPtrs e_ptrs;
     e_ptrs.reserve(this->ev_buffer.size());
     for (auto &e : this->ev_buffer) e_ptrs.push_back(&e);
@@ -131,21 +145,38 @@ template <size_t MAX_SZ, sll SPAN> void DVS_flow<MAX_SZ, SPAN>::recompute() {   
         this->last_model = optimizer.get_model();
         // :233-235 "compute the actual u and v after minimizations are done" (on the device)
         optimizer.fetch_uv();
-        if (this->generate_pictures) {
-            // dvs_flow.h:256-259,324-326: one frame per slice from EventFile::projection_img(ev_buffer, 3, ...).  The
-            // reference composes those with colour-coded time images and flow arrows into a JPEG through OpenCV; here
-            // the two grey images -- events as recorded | motion compensated -- are written side by side as a PGM.
-            bf::Image2D<uint8_t> raw = optimizer.get_projection_img(3, true), comp = optimizer.get_projection_img(3, false);
-            const std::string fname = this->img_prefix + "/frame_" + std::to_string(this->frame_count++) + ".pgm";
-            if (FILE *f = std::fopen(fname.c_str(), "wb")) {
-                std::fprintf(f, "P5\n%d %d\n255\n", raw.cols + comp.cols, raw.rows);
-                for (int r = 0; r < raw.rows; ++r) {
-                    std::fwrite(raw.ptr(r), 1, (size_t)raw.cols, f);
-                    std::fwrite(comp.ptr(r), 1, (size_t)comp.cols, f);
+        if (this->generate_video || this->generate_pictures) {   // :256-335
+            const int fr = RES_X * 3, fc = RES_Y * 3;
+            bf::Image2D<uint8_t> pr_f = optimizer.get_projection_img(3, false), pr_t = optimizer.get_projection_img(3, true);
+            int cr = 0, cc = 0;
+            bf::FrameBGR col_f(0, 0), col_t(0, 0);
+            col_f.px = optimizer.get_color_time_img(3, false, &cr, &cc); col_f.rows = cr; col_f.cols = cc;
+            col_t.px = optimizer.get_color_time_img(3, true, &cr, &cc); col_t.rows = cr; col_t.cols = cc;
+            const bf::FrameBGR frame = bf::mosaic_2x2(
+                bf::resize_bilinear(bf::gray_to_bgr(pr_t.ptr(0), pr_t.rows, pr_t.cols), fr, fc), bf::resize_bilinear(col_t, fr, fc),
+                bf::resize_bilinear(bf::gray_to_bgr(pr_f.ptr(0), pr_f.rows, pr_f.cols), fr, fc), bf::resize_bilinear(col_f, fr, fc));
+            if (this->generate_pictures) {
+                const std::string base = this->img_prefix + "/frame_" + std::to_string(this->frame_count);
+                if (!bf::write_ppm(base + ".ppm", frame) && !this->quiet) std::cerr << "cannot write " << base << ".ppm\n";
+                if (FILE *f = std::fopen((base + ".txt").c_str(), "w")) {   // the cv::putText lines, :277-315
+                    const double slice_time_width = double(this->time_diff) / 1000000000.0;
+                    const double speedup = double(this->on_time_change) / double(this->time_diff);
+                    const ObjectModel &m = this->last_model;
+                    std::fprintf(f, "timestamp: %s\n%%realtime: %s\nTime diff (new): %s\nEvents: %zu\nNew events: %lld\n",
+                                 f2str(double(this->current_slice_time) / 1000000000.0).c_str(), f2str(speedup).c_str(),
+                                 f2str(slice_time_width).c_str(), (size_t)this->ev_buffer.size(), (long long)this->event_diff);
+                    std::fprintf(f, "Model:\nC: (%s, %s)\nShift: (%s, %s); total: (%s, %s)\nRot: %s total: %s\nDiv: %s total: %s\n",
+                                 f2str(m.cx).c_str(), f2str(m.cy).c_str(), f2str(m.dx).c_str(), f2str(m.dy).c_str(),
+                                 f2str(m.total_dx).c_str(), f2str(m.total_dy).c_str(), f2str(m.rot).c_str(),
+                                 f2str(m.total_rot).c_str(), f2str(m.div).c_str(), f2str(m.total_div).c_str());
+                    std::fclose(f);
                 }
-                std::fclose(f);
-            } else if (!this->quiet) {
-                std::cerr << "cannot write " << fname << "\n";
+                this->frame_count++;
+            }
+            if (this->generate_video) {
+                if (!outputvideo.is_open() && !outputvideo.open(this->video_name, frame.rows, frame.cols, this->video_fps))
+                    std::cout << "Could not open the output video for write" << std::endl;   // :329-331
+                if (outputvideo.is_open()) outputvideo.write(frame);
             }
         }
         slices_done++;

@@ -117,6 +117,12 @@ public:
         return accel.projection_img(sc, show_final);
     }
 
+    // EventFile::color_time_img of this optimizer's events (event_file.h:649-747)
+    std::vector<uint8_t> get_color_time_img(int sc, bool show_final, int *rows, int *cols) {
+        this->stage();
+        return accel.color_time_img(sc, show_final, rows, cols);
+    }
+
     const bf_run_info &get_run_info() const { return last_info; }
     int get_scale_img_x() { this->stage(); return scale_img_x; }
     int get_scale_img_y() { this->stage(); return scale_img_y; }

@@ -277,6 +277,24 @@ int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
 int bf_projection_img(bf_ctx *ctx, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
                       uint8_t *img_out);
 
+/* EventFile::color_time_img(events, scale, show_final) (event_file.h:649-747): the colour-coded time image of
+ * the non-noise events on the full sensor, (res_x * scale + scale) x (res_y * scale + scale) pixels of B, G, R
+ * bytes (3 bytes per pixel, row-major).  Every event adds (1, cos a, sin a) to the scale x scale pixels it
+ * covers, a = float(2 * 3.14 * (t - t_min) / (t_max - t_min)) with t_min = min t and t_max = max(0, max t)
+ * (:659-662; a = 0 when they are equal -- the reference divides 0 by 0 there).  Per covered pixel: hue =
+ * uchar((atan2(mean sin, mean cos) + 3.1416) * 180 / 3.1416 / 2), saturation = uchar(255 * |mean|), value = 255
+ * (:712-723); uncovered pixels are black.  Positions are pr (compensated) or, with show_final != 0, the sensor
+ * coordinates (:684-687).  scale = 0 means 11 (:650).
+ * Two things are this build's own, both stated here: (i) the reference adds the f32 cos / sin in event order,
+ * this build adds them as 2^-32 fixed point integers, so the image does not depend on event order and agrees
+ * with the f32 sums to their own rounding error (~1e-7) before the 8-bit quantisation; (ii) HSV -> BGR follows the 8-bit convention of
+ * cv::cvtColor (H in [0, 180), S and V in [0, 255]) in float32: h = H * (6 / 180), sector = floor(h), f = h -
+ * sector, s = S / 255, v = V / 255, p = v (1 - s), q = v (1 - s f), t = v (1 - s (1 - f)), (r, g, b) = (v,t,p),
+ * (q,v,p), (p,v,t), (p,q,v), (t,p,v), (v,p,q) for sectors 0..5, each channel rint(255 x) -- the reference's
+ * cv::cvtColor comes from an un-versioned OpenCV (parity unpinned for that stage). */
+int bf_color_time_img(bf_ctx *ctx, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
+                      uint8_t *bgr_out);
+
 /* The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays event ring kept
  * in pinned memory (bf_host_alloc) -- no AoS -> SoA repack (accel_lib.h:91-99) and no per-slice allocation on
  * the host.  The slice is the n events starting at ring index `first` (wrapping at `cap`), stored oldest ->

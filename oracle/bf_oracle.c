@@ -556,3 +556,76 @@ void bfo_projection_img(const bfo_cloud *ev, int32_t scale, int32_t res_x, int32
         img[k] = (uint8_t)r;
     }
 }
+
+/* ---- EventFile::color_time_img (event_file.h:649-747) ---- */
+static uint8_t unit_to_u8(float x) {
+    const float v = x * 255.0f;
+    return (uint8_t)(v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (int)lrintf(v)));
+}
+
+void bfo_hsv_to_bgr_u8(int32_t H, int32_t S, int32_t V, uint8_t *bgr) {
+    static const int map[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    const float s = (float)S * (1.0f / 255.0f), v = (float)V * (1.0f / 255.0f);
+    float h = (float)H * (6.0f / 180.0f);
+    int sector = (int)floorf(h);
+    h -= (float)sector;
+    sector = ((sector % 6) + 6) % 6;
+    float tab[4];
+    tab[0] = v;
+    tab[1] = v * (1.0f - s);
+    tab[2] = v * (1.0f - s * h);
+    tab[3] = v * (1.0f - s * (1.0f - h));
+    bgr[0] = unit_to_u8(tab[map[sector][0]]);
+    bgr[1] = unit_to_u8(tab[map[sector][1]]);
+    bgr[2] = unit_to_u8(tab[map[sector][2]]);
+}
+
+void bfo_color_time_img(const bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
+                        uint8_t *bgr, float *scratch) {
+    if (scale == 0) scale = 11;                                         /* :650 */
+    uint64_t t_min = (uint64_t)LLONG_MAX, t_max = 0;                    /* :652 */
+    for (int64_t i = 0; i < ev->n; ++i) {                               /* :661-664 */
+        if (ev->t[i] < (int64_t)t_min) t_min = (uint64_t)ev->t[i];
+        if (ev->t[i] > (int64_t)t_max) t_max = (uint64_t)ev->t[i];
+    }
+    const int32_t mx = scale * res_x, my = scale * res_y;               /* :666-676 with the fixed full-sensor box */
+    const int32_t R = mx + scale, C = my + scale;
+    const size_t px = (size_t)R * (size_t)C;
+    float *sum_c = scratch, *sum_s = scratch + px, *cnt = scratch + 2 * px;
+    for (size_t k = 0; k < 3 * px; ++k) scratch[k] = 0.0f;
+    const double x_shift = -(double)(res_x / 2) * (double)scale + (double)mx / 2.0;   /* :677-678 */
+    const double y_shift = -(double)(res_y / 2) * (double)scale + (double)my / 2.0;
+    for (int64_t i = 0; i < ev->n; ++i) {
+        if (ev->noise[i]) continue;                                     /* :679 */
+        int32_t x = trunc_to_int_x86(ev->pr_x[i] * scale + x_shift);    /* :681-682 */
+        int32_t y = trunc_to_int_x86(ev->pr_y[i] * scale + y_shift);
+        if (show_final) {                                               /* :684-687, unsigned product */
+            x = trunc_to_int_x86((double)((uint32_t)ev->fr_x[i] * (uint32_t)scale) + x_shift);
+            y = trunc_to_int_x86((double)((uint32_t)ev->fr_y[i] * (uint32_t)scale) + y_shift);
+        }
+        if ((x >= mx) || (x < 0) || (y >= my) || (y < 0)) continue;     /* :689-692 */
+        const uint64_t num = (uint64_t)ev->t[i] - t_min, den = t_max - t_min;   /* unsigned arithmetic, :694 */
+        const double ratio = den != 0 ? (double)num / (double)den : 0.0;
+        const float angle = (float)(2 * 3.14 * ratio);
+        x += scale / 2;                                                 /* :696-697 */
+        y += scale / 2;
+        for (int32_t jx = x - scale / 2; jx <= x + scale / 2; ++jx)     /* :699-705 */
+            for (int32_t jy = y - scale / 2; jy <= y + scale / 2; ++jy) {
+                const size_t at = (size_t)jx * C + jy;
+                sum_c[at] = (float)((double)sum_c[at] + cos((double)angle));
+                sum_s[at] = (float)((double)sum_s[at] + sin((double)angle));
+                cnt[at] = cnt[at] + 1;
+            }
+    }
+    for (size_t k = 0; k < px; ++k) {                                   /* :708-725 */
+        uint8_t *o = bgr + 3 * k;
+        if (cnt[k] < 1) { o[0] = o[1] = o[2] = 0; continue; }            /* HSV (0,0,0) -> black */
+        const float vx = sum_c[k] / cnt[k], vy = sum_s[k] / cnt[k];
+        const double speed = hypot((double)vx, (double)vy);
+        double angle = 0;
+        if (speed != 0) angle = (atan2((double)vy, (double)vx) + 3.1416) * 180 / 3.1416;
+        const int32_t H = (int32_t)(unsigned char)trunc_to_int_x86(angle / 2);
+        const int32_t S = (int32_t)(unsigned char)trunc_to_int_x86(speed * 255);
+        bfo_hsv_to_bgr_u8(H, S, 255, o);
+    }
+}

@@ -182,6 +182,17 @@ int bfo_local_run(bfo_cloud *ev, const bfo_local_window *w, int32_t res_x, int32
 void bfo_projection_img(const bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
                         uint8_t *img, uint8_t *scratch);
 
+/* ---- Colour-coded time image: EventFile::color_time_img (event_file.h:649-747) ----
+ * (res_x*scale + scale) x (res_y*scale + scale) pixels of B, G, R bytes.  Restated as written: f32 running sums
+ * of cos / sin of the f32 phase in EVENT ORDER (the unqualified cos / sin / hypot / atan2 calls are taken as the
+ * double overloads), f32 means, hue / saturation through double -> uchar truncation, value 255.  t_max == t_min
+ * (0 / 0 in the reference) is taken as phase 0.  The last step, cv::cvtColor(HSV2BGR), is third-party
+ * arithmetic of an un-versioned OpenCV: PARITY UNPINNED; restated as the float formula given in
+ * include/bf_accel.h (bf_color_time_img).  scratch: 3 floats per pixel. */
+void bfo_color_time_img(const bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final,
+                        uint8_t *bgr, float *scratch);
+void bfo_hsv_to_bgr_u8(int32_t H, int32_t S, int32_t V, uint8_t *bgr);
+
 #ifdef __cplusplus
 }
 #endif

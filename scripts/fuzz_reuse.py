@@ -86,6 +86,8 @@ def apply(a, op, sl):
         sc, img = a.local_iteration_step(op[1], op[2], want_img=True); return (np.float64(sc).tobytes(), img.tobytes())
     if k == "proj":
         return (a.projection_img(op[1], sl["H"], sl["W"], show_final=op[2]).tobytes(),)
+    if k == "color":
+        return (a.color_time_img(op[1], sl["H"], sl["W"], show_final=op[2]).tobytes(),)
     if k == "tiles":
         models, infos = a.run_tiles(op[1], op[1], 3, (sl["H"], sl["W"]), (sl["H"] // op[1], sl["W"] // op[1]), 64, max_iter=op[2])
         return tuple(canon(m) for m in models) + tuple((i.rc, i.iterations) for i in infos)
@@ -107,7 +109,7 @@ for step in range(steps):
     choices = ["cloud", "opt"]
     if state["cloud"]:
         choices += ["project", "img", "run", "run", "model", "uv", "writeout", "proj", "tiles"]
-    choices += ["lwin", "proj"]
+    choices += ["lwin", "proj", "color"]
     if state["lwin"]:
         choices += ["lstep", "lstep"]
     k = str(rng.choice(choices))
@@ -139,6 +141,8 @@ for step in range(steps):
         op = ("lstep", float(rng.normal(0, .4)), float(rng.normal(0, .4)))
     elif k == "proj":
         op = ("proj", int(rng.choice([1, 3, 5])), bool(rng.integers(0, 2)))
+    elif k == "color":
+        op = ("color", int(rng.choice([1, 2, 3])), bool(rng.integers(0, 2)))
     elif k == "tiles":
         op = ("tiles", int(rng.choice([2, 4])), int(rng.choice([5, 20])))
     else:
@@ -161,7 +165,7 @@ for step in range(steps):
     checks += 1
     if got != want:
         bad += 1
-        print("step %d: MISMATCH after %s; ops since upload (%d): %s" % (step, op[0], len(script), [(o_[0],) + tuple(o_[1:3]) if o_[0] in ("opt", "cloud", "run", "proj", "lwin") else o_[0] for o_ in script]))
+        print("step %d: MISMATCH after %s; ops since upload (%d): %s" % (step, op[0], len(script), [(o_[0],) + tuple(o_[1:3]) if o_[0] in ("opt", "cloud", "run", "proj", "color", "lwin") else o_[0] for o_ in script]))
         if isinstance(got, tuple) and isinstance(want, tuple) and len(got) == len(want):
             print("    differing fields:", [i for i in range(len(got)) if got[i] != want[i]], "of", len(got))
         else:

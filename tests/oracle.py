@@ -201,6 +201,15 @@ class Cloud:
                                  C.c_int32(1 if show_final else 0), _p(img, C.c_uint8), _p(scratch, C.c_uint8))
         return img
 
+    # EventFile::color_time_img (event_file.h:649-747)
+    def color_time_img(self, scale, res_x, res_y, show_final=False):
+        sc = scale if scale else 11
+        img = np.empty((res_x * sc + sc, res_y * sc + sc, 3), dtype=np.uint8)
+        scratch = np.empty(img.shape, dtype=np.float32)
+        lib().bfo_color_time_img(C.byref(self.c), C.c_int32(scale), C.c_int32(res_x), C.c_int32(res_y),
+                                 C.c_int32(1 if show_final else 0), _p(img, C.c_uint8), _p(scratch, C.c_float))
+        return img
+
     def compute_uv(self):
         u = np.empty(self.n)
         v = np.empty(self.n)

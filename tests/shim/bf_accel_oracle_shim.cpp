@@ -239,4 +239,11 @@ int bf_projection_img(bf_ctx *c, int32_t scale, int32_t res_x, int32_t res_y, in
     return BF_OK;
 }
 
+int bf_color_time_img(bf_ctx *c, int32_t scale, int32_t res_x, int32_t res_y, int32_t show_final, uint8_t *bgr_out) {
+    const int32_t sc = scale ? scale : 11;
+    std::vector<float> scratch((size_t)(res_x * sc + sc) * (size_t)(res_y * sc + sc) * 3);
+    bfo_color_time_img(&c->cloud, scale, res_x, res_y, show_final, bgr_out, scratch.data());
+    return BF_OK;
+}
+
 }  // extern "C"

@@ -257,43 +257,95 @@ def test_stream_flow_equals_dvs_flow_gpu(events_txt, tmp_path):
     _check_stream_output(out)
 
 
-# ---- --img: one frame per slice (events as recorded | motion compensated) ----
+# ---- --img / --video: one 2 x 2 frame per slice (raw grey | raw colour-time / compensated grey | compensated colour-time) ----
 
-def _read_pgm(path):
+def _read_ppm(path):
     raw = open(path, "rb").read()
     magic, dims, maxv, rest = raw.split(b"\n", 3)
-    assert magic == b"P5" and maxv == b"255"
+    assert magic == b"P6" and maxv == b"255"
     w, h = (int(x) for x in dims.split())
-    return np.frombuffer(rest, dtype=np.uint8, count=w * h).reshape(h, w)
+    return np.frombuffer(rest, dtype=np.uint8, count=w * h * 3).reshape(h, w, 3)   # R, G, B
 
 
-def _frames(exe, path, tmp_path, tag):
+def _read_avi(path):
+    """Minimal reader for the uncompressed AVI the host writes: returns (fps, [frames as rows x cols x 3 RGB])."""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"AVI " and struct.unpack("<I", b[4:8])[0] == len(b) - 8
+    us_per_frame, = struct.unpack("<I", b[32:36])
+    n_frames, = struct.unpack("<I", b[48:52])
+    w, h = struct.unpack("<II", b[64:72])
+    assert b[112:116] == b"DIB "
+    movi = b.index(b"movi")
+    stride = (3 * w + 3) & ~3
+    frames, pos = [], movi + 4
+    for _ in range(n_frames):
+        assert b[pos:pos + 4] == b"00db" and struct.unpack("<I", b[pos + 4:pos + 8])[0] == stride * h
+        f = np.frombuffer(b, dtype=np.uint8, count=stride * h, offset=pos + 8).reshape(h, stride)[:, :3 * w].reshape(h, w, 3)
+        frames.append(f[::-1, :, ::-1])   # bottom-up B G R -> top-down R G B
+        pos += 8 + stride * h
+    assert b[pos:pos + 4] == b"idx1" and struct.unpack("<I", b[pos + 4:pos + 8])[0] == 16 * n_frames
+    return round(1e6 / us_per_frame), frames
+
+
+def _frames(exe, path, tmp_path, tag, video=False):
     d = tmp_path / ("frames_" + tag)
     d.mkdir()
-    so = run_cli(exe, ["--img", "--img-prefix", str(d), path], str(tmp_path))
+    extra = ["--video", "--video-name", str(d / "out.avi"), "--video-fps=25"] if video else []
+    so = run_cli(exe, ["--img", "--img-prefix", str(d)] + extra + [path], str(tmp_path))
     n = parse_summary(so)[0]
-    frames = [_read_pgm(str(d / ("frame_%d.pgm" % k))) for k in range(n)]
-    return n, frames
+    frames = [_read_ppm(str(d / ("frame_%d.ppm" % k))) for k in range(n)]
+    texts = [open(str(d / ("frame_%d.txt" % k))).read() for k in range(n)]
+    return n, frames, texts, (_read_avi(str(d / "out.avi")) if video else None)
+
+
+def _tiles(f):
+    R, C = 3 * 180, 3 * 240
+    return f[:R, :C], f[:R, C:], f[R:, :C], f[R:, C:]   # raw grey, raw colour, compensated grey, compensated colour
 
 
 def test_cli_img_frames_oracle(oracle_cli, events_txt, tmp_path):
     path, _ = events_txt
-    n, frames = _frames(oracle_cli, path, tmp_path, "o")
-    assert n == 4 and all(f.shape == (3 * 180, 2 * 3 * 240) for f in frames)
+    n, frames, texts, avi = _frames(oracle_cli, path, tmp_path, "o", video=True)
+    assert n == 4 and all(f.shape == (2 * 3 * 180, 2 * 3 * 240, 3) for f in frames)
     for f in frames:
-        raw, comp = f[:, :720], f[:, 720:]
+        raw, raw_c, comp, comp_c = _tiles(f)
+        assert (raw[..., 0] == raw[..., 1]).all() and (raw[..., 1] == raw[..., 2]).all()      # grey tiles
+        raw, comp = raw[..., 0], comp[..., 0]
         assert (comp > 0).sum() < 0.75 * (raw > 0).sum()        # compensation sharpens the image
         assert abs(float(raw[raw > 0].mean()) - 127) < 12       # brightness normalised to a non-zero mean of 127
+        # colour tiles: value 255 wherever there are events, black elsewhere; the lit area tracks the grey tile's (the
+        # 543 x 723 -> 540 x 720 bilinear resize adds a fringe of partly lit pixels around every block)
+        for grey, col in ((raw, raw_c), (comp, comp_c)):
+            lit = col.any(axis=2)
+            assert 0.9 * (grey > 0).sum() < lit.sum() < 1.6 * (grey > 0).sum()
+            assert (col[lit].max(axis=1) >= 250).mean() > 0.2
+    for t in texts:
+        lines = t.splitlines()
+        assert lines[0].startswith("timestamp: ") and lines[3].startswith("Events: ") and lines[5] == "Model:"
+        assert lines[6].startswith("C: (") and lines[-1].startswith("Div: ")
+    fps, vf = avi
+    assert fps == 25 and len(vf) == n
+    for a, b in zip(vf, frames):
+        assert np.array_equal(a, b)                              # the video holds the same frames
 
 
 @pytest.mark.gpu
 def test_cli_img_frames_gpu_match_oracle(oracle_cli, events_txt, tmp_path):
     path, _ = events_txt
     gpu_cli = os.path.join(ROOT, "better_flow_amd", "host", "bf_motion_compensator")
-    no, fo = _frames(oracle_cli, path, tmp_path, "o")
-    ng, fg = _frames(gpu_cli, path, tmp_path, "g")
-    assert no == ng
-    for a, b in zip(fo, fg):
-        assert np.array_equal(a[:, :720], b[:, :720])           # raw halves: identical
-        # compensated halves: the two models agree to ~1e-6, a handful of events may cross a pixel boundary
-        assert (a[:, 720:] != b[:, 720:]).mean() < 0.01
+    no, fo, to, _ = _frames(oracle_cli, path, tmp_path, "o")
+    ng, fg, tg, avi = _frames(gpu_cli, path, tmp_path, "g", video=True)
+    assert no == ng and len(avi[1]) == ng
+    for a, b, v in zip(fo, fg, avi[1]):
+        ra, ca, pa, qa = _tiles(a)
+        rb, cb, pb, qb = _tiles(b)
+        assert np.array_equal(ra, rb)                            # raw grey tiles: identical
+        # compensated grey: the two models agree to ~1e-6, a handful of events may cross a pixel boundary
+        assert (pa != pb).mean() < 0.01
+        # colour tiles: same lit pixels (raw), hue / saturation on an 8-bit boundary may differ (f32 vs fixed-point sums)
+        assert np.array_equal(ca.any(axis=2), cb.any(axis=2))
+        assert (np.abs(ca.astype(int) - cb.astype(int)).max(axis=2) > 1).mean() < 0.01
+        assert (np.abs(qa.astype(int) - qb.astype(int)).max(axis=2) > 1).mean() < 0.02
+        assert np.array_equal(v, b)
+    assert [t.splitlines()[3:5] for t in to] == [t.splitlines()[3:5] for t in tg]   # Events / New events lines

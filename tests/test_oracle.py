@@ -307,3 +307,106 @@ def test_projection_img_against_numpy(oracle_lib):
         want = np.minimum(np.rint(ref.astype(np.float32) * a), 255).astype(np.uint8)
         assert np.array_equal(img, want), s
         assert abs(float(img[img > 0].mean()) - 127.0) < 8.0
+
+
+def _np_hsv_to_bgr(H, S, V):
+    """The HSV -> BGR convention stated in include/bf_accel.h, vectorised in float32."""
+    h = H.astype(np.float32) * np.float32(6.0 / 180.0)
+    sec = np.floor(h).astype(np.int64)
+    f = h - sec.astype(np.float32)
+    sec %= 6
+    s = S.astype(np.float32) * np.float32(1.0 / 255.0)
+    v = V.astype(np.float32) * np.float32(1.0 / 255.0)
+    one = np.float32(1.0)
+    tab = np.stack([v, v * (one - s), v * (one - s * f), v * (one - s * (one - f))])
+    m = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    out = np.empty(H.shape + (3,), dtype=np.uint8)
+    idx = np.arange(H.size).reshape(H.shape)
+    flat = tab.reshape(4, -1)
+    for ch in range(3):
+        x = flat[m[sec, ch].ravel(), idx.ravel()].reshape(H.shape) * np.float32(255.0)
+        out[..., ch] = np.clip(np.rint(x), 0, 255).astype(np.uint8)
+    return out
+
+
+def test_hsv_to_bgr_convention(oracle_lib):
+    """8-bit HSV -> BGR of the colour time image: primaries, white at zero saturation, and the whole (H, S) table against
+    an independent numpy restatement of the stated formula."""
+    import ctypes as C
+    L = oracle_lib.lib()
+
+    def conv(H, S, V):
+        o = (C.c_uint8 * 3)()
+        L.bfo_hsv_to_bgr_u8(C.c_int32(H), C.c_int32(S), C.c_int32(V), o)
+        return tuple(o)
+    assert conv(0, 255, 255) == (0, 0, 255)      # red
+    assert conv(30, 255, 255) == (0, 255, 255)   # yellow
+    assert conv(60, 255, 255) == (0, 255, 0)     # green
+    assert conv(120, 255, 255) == (255, 0, 0)    # blue
+    assert conv(77, 0, 255) == (255, 255, 255)
+    assert conv(0, 0, 0) == (0, 0, 0)
+    H, S = np.meshgrid(np.arange(180), np.arange(256), indexing="ij")
+    want = _np_hsv_to_bgr(H, S, np.full_like(H, 255))
+    got = np.array([[conv(int(h), int(s), 255) for s in range(256)] for h in range(0, 180, 7)], dtype=np.uint8)
+    assert np.array_equal(got, want[::7])
+
+
+def test_color_time_img_structure(oracle_lib):
+    """EventFile::color_time_img: a lone event paints its scale x scale block with the hue of its phase at full
+    saturation; hue follows (t - t_min) / (t_max - t_min); and the whole image agrees with an order-free float64
+    numpy restatement up to the 8-bit quantisation of hue / saturation."""
+    H, W, s = 40, 50, 3
+    # five isolated events; the first and the last only pin t_min / t_max (their phases sit on a hue boundary)
+    fr_x = np.array([2, 5, 15, 25, 35], dtype=np.int32)
+    fr_y = np.array([3, 7, 17, 27, 37], dtype=np.int32)
+    t = np.array([0, 100000, 400000, 800000, 1000000], dtype=np.int64)
+    c = oracle_lib.Cloud(fr_x, fr_y, t)
+    img = c.color_time_img(s, H, W, show_final=True)
+    assert img.shape == (H * s + s, W * s + s, 3)
+    lit = img.any(axis=2)
+    assert lit.sum() == 5 * s * s
+    xs = -(H // 2) * s + H * s / 2.0
+    ys = -(W // 2) * s + W * s / 2.0
+    for k in (1, 2, 3):
+        x0, y0 = int(fr_x[k] * s + xs), int(fr_y[k] * s + ys)
+        blk = img[x0:x0 + s, y0:y0 + s].reshape(-1, 3)
+        assert (blk == blk[0]).all() and lit[x0:x0 + s, y0:y0 + s].all()
+        a = np.float32(2 * 3.14 * (t[k] / 1e6))
+        cs, sn = float(np.float32(np.cos(float(a)))), float(np.float32(np.sin(float(a))))
+        hue = int(((np.arctan2(sn, cs) + 3.1416) * 180 / 3.1416) / 2)
+        sat = int(np.hypot(cs, sn) * 255)
+        assert tuple(blk[0]) == tuple(_np_hsv_to_bgr(np.array([hue]), np.array([sat]), np.array([255]))[0])
+
+    sl = synth.make_slice(20000, H, W, 0.05, seed=43)
+    c = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    c.noise[::9] = 1
+    for sc in (1, 3, 4):
+        img = c.color_time_img(sc, H, W, show_final=True)
+        keep = c.noise == 0
+        tt = sl["t"].astype(np.int64)
+        tmin, tmax = tt.min(), max(tt.max(), 0)
+        ang = (2 * 3.14 * ((tt - tmin) / float(tmax - tmin))).astype(np.float32).astype(np.float64)[keep]
+        xs = -(H // 2) * sc + H * sc / 2.0
+        ys = -(W // 2) * sc + W * sc / 2.0
+        X = (sl["fr_x"][keep] * sc + xs).astype(np.int64)
+        Y = (sl["fr_y"][keep] * sc + ys).astype(np.int64)
+        ok = (X < H * sc) & (Y < W * sc) & (X >= 0) & (Y >= 0)
+        R, Cc = H * sc + sc, W * sc + sc
+        cnt = np.zeros((R, Cc)); sc_ = np.zeros((R, Cc)); ss_ = np.zeros((R, Cc))
+        bw = 2 * (sc // 2) + 1
+        for da in range(bw):
+            for db in range(bw):
+                np.add.at(cnt, (X[ok] + da, Y[ok] + db), 1)
+                np.add.at(sc_, (X[ok] + da, Y[ok] + db), np.cos(ang[ok]))
+                np.add.at(ss_, (X[ok] + da, Y[ok] + db), np.sin(ang[ok]))
+        assert np.array_equal(img.any(axis=2), cnt > 0)      # value = 255: every covered pixel is lit
+        m = cnt > 0
+        vx = np.where(m, sc_ / np.maximum(cnt, 1), 0).astype(np.float32)
+        vy = np.where(m, ss_ / np.maximum(cnt, 1), 0).astype(np.float32)
+        speed = np.hypot(vx.astype(np.float64), vy.astype(np.float64))
+        angle = np.where(speed != 0, (np.arctan2(vy.astype(np.float64), vx.astype(np.float64)) + 3.1416) * 180 / 3.1416, 0)
+        want = _np_hsv_to_bgr((angle / 2).astype(np.int64), (speed * 255).astype(np.int64), np.full(cnt.shape, 255))
+        want[~m] = 0
+        diff = np.abs(img.astype(np.int64) - want.astype(np.int64)).max(axis=2)
+        # f32 running sums vs float64 sums: only pixels sitting on a hue / saturation truncation boundary may move
+        assert (diff > 0).mean() < 0.01 and diff.max() <= 10, (sc, (diff > 0).mean(), diff.max())

@@ -161,9 +161,13 @@ def main():
     # ---- timed region: exactly K cold-start steps (each step = B slices in flight) ----------
     run_steps(0, args.warmup)
     barrier()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     events, iters = run_steps(args.warmup, args.steps)
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(elapsed, 1e-9)
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -401,6 +405,7 @@ def main():
                 "event_iterations_per_s": events_all / (args.steps * world * B) * iters_all / elapsed,
                 "parallelism": "slice-parallel: %d GPU(s) x %d concurrent slice contexts (HIP streams) per GPU, "
                                "no collectives" % (world, B),
+                "host_cores_busy_per_rank": host_cores_busy,
             },
             "regimes": regimes,
             "roofline": roofline,

@@ -10,7 +10,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <utility>
 #include <vector>
@@ -114,6 +116,7 @@ struct bf_ctx {
 
     DevState* h_state = nullptr;     // pinned, D2H target only: 2 slots (pipelined polling)
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    bool opt_blocking_poll = true;
     SliceStats* h_stats = nullptr;   // pinned, D2H target only
 
     DevState hst;                    // authoritative host mirror outside bf_run
@@ -377,6 +380,22 @@ int d2h_state(bf_ctx* c) {
     return BF_OK;
 }
 
+// Waits for an event without occupying a host core: query, sleep ~20 us (+ the kernel's timer slack), repeat.
+// hipEventSynchronize spins here whatever the event's flags say (measured: one full core per waiting thread).
+int wait_event_sleeping(bf_ctx* c, hipEvent_t ev) {
+    bool waited = false;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) HIP_TRY(c, e);
+        waited = true;
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+    }
+    if (waited) (void)hipGetLastError();   // "not ready" is recorded as the thread's last error: it is not one
+    return BF_OK;
+}
+
 // Folds the per-work-group min / max / sum records k_prepare wrote for the uploaded slice (one
 // device-to-host copy per slice, cached).
 int fold_stats(bf_ctx* c) {
@@ -596,6 +615,10 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     }
     if (!strcmp(key, "co_schedule")) {
         c->opt_co_schedule = value != 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "blocking_poll")) {
+        c->opt_blocking_poll = value != 0;
         return BF_OK;
     }
     if (!strcmp(key, "bin_tile_rows")) {
@@ -1320,6 +1343,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     bool want_rebin = false;
     bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
+    static const bool host_timing = getenv("BF_HOST_TIMING") != nullptr;   // debug: where the host thread's time goes
+    double ht_launch = 0, ht_wait = 0;
+    auto ht_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double ht_mark = host_timing ? ht_now() : 0;
     for (int batch = 0; !persist; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
         // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
@@ -1385,10 +1412,14 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState),
                                   hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipEventRecord(c->poll_ev[batch & 1], c->stream));
+        // A cold run is polled one batch behind the launches, so its wait can sleep (the wake-up latency hides
+        // behind the batch already queued) instead of burning a host core per slice context; a warm start waits
+        // for the batch it has just launched and spins.
+        hipEvent_t* pev = c->poll_ev;
+        HIP_TRY(c, hipEventRecord(pev[batch & 1], c->stream));
         if (batch == 0 && !warm_start) continue;
         if (warm_start) {   // look at this batch straight away
-            HIP_TRY(c, hipEventSynchronize(c->poll_ev[batch & 1]));
+            HIP_TRY(c, hipEventSynchronize(pev[batch & 1]));
             inf.polls++;
             const DevState& ws = c->h_state[batch & 1];
             if (ws.hot.done) {
@@ -1401,7 +1432,14 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;
         }
-        HIP_TRY(c, hipEventSynchronize(c->poll_ev[(batch - 1) & 1]));
+        if (host_timing) { const double t = ht_now(); ht_launch += t - ht_mark; ht_mark = t; }
+        if (c->opt_blocking_poll) {
+            int rcw = wait_event_sleeping(c, pev[(batch - 1) & 1]);
+            if (rcw != BF_OK) return rcw;
+        } else {
+            HIP_TRY(c, hipEventSynchronize(pev[(batch - 1) & 1]));
+        }
+        if (host_timing) { const double t = ht_now(); ht_wait += t - ht_mark; ht_mark = t; }
         inf.polls++;
         const DevState& snap = c->h_state[(batch - 1) & 1];
         if (snap.hot.done) {
@@ -1413,6 +1451,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
             return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
     }
+    if (host_timing)
+        fprintf(stderr, "bf_run host time: launching %.3f ms, waiting %.3f ms, %d launches\n", 1e3 * ht_launch,
+                1e3 * ht_wait, (int)inf.launches);
     if (binned) {   // the device chose which set holds the (tile-sorted) events
         c->cs = fin.hot.cs;
         c->has_perm = true;

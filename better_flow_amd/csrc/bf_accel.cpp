@@ -853,6 +853,8 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     c->degenerate = false;
     if ((size_t)w.scale_img_x * (size_t)w.scale_img_y > c->cap_px)
         return fail(c, BF_ERR_CAPACITY, "window %d x %d exceeds the image capacity", w.scale_img_x, w.scale_img_y);
+    if (w.scale_img_x > 65535 || w.scale_img_y > 65535)   // 16-bit pixel coordinates in the packed moment sums
+        return fail(c, BF_ERR_CAPACITY, "window %d x %d: at most 65535 rows / columns", w.scale_img_x, w.scale_img_y);
     int gx, gy;
     stencil_grid(w.scale_img_x, w.scale_img_y, &gx, &gy);
     if (gx * gy > c->cap_blocks) return fail(c, BF_ERR_CAPACITY, "window needs %d tiles > %d", gx * gy, c->cap_blocks);

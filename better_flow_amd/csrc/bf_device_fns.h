@@ -138,12 +138,17 @@ __device__ __forceinline__ void sums_wave_reduce(Sums& s) {
 }
 
 // Wave64 sum of a 64-bit pattern on the DPP network (no LDS traffic): inclusive scan by row_shr 1 / 2 / 4 / 8
-// inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 --
-// lane 63 ends up with the total, added in a fixed order.  Lanes without a source read the identity (0).
+// inside each row of 16 lanes, then row_bcast:15 (lane 15 of a row into the next row) and row_bcast:31 (lane 31 into
+// rows 2 and 3) -- lane 63 ends up with the total, added in a fixed order; no other lane is meaningful.
+// Every step runs with all rows enabled and bound_ctrl:0 (a lane without a source reads 0), so no register has to be
+// zeroed for the lanes a step does not feed.  The row_bcast steps then also add into rows that a masked step would
+// skip (row 2 picks up row 1's total, rows 0 / 1 pick up nothing); those lanes are never read again: lane 63 adds
+// lane 47's value as it was BEFORE the step (DPP reads the operand of the other lane, not its result), then lane 31's,
+// which is (row 1 + row 0) -- the same four row totals in the same order as with the masks.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, ROW_MASK, 0xf, true);
     return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
 }
 __device__ __forceinline__ long long wave_total_dpp(long long v) {
@@ -151,8 +156,8 @@ __device__ __forceinline__ long long wave_total_dpp(long long v) {
     v += (long long)dpp_u64<0x112, 0xf>((unsigned long long)v);   // row_shr:2
     v += (long long)dpp_u64<0x114, 0xf>((unsigned long long)v);   // row_shr:4
     v += (long long)dpp_u64<0x118, 0xf>((unsigned long long)v);   // row_shr:8
-    v += (long long)dpp_u64<0x142, 0xa>((unsigned long long)v);   // row_bcast:15 -> rows 1, 3
-    v += (long long)dpp_u64<0x143, 0xc>((unsigned long long)v);   // row_bcast:31 -> rows 2, 3
+    v += (long long)dpp_u64<0x142, 0xf>((unsigned long long)v);   // row_bcast:15: lane 15 of a row -> the next row
+    v += (long long)dpp_u64<0x143, 0xf>((unsigned long long)v);   // row_bcast:31: lane 31 -> rows 2, 3
     return v;   // lane 63: sum of all 64 lanes
 }
 __device__ __forceinline__ double wave_total_dpp(double v) {
@@ -162,8 +167,8 @@ __device__ __forceinline__ double wave_total_dpp(double v) {
     BF_DPP_STEP(0x112, 0xf);
     BF_DPP_STEP(0x114, 0xf);
     BF_DPP_STEP(0x118, 0xf);
-    BF_DPP_STEP(0x142, 0xa);
-    BF_DPP_STEP(0x143, 0xc);
+    BF_DPP_STEP(0x142, 0xf);
+    BF_DPP_STEP(0x143, 0xf);
 #undef BF_DPP_STEP
     return v;
 }
@@ -173,12 +178,62 @@ __device__ __forceinline__ double wave_total_dpp(double v) {
 // wave64 __shfl_down tree costs 107 ds_bpermute_b32 per wave, ~1.9 us with every wave at it; an
 // LDS-transposed version ~1.8 us; this one stays on the VALU.)  Every thread gets the total.
 // `tid` is the thread's index inside its THREADS-wide group (groups are wave aligned).
+// Wave64 total of a 32-bit word, same network; the compiler folds each step into one v_add_u32 with a DPP operand.
+__device__ __forceinline__ unsigned int wave_total_dpp(unsigned int v) {
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xf, 0xf, true);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xf, 0xf, true);
+    return v;
+}
+
+// PACK_INTS: the group contributes at most 1024 pixels, all inside a tile whose first centred row / column is
+// (base_i, base_j) and which is at most 64 x 64 (a 16 x 64 stencil tile).  The three integer sums then travel as two
+// 32-bit words of tile-local coordinates -- n << 16 | sum(cj - base_j), and sum(ci - base_i), each field with room
+// for 1024 terms -- through the wave reduction (one instruction per step and word, against five for a 64-bit
+// integer) and as one 64-bit word through the LDS hop.  Exact: sci = sum + n base_i.
 constexpr int kSumFields = 9;
-template <int THREADS>
+template <int THREADS, bool PACK_INTS = false>
 __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_part /* 9 * THREADS / 64 */,
-                                                  const int tid) {
+                                                  const int tid, const int base_i = 0, const int base_j = 0) {
     constexpr int W = THREADS / 64;
     Sums r;
+    if constexpr (PACK_INTS) {
+        const int tn = (int)sm.n;
+        const unsigned int wa = wave_total_dpp(((unsigned int)tn << 16) | (unsigned int)((int)sm.scj - tn * base_j));
+        const unsigned int wb = wave_total_dpp((unsigned int)((int)sm.sci - tn * base_i));
+        r.sgx = wave_total_dpp(sm.sgx); r.sgy = wave_total_dpp(sm.sgy);
+        r.sigx = wave_total_dpp(sm.sigx); r.sigy = wave_total_dpp(sm.sigy);
+        r.sjgx = wave_total_dpp(sm.sjgx); r.sjgy = wave_total_dpp(sm.sjgy);
+        if ((tid & 63) == 63) {
+            const int w = tid >> 6;
+            s_part[0 * W + w] = ((unsigned long long)wa << 32) | (unsigned long long)wb;
+            s_part[3 * W + w] = (unsigned long long)__double_as_longlong(r.sgx);
+            s_part[4 * W + w] = (unsigned long long)__double_as_longlong(r.sgy);
+            s_part[5 * W + w] = (unsigned long long)__double_as_longlong(r.sigx);
+            s_part[6 * W + w] = (unsigned long long)__double_as_longlong(r.sigy);
+            s_part[7 * W + w] = (unsigned long long)__double_as_longlong(r.sjgx);
+            s_part[8 * W + w] = (unsigned long long)__double_as_longlong(r.sjgy);
+        }
+        __syncthreads();
+        Sums t;
+        unsigned long long pt = 0;
+        double d_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            pt += s_part[0 * W + w];
+#pragma unroll
+            for (int f = 3; f < kSumFields; ++f) d_[f - 3] += __longlong_as_double((long long)s_part[f * W + w]);
+        }
+        const unsigned int ta = (unsigned int)(pt >> 32), tb = (unsigned int)pt;
+        t.n = (long long)(ta >> 16);
+        t.sci = (long long)tb + t.n * (long long)base_i;
+        t.scj = (long long)(ta & 0xffffu) + t.n * (long long)base_j;
+        t.sgx = d_[0]; t.sgy = d_[1]; t.sigx = d_[2]; t.sigy = d_[3]; t.sjgx = d_[4]; t.sjgy = d_[5];
+        return t;
+    }
     r.n = wave_total_dpp(sm.n); r.sci = wave_total_dpp(sm.sci); r.scj = wave_total_dpp(sm.scj);
     r.sgx = wave_total_dpp(sm.sgx); r.sgy = wave_total_dpp(sm.sgy);
     r.sigx = wave_total_dpp(sm.sigx); r.sigy = wave_total_dpp(sm.sigy);
@@ -514,7 +569,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         if (a.ticket && tid < (int)(sizeof(DevState) / 8))
             reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st_rw)[tid];
         __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
-        const Sums blk = block_reduce_sums<kThreads>(sm, s_rpart, tid);
+        const Sums blk = block_reduce_sums<kThreads, (TR * TC <= 1024 && TR <= 64 && TC <= 64)>(sm, s_rpart, tid, r0 - hR, c0 - hC);
         tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;

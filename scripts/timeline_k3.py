@@ -19,7 +19,8 @@ for ln in open("/tmp/bf_tl.txt"):
 names = {0: "entry", 1: "state", 2: "slabs loaded+LDS", 3: "sync", 4: "time img+sync", 5: "tail pixels", 6: "wave reduce+sync", 7: "published+ticket",
          10: "LAST:partials loaded", 11: "LAST:reduced", 12: "LAST:update done"}
 k1names = {0: "entry", 1: "state+zero", 2: "events done", 3: "sync", 4: "flushed"}
-for L in (20, 21):
+L0 = int(os.environ.get("TL_LAUNCH", "20"))
+for L in (L0, L0 + 1):
     base = min(d[(1, L, 0)].values()) if d.get((1, L, 0)) else None
     for g in (0, 1):
         st = d.get((1, L, g), {})

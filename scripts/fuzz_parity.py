@@ -152,7 +152,11 @@ for ci in range(cases):
             g, o_ = ref[6][k][0], otr[k].model
             if g["cnt"] != o_.cnt and not np.isnan(o_.dx):
                 print(tag, "TRACE cnt at", k, g["cnt"], o_.cnt); bad += 1; dump(ci, c, K); break
-            worst = max((rel(g[f], getattr(o_, f)) for f in ("dx", "dy", "rot", "div", "total_dx", "total_dy", "total_rot", "total_div")
+            # rot / div are means of r x g and r . g with |r| up to half the image: the same gradient noise weighs
+            # |r| times more there, so their absolute floor scales with the image radius (in units of 100 pixels)
+            rad = max(1.0, max(s * H, s * W) / 200.0)
+            worst = max((rel(g[f], getattr(o_, f)) / (rad if ("rot" in f or "div" in f) else 1.0)
+                         for f in ("dx", "dy", "rot", "div", "total_dx", "total_dy", "total_rot", "total_div")
                          if not np.isnan(getattr(o_, f))), default=0.0)
             if worst > 3e-4:   # gradient noise of the oracle's own f32 time sums on small clouds
                 print(tag, "TRACE model at", k, "rel", worst); bad += 1; dump(ci, c, K); break

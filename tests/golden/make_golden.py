@@ -89,6 +89,43 @@ def main():
     np.savez_compressed(os.path.join(HERE, "slice_6k_120x90_images.npz"), **extra)
     man["images_file"] = "slice_6k_120x90_images.npz"
     man["local"] = local
+    # ---- third fixture: a warm-started (STM) run, the colour-coded time images, the command line ----
+    stream = {}
+    sl_b = synth.make_slice(6000, H, W, 0.05, seed=22)           # the next slice of the same scene
+    c5 = oracle.Cloud(sl_b["fr_x"], sl_b["fr_y"], sl_b["t"])
+    w5 = c5.set_cloud(S, H, W)
+    m5 = c5.set_model(m2)                                         # OptimizerRolling::set_model(last slice's model)
+    rc5, loop5, tr5 = c5.run(w5, m5, res_x=H, res_y=W, trace_cap=4096)
+    stream["b_fr_x"], stream["b_fr_y"], stream["b_t"] = sl_b["fr_x"], sl_b["fr_y"], sl_b["t"]
+    stream["warm_trajectory"] = np.array(
+        [[r.model.total_dx, r.model.total_dy, r.model.total_rot, r.model.total_div,
+          r.loop.x_divider, r.loop.y_divider, r.loop.rot_divider, r.loop.div_divider] for r in tr5])
+    c6 = oracle.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    c6.set_cloud(S, H, W)
+    stream["color_raw"] = c6.color_time_img(S, H, W, show_final=True)
+    c6.project_4param_reinit(*WARPS[2])
+    stream["color_warp2"] = c6.color_time_img(S, H, W)
+    # bf_motion_compensator -o on the config-1 input (10k events, 240x180), through the oracle-backed build of the
+    # host front end (tests/shim): slice count, skip decisions, and the per-event output file
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "shim"))
+    import build as shim_build
+    exe = shim_build.build()
+    with tempfile.TemporaryDirectory() as d:
+        sl_c = synth.make_slice(10000, 180, 240, 0.1, seed=5)
+        synth.write_txt(os.path.join(d, "ev.txt"), sl_c)
+        so = subprocess.run([exe, "-o", os.path.join(d, "out.txt"), os.path.join(d, "ev.txt")], cwd=d,
+                            stdout=subprocess.PIPE, check=True).stdout.decode()
+        out = np.loadtxt(os.path.join(d, "out.txt"))
+    import re
+    summ = [int(x) for x in re.search(r"slices: (\d+) \(skipped (\d+)\), minimizer iterations: (\d+)", so).groups()]
+    stream["cli_t"], stream["cli_x"], stream["cli_y"] = out[:, 0], out[:, 1].astype(np.int32), out[:, 2].astype(np.int32)
+    stream["cli_v"], stream["cli_u"] = out[:, 4], out[:, 5]
+    np.savez_compressed(os.path.join(HERE, "slice_6k_120x90_stream.npz"), **stream)
+    man["stream"] = {"file": "slice_6k_120x90_stream.npz", "warm_rc": rc5, "warm_iterations": int(loop5.itercount),
+                     "warm_final_model": m5.as_dict(), "cli": {"events": 10000, "height": 180, "width": 240, "seed": 5,
+                                                                "slices": summ[0], "skipped": summ[1], "iterations": summ[2]}}
     json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
     print("wrote", man["file"], man["images_file"], "iterations", loop.itercount, "events", len(sl["t"]))
 

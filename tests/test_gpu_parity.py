@@ -340,6 +340,46 @@ def test_golden_images_gpu(accel_mod):
     acc.close()
 
 
+def test_golden_stream_gpu(accel_mod):
+    """Third fixture (no oracle build needed): the warm-started (STM) run of the next slice from the golden model of
+    the previous one -- same iteration count within one, the first iterations' accumulators to 1e-6, the final flow to
+    the stated tolerance -- and the colour-coded time images (covered pixels exact, at most 1 % of them off by one hue /
+    saturation step)."""
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    man = json.load(open(os.path.join(gold, "manifest.json")))
+    z, zs = np.load(os.path.join(gold, man["file"])), np.load(os.path.join(gold, man["stream"]["file"]))
+    H, W, s, st = man["height"], man["width"], man["scale"], man["stream"]
+    acc = accel_mod.Accel(max_events=8192, max_rows=s * H + s, max_cols=s * W + s)
+    acc.upload_events(zs["b_fr_x"], zs["b_fr_y"], zs["b_t"])
+    acc.set_cloud(s, H, W)
+    acc.set_model(accel_mod.Model(**man["final_model"]))
+    o = acc.default_opts()
+    o.res_x, o.res_y, o.trace_cap = H, W, 64
+    rc, m, info = acc.run(o)
+    assert rc == st["warm_rc"] and abs(info.iterations - st["warm_iterations"]) <= 1
+    tr = acc.get_trace(64)
+    gt = zs["warm_trajectory"]
+    for k in range(min(3, len(tr), len(gt))):
+        got = np.array([tr[k].model.total_dx, tr[k].model.total_dy, tr[k].model.total_rot, tr[k].model.total_div])
+        np.testing.assert_allclose(got, gt[k, :4], rtol=1e-6, atol=1e-9)
+    fm = st["warm_final_model"]
+    for f in ("total_dx", "total_dy"):
+        assert abs(getattr(m, f) - fm[f]) <= max(1e-4 * abs(fm[f]), 2e-5), (f, getattr(m, f), fm[f])
+    acc.upload_events(z["fr_x"], z["fr_y"], z["t"])
+    acc.set_cloud(s, H, W)
+    for img, want in ((acc.color_time_img(s, H, W, show_final=True), zs["color_raw"]),):
+        assert np.array_equal(img.any(axis=2), want.any(axis=2))
+        d = np.abs(img.astype(np.int64) - want.astype(np.int64)).max(axis=2)
+        assert (d[want.any(axis=2)] > 0).mean() < 0.01 and d.max() <= 9
+    acc.project_4param_reinit(*man["warps"][2])
+    img, want = acc.color_time_img(s, H, W), zs["color_warp2"]
+    assert np.array_equal(img.any(axis=2), want.any(axis=2))
+    d = np.abs(img.astype(np.int64) - want.astype(np.int64)).max(axis=2)
+    assert (d[want.any(axis=2)] > 0).mean() < 0.01 and d.max() <= 9
+    acc.close()
+
+
 def _run_mode(accel_mod, sl, H, W, scale, trace_cap=0, warm=None, **options):
     acc = accel_mod.Accel(max_events=max(len(sl["t"]), 8192), max_rows=scale * H + scale,
                           max_cols=scale * W + scale)

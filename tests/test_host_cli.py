@@ -73,6 +73,13 @@ def test_cli_config1_oracle(oracle_cli, events_txt, tmp_path):
     assert np.array_equal(a[:, 1].astype(int), sl["fr_y"]) and np.array_equal(a[:, 2].astype(int), sl["fr_x"])
     # the reader makes every timestamp relative to the first line (bf_motion_compensator.cpp:188-199)
     np.testing.assert_allclose(a[:, 0], (sl["t"] - sl["t"][0]) * 1e-9, rtol=0, atol=3e-9)
+    # the committed golden run of this input (tests/golden/make_golden.py): same slices, same per-event output
+    import json
+    gold = os.path.join(ROOT, "tests", "golden")
+    man = json.load(open(os.path.join(gold, "manifest.json")))["stream"]
+    zs = np.load(os.path.join(gold, man["file"]))
+    assert (slices, skipped, iters) == (man["cli"]["slices"], man["cli"]["skipped"], man["cli"]["iterations"])
+    assert np.array_equal(a[:, 0], zs["cli_t"]) and np.array_equal(a[:, 4], zs["cli_v"]) and np.array_equal(a[:, 5], zs["cli_u"])
     vr, vc = sl["velocity"]
     assert abs(a[:, 4].mean() - vc) < 0.01 * abs(vc) and abs(a[:, 5].mean() - vr) < 0.01 * abs(vr)
     # --stm-disable: every slice cold-started -> more iterations in total
@@ -102,6 +109,19 @@ def test_cli_gpu_matches_oracle_cli(oracle_cli, events_txt, tmp_path):
             d = np.abs(a[:, col] - b[:, col])
             assert np.all(d <= np.maximum(5e-3 * np.abs(a[:, col]), 1.0)), (extra, col, d.max())
             assert abs(a[:, col].mean() - b[:, col].mean()) < 0.05
+    # ... and against the committed golden run (no oracle involved): default flags
+    import json
+    gold = os.path.join(ROOT, "tests", "golden")
+    man = json.load(open(os.path.join(gold, "manifest.json")))["stream"]
+    zs = np.load(os.path.join(gold, man["file"]))
+    g_out = str(tmp_path / "g2.txt")
+    sg = parse_summary(run_cli(gpu_cli, ["-o", g_out, path], str(tmp_path)))
+    assert sg[:2] == (man["cli"]["slices"], man["cli"]["skipped"]) and abs(sg[2] - man["cli"]["iterations"]) <= 2 * sg[0]
+    b = np.loadtxt(g_out)
+    assert np.array_equal(b[:, 0], zs["cli_t"]) and np.array_equal(b[:, 1].astype(np.int32), zs["cli_x"])
+    for col, key in ((4, "cli_v"), (5, "cli_u")):
+        assert np.all(np.abs(b[:, col] - zs[key]) <= np.maximum(5e-3 * np.abs(zs[key]), 1.0))
+        assert abs(b[:, col].mean() - zs[key].mean()) < 0.05
     # the library identifies itself as the HIP build, not the test shim
     ver = subprocess.check_output([gpu_cli, "--version"]).decode()
     assert "gfx950" in ver and "SHIM" not in ver

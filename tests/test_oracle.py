@@ -211,6 +211,31 @@ def test_golden_images(oracle_lib):
     assert np.array_equal(c2.projection_img(s, H, W), zi["proj_warp2"])
 
 
+def test_golden_stream(oracle_lib):
+    """Third fixture: a warm-started (STM) run -- the next slice of the scene from the previous slice's model -- and the
+    colour-coded time images."""
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))
+    z, zs = np.load(os.path.join(GOLD, man["file"])), np.load(os.path.join(GOLD, man["stream"]["file"]))
+    H, W, s, st = man["height"], man["width"], man["scale"], man["stream"]
+    last = oracle_lib.Model()
+    for k, v in man["final_model"].items():
+        setattr(last, k, v)
+    c = oracle_lib.Cloud(zs["b_fr_x"], zs["b_fr_y"], zs["b_t"])
+    w = c.set_cloud(s, H, W)
+    m = c.set_model(last)
+    rc, loop, tr = c.run(w, m, res_x=H, res_y=W, trace_cap=4096)
+    assert rc == st["warm_rc"] and loop.itercount == st["warm_iterations"] and m.as_dict() == st["warm_final_model"]
+    assert loop.itercount < man["iterations"]          # the warm start needs fewer iterations than the cold one
+    got = np.array([[r.model.total_dx, r.model.total_dy, r.model.total_rot, r.model.total_div,
+                     r.loop.x_divider, r.loop.y_divider, r.loop.rot_divider, r.loop.div_divider] for r in tr])
+    assert np.array_equal(got, zs["warm_trajectory"])
+    c2 = oracle_lib.Cloud(z["fr_x"], z["fr_y"], z["t"])
+    c2.set_cloud(s, H, W)
+    assert np.array_equal(c2.color_time_img(s, H, W, show_final=True), zs["color_raw"])
+    c2.project_4param_reinit(*man["warps"][2])
+    assert np.array_equal(c2.color_time_img(s, H, W), zs["color_warp2"])
+
+
 # ---- OptimizerLocal: the contrast-score optimiser (optimizer_sampler.cpp) ----
 
 def _np_gauss(img, k):

@@ -121,15 +121,20 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
 /* AccelLib::~AccelLib / clear_buffers (accel_lib.h:57-69). */
 void bf_destroy(bf_ctx *ctx);
 
-/* Text of the last error on this ctx ("" if none).  Never NULL. */
+/* Text of the last error on this ctx ("" if none).  Never NULL.  Takes the place of the reference's
+ * "OpenCL Error: <n>" prints (accel_lib.h:125,138,253,299,361): errors are returned, the text is kept here. */
 const char *bf_last_error(const bf_ctx *ctx);
 
-/* Library / build identification, e.g. "bf_accel gfx950 r1". */
+/* Library / build identification, e.g. "bf_accel gfx950 r1" (printed by `bf_motion_compensator --version`
+ * next to the reference's version line, bf_motion_compensator.cpp:26-33). */
 const char *bf_version(void);
 
+/* The reference's settings of OptimizerRolling::run: no iteration cap (optimizer_rolling.h:25,43, max_itercount = -1),
+ * guards of :49-58 (1000 events, window >= scale * RES / 15), sensor 180 x 240 (common.h:39-40). */
 void bf_run_opts_default(bf_run_opts *opts);
 
-/* sizeof() of bf_model, bf_window, bf_run_opts, bf_run_info, bf_trace_rec, bf_profile,
+/* No reference counterpart (the reference has no foreign-language boundary).
+ * sizeof() of bf_model, bf_window, bf_run_opts, bf_run_info, bf_trace_rec, bf_profile,
  * bf_local_window, bf_local_state (in that order) as this library was compiled -- lets a
  * foreign-language binding verify its struct layouts.  Writes min(n, 8) entries; returns 8. */
 int bf_abi_struct_sizes(int32_t *out, int32_t n);
@@ -181,12 +186,14 @@ int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 int bf_upload_events(bf_ctx *ctx, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns,
                      const uint8_t *noise, int64_t n);
 
-/* Same, but the three arrays are DEVICE pointers (slice already resident in HBM). */
+/* Same (accel_lib.h:71-115 without the blocking enqueueWriteBuffer calls of :109-115), but the three arrays are
+ * DEVICE pointers (slice already resident in HBM). */
 int bf_upload_events_device(bf_ctx *ctx, const int32_t *d_fr_x, const int32_t *d_fr_y,
                             const int32_t *d_t_ns, int64_t n);
 
 /* Streaming front end (BASELINE config 3): stage the NEXT slice while the current one is being
- * optimised.  bf_host_alloc returns pinned host memory; bf_upload_events_async copies a slice from
+ * optimised -- the reference uploads with blocking writes on its one queue (accel_lib.h:109-115, CL_TRUE) and
+ * re-allocates its staging arrays per slice (:82-89).  bf_host_alloc returns pinned host memory; bf_upload_events_async copies a slice from
  * pinned arrays into one of two device staging slots on the ctx's COPY stream and returns at once
  * (the arrays must stay untouched until the matching bf_commit_upload returns);
  * bf_commit_upload makes the compute stream wait for the oldest pending copy and stages it
@@ -268,7 +275,8 @@ typedef struct bf_tile_opts {
 } bf_tile_opts;
 int bf_run_tiles(bf_ctx *ctx, const bf_tile_opts *opts, bf_model *models_out, bf_run_info *infos_out);
 
-/* Records of the last bf_run (opts->trace_cap > 0).  Returns the number written. */
+/* Records of the last bf_run (opts->trace_cap > 0): model and dividers after every iteration_step -- what the
+ * reference prints under VERBOSE (optimizer_rolling.h:116-118) or shows in manual() (:212).  Returns the number written. */
 int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);
 
 /* ---- raw device buffers ----------------------------------------------------------- */
@@ -351,24 +359,27 @@ int bf_local_iteration_step(bf_ctx *ctx, double nx, double ny, double *score, ui
 int bf_local_run(bf_ctx *ctx, int32_t res_x, int32_t res_y, int64_t max_evaluations, bf_local_state *out);
 
 /* For callers that keep slices resident in HBM (bench.py, the streaming front end) and
- * hand them over with bf_upload_events_device.  bf_memcpy_h2d is synchronous. */
+ * hand them over with bf_upload_events_device.  bf_memcpy_h2d is synchronous.  (The reference's device buffers are
+ * private members of AccelLib, accel_lib.h:15-27; no counterpart.) */
 int bf_device_malloc(bf_ctx *ctx, int64_t bytes, void **out);
 int bf_device_free(bf_ctx *ctx, void *ptr);
 int bf_memcpy_h2d(bf_ctx *ctx, void *dst, const void *src, int64_t bytes);
 
 /* ---- measurement ---------------------------------------------------------------- */
 
-/* Per-kernel hipEvent timing.  mode 0: off (default).  mode 1: bracket every kernel
+/* Per-kernel hipEvent timing (the reference times whole slices with std::clock in its driver,
+ * bf_motion_compensator.cpp:158-177, and the minimiser under VERBOSE, optimizer_rolling.h:116-118).  mode 0: off (default).  mode 1: bracket every kernel
  * launch with events on the ctx stream; totals are read with bf_profile_get, which
  * synchronises the stream. */
 int bf_profile_enable(bf_ctx *ctx, int32_t mode);
 int bf_profile_reset(bf_ctx *ctx);
 int bf_profile_get(bf_ctx *ctx, bf_profile *out);
 
-/* Block until everything enqueued on the ctx stream has finished. */
+/* Block until everything enqueued on the ctx stream has finished (the reference's calls are all blocking:
+ * CL_TRUE reads / writes and queue->finish(), accel_lib.h:109-115,317-321). */
 int bf_synchronize(bf_ctx *ctx);
 
-/* Streaming-copy bandwidth probe on this device: copies `bytes` bytes `reps` times
+/* No reference counterpart.  Streaming-copy bandwidth probe on this device: copies `bytes` bytes `reps` times
  * with a float4 kernel and returns the best GB/s (read + write counted).  Used by
  * bench.py to report the measured HBM ceiling next to the 8 TB/s nominal peak. */
 int bf_copy_bandwidth(bf_ctx *ctx, int64_t bytes, int32_t reps, double *gbps_out);

@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT)
 os.environ["BF_TIMELINE"] = "/tmp/bf_tl.txt"
 os.environ["BF_ACCEL_LIB"] = os.path.join(ROOT, "better_flow_amd", "libbf_accel_tl.so")
 from better_flow_amd import accel, synth
-N, H, W, s = 1000000, 260, 346, 3
+N, H, W, s = 1000000, int(os.environ.get("BF_RUN_H", "260")), int(os.environ.get("BF_RUN_W", "346")), 3
 sl = synth.make_slice(N, H, W, 0.030, seed=1)
 acc = accel.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
 opts = acc.default_opts(); opts.res_x, opts.res_y = H, W

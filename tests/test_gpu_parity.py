@@ -571,6 +571,45 @@ def test_full_size_config2(oracle_lib, accel_mod):
             assert abs(g[f] - getattr(o_, f)) <= 1e-6 * max(abs(getattr(o_, f)), 1e-4), (k, f, g[f], getattr(o_, f))
 
 
+def test_full_size_properties(accel_mod):
+    """Size-independent properties at BASELINE config 2's full size (1M events, cold run to convergence, no oracle):
+    * order invariance -- any permutation of the events gives the same model, iteration count and per-event flow BIT
+      FOR BIT (the accumulators are integers; the reference itself is order-dependent at the 1e-8 level);
+    * sensor translation -- the same scene shifted by whole pixels converges to the same flow within the stated
+      tolerance, with the centre shifted by the same amount;
+    * the flow that was injected into the synthetic scene comes back (median over the events within 0.5 %)."""
+    H, W, s = 260, 346, 3
+    sl = synth.make_slice(1000000, H, W, 0.030, seed=1)
+    n = len(sl["t"])
+
+    def run(fx, fy, t, Hs=H, Ws=W):
+        a = accel_mod.Accel(max_events=n, max_rows=s * Hs + s, max_cols=s * Ws + s)
+        a.upload_events(fx, fy, t)
+        a.set_cloud(s, Hs, Ws)
+        o = a.default_opts()
+        o.res_x, o.res_y, o.want_uv = Hs, Ws, 1
+        rc, m, info = a.run(o)
+        u, v = a.compute_uv()
+        a.close()
+        return rc, info.iterations, m.as_dict(), u, v
+
+    rc0, it0, m0, u0, v0 = run(sl["fr_x"], sl["fr_y"], sl["t"])
+    assert rc0 == 0
+    perm = np.random.default_rng(7).permutation(n)
+    rc1, it1, m1, u1, v1 = run(sl["fr_x"][perm].copy(), sl["fr_y"][perm].copy(), sl["t"][perm].copy())
+    assert (rc1, it1) == (rc0, it0) and m1 == m0
+    assert np.array_equal(u1, u0[perm]) and np.array_equal(v1, v0[perm])
+    # translation by (7, 12) sensor pixels on a correspondingly larger sensor
+    rc2, it2, m2, u2, v2 = run(sl["fr_x"] + 7, sl["fr_y"] + 12, sl["t"], H + 7, W + 12)
+    assert rc2 == 0
+    assert _flow_close(u2, u0) and _flow_close(v2, v0)
+    # (the converged model keeps its centre in sensor coordinates, optimizer_rolling.h:345-346)
+    assert abs(m2["cx"] - (m0["cx"] + 7)) < 1e-3 and abs(m2["cy"] - (m0["cy"] + 12)) < 1e-3
+    # injected flow: (-150 H / 180, 300 W / 240) px/s
+    assert abs(np.median(u0) - (-150.0 * H / 180.0)) < 0.005 * 150.0 * H / 180.0
+    assert abs(np.median(v0) - (300.0 * W / 240.0)) < 0.005 * 300.0 * W / 240.0
+
+
 def test_concurrent_contexts_match_sequential(accel_mod):
     """Several slice contexts in flight on one GPU (bench.py --concurrent): same results as one
     after the other."""

@@ -1,0 +1,61 @@
+"""bench.py's contract with the driver (GPU): one JSON line with the required keys, for the plain launch and for the
+one-process-per-GPU launch (`python -m torch.distributed.run ... bench.py --gpus N`; two ranks share GPU 0 here, which
+exercises the rendezvous, the barrier / max-over-ranks timing and the whole-job aggregation)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _line(cmd):
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]          # exactly ONE JSON line (rank 0)
+    return json.loads(lines[0])
+
+
+def _check(d, n_gpus, steps, warmup):
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "Mevents/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # value = whole-job events / time: consistent with ms_per_step and the per-step slice count
+    ev_per_step = d["config"]["events_per_slice"] * d["config"]["slices_per_step_per_gpu"] * n_gpus
+    assert abs(d["value"] - ev_per_step / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_single_process():
+    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-iters", "8", "--cpu-cores", "2"])
+    _check(d, 1, 3, 1)
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and 0 < c["value"] < d["value"]
+    assert d["roofline"]["frac"] > 0.2 and set(d["regimes"]) >= {"warm_stm", "capped_max_iter_10"}
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_torchrun():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"])
+    _check(d, 2, 2, 1)
+    assert d["cpu_baseline"] is None          # timed on rank 0 at N = 1 only

@@ -977,8 +977,8 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     }
     c->last_R = w.scale_img_x;
     c->last_C = w.scale_img_y;
-    launch_set_state(c->d_state, c->hst, c->stream);
-    HIP_TRY(c, hipGetLastError());
+    // (the device copy of the state is written by whoever uses it next -- bf_run, the AccelLib operators,
+    // flush_pending all upload c->hst first; a launch here would only add ~5 us to every slice)
     if (window_out) *window_out = w;
     return BF_OK;
 }

@@ -356,9 +356,13 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
         // relaxed = global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat
         // dirty in the L2s until the end of the kernel, and their write-back stretched the kernel
         // boundary to ~5.6 us (measured; "B / 6 TB/s" in the MI355X notes).
+        // (16 bytes per lane: L is even, so LL is, and a slab starts on a 16-byte boundary)
         unsigned long long* dst = slabs + (size_t)b * (size_t)LL;
-        for (int i = threadIdx.x; i < LL; i += THREADS)
-            __hip_atomic_store(&dst[i], s_tile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bf_u32x4* src4 = reinterpret_cast<const bf_u32x4*>(s_tile);
+        for (int i = threadIdx.x; i < LL / 2; i += THREADS) {
+            const bf_u32x4 v = src4[i];
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + 2 * i), "v"(v) : "memory");
+        }
     }
     tl_stamp(tl, tl_launch, 4);
 #ifdef BF_TIMELINE

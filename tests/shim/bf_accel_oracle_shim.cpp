@@ -47,6 +47,18 @@ static void from_abi(const bf_model &m, bfo_model *o) {
     o->total_dx = m.total_dx; o->total_dy = m.total_dy; o->total_rot = m.total_rot; o->total_div = m.total_div;
 }
 
+// BF_SHIM_EVENT_ORDER=reversed hands every slice to the oracle in the opposite event order (outputs are mapped back).
+// The reference accumulates its time image in f32 in container order (accel_lib.h:162), so this is the smallest
+// perturbation the reference itself is subject to; tests use it to measure the oracle's OWN spread over an STM chain
+// and derive the admissible GPU-vs-oracle difference from it.
+static bool flip_order() {
+    static const bool f = [] { const char *e = std::getenv("BF_SHIM_EVENT_ORDER"); return e && !strcmp(e, "reversed"); }();
+    return f;
+}
+template <class T> static void reverse_vec(std::vector<T> &v) {
+    for (size_t i = 0, n = v.size(); i < n / 2; ++i) std::swap(v[i], v[n - 1 - i]);
+}
+
 extern "C" {
 
 const char *bf_version(void) { return "bf_accel ORACLE TEST SHIM (CPU) -- not the product"; }
@@ -72,9 +84,13 @@ int bf_upload_events(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, const 
     c->noise.assign(n, 0);
     if (noise) c->noise.assign(noise, noise + n);
     c->pr_x.assign(n, 0); c->pr_y.assign(n, 0); c->nx.assign(n, 0); c->ny.assign(n, 0);
+    c->reversed = false;
+    if (flip_order()) {
+        reverse_vec(c->fx); reverse_vec(c->fy); reverse_vec(c->t); reverse_vec(c->noise);
+        c->reversed = true;
+    }
     c->bind();
     c->have_window = false;
-    c->reversed = false;
     return BF_OK;
 }
 
@@ -128,10 +144,12 @@ int bf_fast_model(bf_ctx *c, const float *img, int32_t rows, int32_t cols, bf_mo
 
 int bf_writeout_events(bf_ctx *c, double *pr_x, double *pr_y, double *nx, double *ny) {
     const size_t n = c->fx.size();
-    if (pr_x) memcpy(pr_x, c->pr_x.data(), n * 8);
-    if (pr_y) memcpy(pr_y, c->pr_y.data(), n * 8);
-    if (nx) memcpy(nx, c->nx.data(), n * 8);
-    if (ny) memcpy(ny, c->ny.data(), n * 8);
+    const std::vector<double> *src[4] = {&c->pr_x, &c->pr_y, &c->nx, &c->ny};
+    double *dst[4] = {pr_x, pr_y, nx, ny};
+    for (int k = 0; k < 4; ++k) {
+        if (!dst[k]) continue;
+        for (size_t i = 0; i < n; ++i) dst[k][i] = (*src[k])[c->reversed ? n - 1 - i : i];
+    }
     return BF_OK;
 }
 
@@ -226,9 +244,13 @@ int bf_commit_upload(bf_ctx *c) {
     c->fx = c->pend_x; c->fy = c->pend_y; c->t = c->pend_t;
     c->noise.assign(n, 0);
     c->pr_x.assign(n, 0); c->pr_y.assign(n, 0); c->nx.assign(n, 0); c->ny.assign(n, 0);
+    c->reversed = true;
+    if (flip_order()) {
+        reverse_vec(c->fx); reverse_vec(c->fy); reverse_vec(c->t);
+        c->reversed = false;
+    }
     c->bind();
     c->have_window = false;
-    c->reversed = true;
     return BF_OK;
 }
 

@@ -219,15 +219,35 @@ def test_run_warm_start(oracle_lib, accel_mod):
     u, v = acc.compute_uv()
     ou, ov = oc2.compute_uv()
     assert _flow_close(u, ou) and _flow_close(v, ov)
-    # The chained GPU estimate (own cold model -> warm) lands on the same solution, but only
-    # to the looseness of the loop's own stopping rule (|rot/rot_div| < 1e-4, |div/div_div| <
-    # 1e-1, optimizer_rolling.h:81-84): different starting points stop at slightly different
-    # rot / div, which moves per-event flow by a few 0.1 px/s.  Not a parity bar, a sanity bar.
+    # The chained estimate (own cold model -> warm start, the way dvs_flow.h:218-224 runs) against the oracle's own
+    # chain.  Yardstick: the oracle chain run on the same two slices in reversed event order (the reference's f32 time
+    # sums depend on the order, accel_lib.h:162); the GPU chain must agree with the oracle chain within north_star's
+    # bar (1e-4 / 0.02 px/s) or 4 x the oracle's own forward / reversed spread, whichever is larger.
+    def oracle_chain(rev):
+        sel = slice(None, None, -1) if rev else slice(None)
+        c1 = oracle_lib.Cloud(a["fr_x"][sel].copy(), a["fr_y"][sel].copy(), a["t"][sel].copy())
+        m1 = oracle_lib.Model()
+        c1.run(c1.set_cloud(3, H, W), m1, res_x=H, res_y=W)
+        c2 = oracle_lib.Cloud(b["fr_x"][sel].copy(), b["fr_y"][sel].copy(), b["t"][sel].copy())
+        w2 = c2.set_cloud(3, H, W)
+        m2 = c2.set_model(m1)
+        _, lp2, _ = c2.run(w2, m2, res_x=H, res_y=W)
+        uu, vv = c2.compute_uv()
+        return lp2.itercount, uu[sel], vv[sel]
+    it_f, uf, vf = oracle_chain(False)
+    it_r, ur, vr = oracle_chain(True)
     acc.set_cloud(3, H, W)
     acc.set_model(gm)
-    acc.run(opts)
+    _, _, info_c = acc.run(opts)
     u2, v2 = acc.compute_uv()
-    assert _flow_close(u2, ou, rel=5e-3, abs_=1.0) and _flow_close(v2, ov, rel=5e-3, abs_=1.0)
+    yard = max(np.abs(uf - ur).max(), np.abs(vf - vr).max())
+    dev = max(np.abs(u2 - uf).max(), np.abs(v2 - vf).max())
+    print("chained warm start: GPU vs oracle chain %.3e px/s (iterations %d vs %d), oracle forward vs reversed %.3e px/s "
+          "(iterations %d vs %d)" % (dev, info_c.iterations, it_f, yard, it_f, it_r))
+    # (this pair of slices: the oracle itself needs 8 iterations forward and 11 reversed, and lands 0.29 px/s apart)
+    assert abs(info_c.iterations - it_f) <= abs(it_f - it_r) + 1
+    for g_, o_ in ((u2, uf), (v2, vf)):
+        assert np.all(np.abs(g_ - o_) <= np.maximum(np.maximum(1e-4 * np.abs(o_), 0.02), 4.0 * yard))
     acc.close()
 
 
@@ -455,6 +475,7 @@ def test_tile_grid_matches_per_tile_oracle(oracle_lib, accel_mod):
     tc = np.minimum(sl["fr_y"].astype(np.int64) * G // W, G - 1)
     tid = tr * G + tc
     ran = skipped = 0
+    worst = [0.0, 0.0]
     for k in range(G * G):
         sel = np.nonzero(tid == k)[0]
         oc = oracle_lib.Cloud(sl["fr_x"][sel], sl["fr_y"][sel], sl["t"][sel])
@@ -472,10 +493,10 @@ def test_tile_grid_matches_per_tile_oracle(oracle_lib, accel_mod):
         ran += 1
         assert abs(infos[k].iterations - oloop.itercount) <= 1, (k, infos[k].iterations, oloop.itercount)
         ou, ov = oc.compute_uv()
-        if infos[k].iterations == oloop.itercount:
-            assert _flow_close(u[sel], ou, rel=1e-4, abs_=0.05) and _flow_close(v[sel], ov, rel=1e-4, abs_=0.05), k
-        else:
-            assert _flow_close(u[sel], ou, rel=5e-3, abs_=1.0) and _flow_close(v[sel], ov, rel=5e-3, abs_=1.0), k
+        worst[0 if infos[k].iterations == oloop.itercount else 1] = max(
+            worst[0 if infos[k].iterations == oloop.itercount else 1], np.abs(u[sel] - ou).max(), np.abs(v[sel] - ov).max())
+        assert _flow_close(u[sel], ou) and _flow_close(v[sel], ov), (k, infos[k].iterations, oloop.itercount)
+    print("tile grid: worst per-event flow deviation %.3e px/s (same iteration count) / %.3e px/s (count off by one)" % tuple(worst))
     assert ran >= G * G // 2, (ran, skipped)
     # the run is repeatable bit for bit (integer accumulators, fixed reduction order)
     acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])

@@ -89,6 +89,28 @@ def test_cli_config1_oracle(oracle_cli, events_txt, tmp_path):
     assert parse_summary(stdout3)[2] > iters
 
 
+def test_oracle_chain_order_spread(oracle_cli, events_txt, tmp_path):
+    """How far the ORACLE moves when nothing but the event order inside every slice changes (the reference's time
+    image is an f32 running sum in container order, accel_lib.h:162), over the whole config-1 STM chain: the yardstick
+    for any bar put on a GPU-vs-oracle comparison of this chain.  It is four orders of magnitude below north_star's
+    1e-4 / 0.02 px/s, so that bar is used as it stands (test_cli_gpu_matches_oracle_cli)."""
+    path, sl = events_txt
+    for extra in ([], ["--stm-disable"], ["--max-iter=10"]):
+        outs = []
+        for order in ("forward", "reversed"):
+            out = str(tmp_path / ("o_%s.txt" % order))
+            env = dict(os.environ, BF_SHIM_EVENT_ORDER=order)
+            r = subprocess.run([oracle_cli] + extra + ["-o", out, path], cwd=str(tmp_path), env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            outs.append((parse_summary(r.stdout.decode()), np.loadtxt(out)))
+        (sa, a), (sb, b) = outs
+        assert sa == sb                                    # same slices, same iteration counts
+        assert np.array_equal(a[:, :4], b[:, :4])
+        spread = max(np.abs(a[:, 4] - b[:, 4]).max(), np.abs(a[:, 5] - b[:, 5]).max())
+        assert 0.0 < spread < 1e-4, (extra, spread)        # order matters, at the 1e-6 px/s level
+
+
 @pytest.mark.gpu
 def test_cli_gpu_matches_oracle_cli(oracle_cli, events_txt, tmp_path):
     path, sl = events_txt
@@ -100,15 +122,16 @@ def test_cli_gpu_matches_oracle_cli(oracle_cli, events_txt, tmp_path):
         sg = run_cli(gpu_cli, extra + ["-o", g_out, path], str(tmp_path))
         os_, og_ = parse_summary(so), parse_summary(sg)
         assert os_[:2] == og_[:2], (extra, os_, og_)              # same slices, same skip decisions
-        assert abs(os_[2] - og_[2]) <= 2 * os_[0], (extra, os_, og_)   # iteration counts within +-2 per slice
+        assert abs(os_[2] - og_[2]) <= os_[0], (extra, os_, og_)   # iteration counts within +-1 per slice
         a, b = np.loadtxt(o_out), np.loadtxt(g_out)
         assert a.shape == b.shape
         assert np.array_equal(a[:, :4], b[:, :4])
-        # chained warm starts: solution-level agreement (see test_run_warm_start)
+        # The whole STM chain (4 slices, each warm-started from the previous model) at north_star's bar: 1e-4 relative
+        # or 0.02 px/s.  Measured (scripts/chain_spread.py): GPU vs oracle <= 7e-6 px/s on every flag set, the same
+        # size as the oracle's own forward / reversed event-order spread (4e-6 px/s, test_oracle_chain_order_spread).
         for col in (4, 5):
             d = np.abs(a[:, col] - b[:, col])
-            assert np.all(d <= np.maximum(5e-3 * np.abs(a[:, col]), 1.0)), (extra, col, d.max())
-            assert abs(a[:, col].mean() - b[:, col].mean()) < 0.05
+            assert np.all(d <= np.maximum(1e-4 * np.abs(a[:, col]), 0.02)), (extra, col, d.max())
     # ... and against the committed golden run (no oracle involved): default flags
     import json
     gold = os.path.join(ROOT, "tests", "golden")
@@ -116,12 +139,11 @@ def test_cli_gpu_matches_oracle_cli(oracle_cli, events_txt, tmp_path):
     zs = np.load(os.path.join(gold, man["file"]))
     g_out = str(tmp_path / "g2.txt")
     sg = parse_summary(run_cli(gpu_cli, ["-o", g_out, path], str(tmp_path)))
-    assert sg[:2] == (man["cli"]["slices"], man["cli"]["skipped"]) and abs(sg[2] - man["cli"]["iterations"]) <= 2 * sg[0]
+    assert sg[:2] == (man["cli"]["slices"], man["cli"]["skipped"]) and abs(sg[2] - man["cli"]["iterations"]) <= sg[0]
     b = np.loadtxt(g_out)
     assert np.array_equal(b[:, 0], zs["cli_t"]) and np.array_equal(b[:, 1].astype(np.int32), zs["cli_x"])
     for col, key in ((4, "cli_v"), (5, "cli_u")):
-        assert np.all(np.abs(b[:, col] - zs[key]) <= np.maximum(5e-3 * np.abs(zs[key]), 1.0))
-        assert abs(b[:, col].mean() - zs[key].mean()) < 0.05
+        assert np.all(np.abs(b[:, col] - zs[key]) <= np.maximum(1e-4 * np.abs(zs[key]), 0.02))
     # the library identifies itself as the HIP build, not the test shim
     ver = subprocess.check_output([gpu_cli, "--version"]).decode()
     assert "gfx950" in ver and "SHIM" not in ver

@@ -84,8 +84,6 @@ class Profile(C.Structure):
         ("update_ms", C.c_double), ("update_launches", C.c_uint64),
         ("other_ms", C.c_double), ("other_launches", C.c_uint64),
         ("warp_scatter_events", C.c_uint64),
-        ("persist_ms", C.c_double), ("persist_launches", C.c_uint64),
-        ("persist_iterations", C.c_uint64), ("persist_events", C.c_uint64),
     ]
 
 

@@ -52,18 +52,11 @@ struct bf_ctx {
     int opt_binned = 1;              // 0 never, 1 when it pays (dense enough), 2 whenever possible
     bool opt_bin_predict = true;
     int opt_bin_tile = 0, opt_bin_margin = 8, opt_bin_threads = 1024;   // bin_tile 0: chosen per slice
-    bool opt_co_schedule = false;    // several slice contexts share the GPU: favour co-residency over single-slice speed
+    bool opt_co_schedule = false;    // several slice contexts share the GPU: the update runs in the stencil kernel's last work-group
     int opt_bin_pack_limit = 64;     // bits available to the per-bin packing (lower only to test the fallback)
     int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
     int n_cus = 0;
     bool use_binned = false;         // decided per slice in bf_set_cloud
-    // whole loop in one cooperative launch (bf_persist.hip)
-    bool opt_persist = false;        // measured slower than the multi-kernel loop: opt-in
-    int opt_persist_threads = 1024;
-    bool use_persist = false;        // decided per slice in bf_set_cloud
-    unsigned int* d_bar = nullptr;   // grid-barrier counters
-    int persist_key[3] = {0, 0, 0};  // (L, scale, threads) the cached co-residency limit is for
-    int persist_max = 0;
     BinGrid grid;
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
@@ -91,11 +84,12 @@ struct bf_ctx {
     uint32_t* d_cplane[2] = {nullptr, nullptr};
     float *d_time = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_img = nullptr;
     uint32_t* d_count = nullptr;
-    Partial* d_partials = nullptr;
+    MomentAcc* d_acc = nullptr;      // 2 x kAccGroups exact moment accumulators (parity of the iteration)
+    uint32_t* d_ovf = nullptr;       // tile-binned loop: overflow events of iteration j in slot j % 3
     unsigned int* d_ticket = nullptr;
     unsigned long long* d_tl = nullptr;   // debug timeline (BF_TIMELINE=<file>, `make tl` build)
     const char* tl_path = nullptr;
-    DevState* d_state = nullptr;
+    DevState* d_state = nullptr;     // 2 buffers: the tile-binned loop ping-pongs, everything else uses [0]
     SliceStats* d_stats = nullptr;
     bf_trace_rec* d_trace = nullptr;
     int trace_alloc = 0;
@@ -128,6 +122,7 @@ struct bf_ctx {
     bool degenerate = false;         // window with R <= 0 or C <= 0 (empty slice)
     bool pending_warp = false;       // bf_set_model's warp not applied yet
     bool n_valid = false;            // d_nxny holds the n of the last warp
+    uint32_t run_counter = 0;
     int warm_iters_hint = 6;         // iterations the previous warm-started run needed
     bool p_clean = false;            // p is all zero (Event::reset state): set by the upload, cleared by any warp
     bool out_sorted = false;         // d_nxny (and d_uv) are in slot order: un-permute with set[cs].perm before reading back
@@ -213,7 +208,6 @@ int prof_fold(bf_ctx* c) {
                     c->prof.warp_scatter_events += (uint64_t)r.nev; break;
             case 1: c->prof.stencil_ms += ms; c->prof.stencil_launches++; break;
             case 2: c->prof.update_ms += ms; c->prof.update_launches++; break;
-            case 4: c->prof.persist_ms += ms; c->prof.persist_launches++; break;
             default: c->prof.other_ms += ms; c->prof.other_launches++; break;
         }
         c->ev_pool.push_back(r.a);
@@ -280,8 +274,8 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.zero_cplane = (c->packed && !c->use_binned) ? nullptr : c->d_cplane[buf ^ 1];
     a.slabs = c->d_slabs;
     a.g = c->grid;
+    a.ovf_cur = a.ovf_prev = c->d_ovf;   // (the tile-binned loop sets the three counters per launch)
     a.cur = buf;
-    a.co_schedule = c->opt_co_schedule ? 1 : 0;
     return a;
 }
 
@@ -348,9 +342,9 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
 
 // Device-conditional counting sort of the live events by the image tile of their current
 // target (runs only when hot.need_rebin is set); no host synchronisation.
-int enqueue_rebin(bf_ctx* c, bool has_perm_at_start, const WarpParams* prewarp = nullptr) {
+int enqueue_rebin(bf_ctx* c, DevState* st, bool has_perm_at_start, const WarpParams* prewarp = nullptr) {
     ProfScope ps(c, 3);
-    launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, c->d_state, c->grid, c->d_binid, c->d_hist_cnt,
+    launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, st, c->grid, c->d_binid, c->d_hist_cnt,
                  c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->opt_bin_pack_limit, c->stream);
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
@@ -515,15 +509,18 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMalloc(&c->d_gy, c->cap_px * sizeof(float)));
         HIP_TRY(c, hipMalloc(&c->d_img, c->cap_px * sizeof(float)));
         HIP_TRY(c, hipMalloc(&c->d_count, c->cap_px * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_partials, (size_t)c->cap_blocks * sizeof(Partial)));
-        HIP_TRY(c, hipMalloc(&c->d_state, sizeof(DevState)));
+        HIP_TRY(c, hipMalloc(&c->d_acc, 2 * kAccGroups * sizeof(MomentAcc)));
+        HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, 2 * kAccGroups * sizeof(MomentAcc), c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_ovf, 64));
+        HIP_TRY(c, hipMemsetAsync(c->d_ovf, 0, 64, c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_state, 2 * sizeof(DevState)));
         HIP_TRY(c, hipMalloc(&c->d_ticket, 16 * 64 * sizeof(unsigned int)));   // 1 + 32 counters, 64 B apart
         HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, 16 * 64 * sizeof(unsigned int), c->stream));
         HIP_TRY(c, hipMalloc(&c->d_stats, kPrepBlocks * sizeof(SliceStats)));
         HIP_TRY(c, hipHostMalloc(&c->h_state, 2 * sizeof(DevState), hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
         HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
-        HIP_TRY(c, hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_state, 0, 2 * sizeof(DevState), c->stream));
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
             HIP_TRY(c, hipMalloc(&c->d_tl, 3 * 64 * 2 * 16 * sizeof(unsigned long long)));
@@ -566,10 +563,10 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_bar, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
-                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_partials, c->d_ticket, c->d_state, c->d_stats,
+                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_ticket, c->d_state, c->d_stats,
                     c->d_trace};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -597,15 +594,6 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         if (value != 0 && value != 16 && value != 32 && value != 64 && value != 128)
             return fail(c, BF_ERR_ARG, "bin_tile must be 0 (auto), 16, 32, 64 or 128");
         c->opt_bin_tile = (int)value;
-        return BF_OK;
-    }
-    if (!strcmp(key, "persist")) {
-        c->opt_persist = value != 0;
-        return BF_OK;
-    }
-    if (!strcmp(key, "persist_threads")) {
-        if (value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "persist_threads must be 512 or 1024");
-        c->opt_persist_threads = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "bin_pack_limit")) {
@@ -908,8 +896,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         // "bin_tile" / "bin_tile_rows" override.
         g.TS = c->opt_bin_tile > 0 ? c->opt_bin_tile : 64;
         g.TSR = c->opt_bin_tile_rows > 0 ? c->opt_bin_tile_rows : (g.TS < 32 ? 32 : g.TS);
-        if (c->n_cus > 0 && !c->opt_persist && (c->opt_bin_tile <= 0 || c->opt_bin_tile_rows <= 0)) {
-            // (the single-launch loop is written for square 64 x 64 tiles: no search with "persist")
+        if (c->n_cus > 0 && (c->opt_bin_tile <= 0 || c->opt_bin_tile_rows <= 0)) {
             const double density = (double)c->n / ((double)w.scale_img_x * (double)w.scale_img_y);
             double best = -1.0;
             int best_area = 0;
@@ -945,22 +932,12 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         const bool dense = (double)w.scale_img_x * (double)w.scale_img_y < 12.0 * (double)c->n;
         c->use_binned = (c->opt_binned == 2 || (c->opt_binned == 1 && dense)) && !c->force_split && !c->has_noise && c->n > 0 &&
                         g.nbins <= 8192 &&
-                        (size_t)g.LR * g.L * 8 <= 160 * 1024 && w.scale_img_x < (1 << 20);
+                        (size_t)g.LR * g.L * 8 <= (size_t)kBinTileLdsMax && w.scale_img_x < (1 << 20);
         if (c->use_binned) {
             int rc = ensure_cplanes(c);
             if (rc == BF_OK) rc = ensure_bin_buffers(c, g);
             if (rc != BF_OK) return rc;
             c->grid = g;
-        }
-        c->use_persist = false;
-        if (c->use_binned && c->opt_persist) {
-            const int key[3] = {g.L * 1024 + g.LR, scale, c->opt_persist_threads};
-            if (memcmp(key, c->persist_key, sizeof(key)) != 0) {
-                c->persist_max = persist_max_groups(g, scale, c->opt_persist_threads, c->device);
-                memcpy(c->persist_key, key, sizeof(key));
-            }
-            c->use_persist = g.nbins <= c->persist_max;
-            if (c->use_persist && !c->d_bar) HIP_TRY(c, hipMalloc(&c->d_bar, 4096));
         }
         h.hot.binned = c->use_binned ? 1 : 0;
         h.n_events = (uint32_t)c->n;
@@ -1051,7 +1028,12 @@ static int image_pass(bf_ctx* c, const float* d_src, int rows, int cols, bool gr
     a.R = rows; a.C = cols; a.scale = 1;
     a.time_in = d_src;
     if (grads) { a.gx_out = c->d_gx; a.gy_out = c->d_gy; }
-    if (moments) a.partials = c->d_partials;
+    if (moments) {   // sums -> exact accumulators; the last work-group forms the model (mode 0)
+        a.acc = c->d_acc;
+        a.ticket = c->d_ticket;
+        a.st_rw = c->d_state;
+        a.update_mode = 0;
+    }
     ProfScope ps(c, 1);
     launch_stencil(a, 2, c->stream);
     return BF_OK;
@@ -1091,14 +1073,10 @@ int bf_fast_model(bf_ctx* c, const float* img, int32_t rows, int32_t cols, bf_mo
     int gx, gy;
     stencil_grid(rows, cols, &gx, &gy);
     if (gx * gy > c->cap_blocks) return fail(c, BF_ERR_CAPACITY, "image needs %d tiles", gx * gy);
-    image_pass(c, src, rows, cols, false, true);
     DevState tmp = c->hst;
     tmp.hot.R = rows; tmp.hot.C = cols;
     launch_set_state(c->d_state, tmp, c->stream);
-    {
-        ProfScope ps(c, 2);
-        launch_update(c->d_state, c->d_partials, gx * gy, nullptr, 0, 0, c->stream);
-    }
+    image_pass(c, src, rows, cols, false, true);
     HIP_TRY(c, hipGetLastError());
     int rc = d2h_state(c);
     if (rc != BF_OK) return rc;
@@ -1269,6 +1247,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     h.rot_div = h.div_div = 10000.0f;    // :62-63
     h.old_dx = h.old_dy = h.old_rot = h.old_div = 0.f;
     h.hot.it = 0; h.hot.done = 0; h.rc = 0;
+    h.run_tag = (int32_t)((++c->run_counter & 0x3fffffff) | 0x40000000);   // `done` is set to this (non-zero) tag
     h.max_iter = o.max_iter;
     h.hard_cap = o.hard_iter_cap;
     h.trace_cap = o.trace_cap;
@@ -1287,80 +1266,45 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     bf_trace_rec* trace = o.trace_cap > 0 ? c->d_trace : nullptr;
     int launched_iters = 0;
     DevState fin;
-    const bool persist = c->use_persist && binned;
-    if (persist) {
-        // The whole loop in one cooperative launch; it comes back when the loop is done or the
-        // update wants the events re-sorted (the device-gated re-bin kernels that follow do it).
-        int gx, gy;
-        stencil_grid(w.scale_img_x, w.scale_img_y, &gx, &gy);
-        for (int round = 0;; ++round) {
-            int rc = enqueue_rebin(c, perm_at_start, (prewarp && round == 0) ? &prewarp_wp : nullptr);   // round 0: builds the bins
-            if (rc != BF_OK) return rc;
-            HIP_TRY(c, hipMemsetAsync(c->d_bar, 0, 4096, c->stream));
-            PersistArgs pa;
-            memset(&pa, 0, sizeof(pa));
-            pa.sets = ev_sets(c);
-            pa.bin_start = c->d_bin_start;
-            pa.slabs = c->d_slabs;
-            for (int i = 0; i < 2; ++i) { pa.ovf_plane[i] = c->d_plane[i]; pa.ovf_cplane[i] = c->d_cplane[i]; }
-            pa.st = c->d_state;
-            pa.partials = reinterpret_cast<unsigned long long*>(c->d_partials);
-            pa.bar = c->d_bar;
-            pa.trace = trace;
-            pa.tl = c->d_tl;
-            pa.g = c->grid;
-            pa.cur0 = buf;
-            pa.first_nowarp = (first && !first_warp) ? 1 : 0;
-            pa.max_iters = INT_MAX;
-            pa.gx = gx; pa.gy = gy;
-            {
-                ProfScope ps(c, 4);
-                HIP_TRY(c, launch_persist(pa, w.scale, c->opt_persist_threads, c->stream));
-            }
-            inf.launches += 5;
-            HIP_TRY(c, hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(DevState), hipMemcpyDeviceToHost,
-                                      c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            inf.polls++;
-            const DevState& snap = c->h_state[0];
-            if (c->prof_mode == 1) {
-                c->prof.persist_iterations += (uint64_t)(snap.hot.it - launched_iters);
-                c->prof.persist_events += (uint64_t)(snap.hot.it - launched_iters) * (uint64_t)c->n;
-            }
-            if (snap.hot.it == launched_iters && !snap.hot.done)
-                return fail(c, BF_ERR_HIP, "single-launch loop made no progress (grid barrier timed out?)");
-            launched_iters = snap.hot.it;
-            buf = b0 ^ (snap.hot.it & 1);
-            first = false;
-            if (snap.hot.done) {
-                fin = snap;
-                break;
-            }
-            if (round > 100000) return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
-        }
-    }
+    // Tile-binned loop: the update of iteration j runs at the head of warp+scatter launch j + 1, so the state
+    // ping-pongs between two buffers (launch j reads [j & 1], writes [(j + 1) & 1]), the moment accumulators alternate
+    // with the iteration's parity, and the overflow events of iteration j are counted in slot j % 3 (slot 2 stands
+    // for "iteration -1": is plane buffer b0 ^ 1 still dirty from an earlier operator?).
+    auto state_of = [&](int j) { return c->d_state + (j & 1); };
+    auto acc_of = [&](int j) { return c->d_acc + (size_t)(j & 1) * kAccGroups; };
+    auto ovf_of = [&](int j) { return c->d_ovf + ((j % 3) + 3) % 3; };
+    if (binned) launch_loop_init(c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, c->stream);
+    // Where the model / loop update runs.  One slice context alone: at the head of the next warp+scatter launch (every
+    // work-group for itself; shortest iteration).  Several contexts sharing the GPU ("co_schedule"): in the last
+    // work-group of the stencil kernel -- a serial tail on ONE CU that the other contexts' kernels fill, instead of
+    // ~1.5 us on all 256 CUs.
+    const bool head_update = binned && !c->opt_co_schedule;
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
     bool want_rebin = false;
+    int last_rebin_at = 0;
+    const bool snap_polled = binned && !warm_start;   // progress is read from the pinned snapshot (below)
+    if (snap_polled) *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
     bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
     static const bool host_timing = getenv("BF_HOST_TIMING") != nullptr;   // debug: where the host thread's time goes
     double ht_launch = 0, ht_wait = 0;
     auto ht_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double ht_mark = host_timing ? ht_now() : 0;
-    for (int batch = 0; !persist; ++batch) {
+    for (int batch = 0;; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
         // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
         // when a polled snapshot shows the update asking for one.  The request is predictive
         // (0.6 x margin of drift), which covers the one-to-two batches of polling lag; anything
         // that still escapes takes the exact overflow path.
         if (binned && (batch == 0 || want_rebin)) {
-            int rc = enqueue_rebin(c, perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr);
+            int rc = enqueue_rebin(c, state_of(launched_iters), perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr);
             if (rc != BF_OK) return rc;
             inf.launches += 3;
             want_rebin = false;
             skip_rebin_checks = 1;   // the next snapshot predates this re-bin
+            last_rebin_at = launched_iters;
         }
         // A warm start (bf_set_model) converges in a handful of iterations: its first batch is short and is
         // polled at once, so that ~20 no-op launches and a second poll are not queued behind it.
@@ -1372,20 +1316,44 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         }
         for (int k = 0; k < batch_len; ++k) {
             const bool warp = first ? first_warp : true;
+            const int j = launched_iters;
             if (binned) {
+                BinScatterArgs ba;
+                ba.sets = ev_sets(c);
+                ba.bin_start = c->d_bin_start;
+                ba.slabs = c->d_slabs;
+                ba.ovf_plane = c->d_plane[buf]; ba.ovf_cplane = c->d_cplane[buf];
+                ba.st_in = state_of(j); ba.st_out = state_of(j + 1);
+                ba.acc = head_update ? acc_of(j - 1) : nullptr;
+                ba.ovf_cur = ovf_of(j); ba.ovf_prev = ovf_of(j - 1);
+                ba.snap = warm_start ? nullptr : &c->h_state[0];
+                ba.trace = trace;
+                ba.g = c->grid;
+                ba.cur = buf; ba.j = j;
+                ba.tl = c->d_tl ? c->d_tl + 64 * 2 * 16 : nullptr;
                 ProfScope ps(c, 0, c->n);
-                launch_bin_warp_scatter(ev_sets(c), c->d_bin_start, c->d_slabs, c->d_plane[buf],
-                                        c->d_cplane[buf], c->d_state, c->grid, buf, warp, 1, c->opt_bin_threads,
-                                        c->d_tl ? c->d_tl + 64 * 2 * 16 : nullptr, launched_iters, c->stream);
+                launch_bin_warp_scatter(ba, warp, c->opt_bin_threads, c->stream);
             } else {
                 ProfScope ps(c, 0, c->n);
                 launch_warp_scatter(ws_args(c, buf, 1), warp, true, false, c->stream);
             }
             {   // stencil + moments; its last work-group reduces and runs the model / loop update
                 StencilArgs a = st_args(c, buf, 1);
-                a.partials = c->d_partials;
-                a.ticket = c->d_ticket;
-                a.st_rw = c->d_state;
+                if (binned) {
+                    a.st = state_of(j + 1);
+                    a.ovf_cur = ovf_of(j); a.ovf_prev = ovf_of(j - 1); a.ovf_next = ovf_of(j + 1);
+                }
+                if (head_update) {   // accumulate only: the update runs at the head of the next warp+scatter launch
+                    a.acc = acc_of(j); a.acc_zero = acc_of(j + 1);
+                } else if (binned) {   // "co_schedule": the last work-group of the stencil kernel updates
+                    a.acc = c->d_acc;
+                    a.ticket = c->d_ticket;
+                    a.st_rw = state_of(j + 1);
+                } else {        // the last work-group reduces and updates
+                    a.acc = c->d_acc;
+                    a.ticket = c->d_ticket;
+                    a.st_rw = c->d_state;
+                }
                 a.trace = trace;
                 a.update_mode = 1;
                 a.tl = c->d_tl;
@@ -1403,8 +1371,14 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // final warp rides along with every batch, gated on `done` (check_done 2) and picking the event
             // set on the device: when the batch was enough -- the usual case -- nothing is left to launch
             // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
+            if (head_update) {   // `done` of the batch's last iteration: apply its update now (normally the next launch would)
+                launch_finish_update(state_of(launched_iters), acc_of(launched_iters - 1), ovf_of(launched_iters - 1),
+                                     launched_iters, buf ^ 1, trace, c->stream);
+                inf.launches++;
+            }
             ProfScope ps(c, 3);
             WarpScatterArgs fa = ws_args(c, buf, 2);
+            fa.st = state_of(binned ? launched_iters : 0);
             fa.pick_set = binned ? 1 : 0;
             fa.sorted_out = 1;
             if (o.want_uv) fa.uv = c->d_uv;
@@ -1412,7 +1386,42 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             inf.launches++;
         }
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState),
+        if (snap_polled) {
+            // Tile-binned cold run: no copy command, no event.  Work-group 0 of every warp+scatter launch writes the state
+            // it has just computed to pinned host memory as well; its first 8-byte word -- (done, it), one lane's store
+            // -- tells the host how far the device is and whether the loop is over (`done` carries this run's tag: a
+            // straggler launch of an earlier run on this context cannot be mistaken for it).  The host enqueues the next batch
+            // when less than one batch is left in the queue and sleeps in between (the queue hides its wake-up latency).
+            const volatile unsigned long long* w0p = reinterpret_cast<const volatile unsigned long long*>(&c->h_state[0]);
+            const volatile int32_t* rebin_p = &c->h_state[0].hot.need_rebin;
+            bool done_seen = false;
+            int gpu_it = 0;
+            if (host_timing) { const double t = ht_now(); ht_launch += t - ht_mark; ht_mark = t; }
+            for (long spins = 0;; ++spins) {
+                const unsigned long long w0 = *w0p;
+                const int32_t sdone = (int32_t)(uint32_t)(w0 & 0xffffffffull), sit = (int32_t)(uint32_t)(w0 >> 32);
+                if (sdone == h.run_tag) { done_seen = true; break; }
+                gpu_it = (sdone == 0) ? sit : 0;
+                if (launched_iters - gpu_it <= o.poll_interval) break;   // less than a batch left in the queue: feed it
+                if (c->opt_blocking_poll) {
+                    struct timespec ts = {0, 20000};
+                    nanosleep(&ts, nullptr);
+                }
+                if (spins > 2000000) {   // > 40 s without progress
+                    const hipError_t e = hipStreamQuery(c->stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(c, e);
+                    return fail(c, BF_ERR_HIP, "device loop makes no progress");
+                }
+            }
+            if (host_timing) { const double t = ht_now(); ht_wait += t - ht_mark; ht_mark = t; }
+            inf.polls++;
+            if (done_seen) break;
+            if (gpu_it >= last_rebin_at && gpu_it > 0 && *rebin_p) want_rebin = true;   // (a snapshot older than the last re-bin does not count)
+            if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
+                return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
+            continue;
+        }
+        HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], state_of(binned ? launched_iters : 0), sizeof(DevState),
                                   hipMemcpyDeviceToHost, c->stream));
         // A cold run is polled one batch behind the launches, so its wait can sleep (the wake-up latency hides
         // behind the batch already queued) instead of burning a host core per slice context; a warm start waits
@@ -1456,19 +1465,32 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (host_timing)
         fprintf(stderr, "bf_run host time: launching %.3f ms, waiting %.3f ms, %d launches\n", 1e3 * ht_launch,
                 1e3 * ht_wait, (int)inf.launches);
-    if (binned) {   // the device chose which set holds the (tile-sorted) events
-        c->cs = fin.hot.cs;
-        c->has_perm = true;
-    }
     // final warp: the last project_4param_reinit of iteration_step (:340-344), kept so that
     // pr / nx / ny describe the converged model; n is written for compute_uv / writeout.
     if (!final_done) {
         ProfScope ps(c, 3);
         WarpScatterArgs fa = ws_args(c, buf, 0);
+        fa.st = state_of(binned ? launched_iters : 0);   // (after `done` every launch keeps both buffers identical)
+        fa.pick_set = binned ? 1 : 0;                    // the device knows which set holds the (tile-sorted) events
         fa.sorted_out = 1;
         if (o.want_uv) fa.uv = c->d_uv;   // Event::compute_uv (event.h:135-142) in the same pass
         launch_warp_scatter(fa, true, false, true, c->stream);
         inf.launches++;
+    }
+    if (snap_polled) {   // the final state, consistently: behind everything that is queued
+        HIP_TRY(c, hipMemcpyAsync(&c->h_state[1], state_of(launched_iters), sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(c->poll_ev[1], c->stream));
+        if (c->opt_blocking_poll) {
+            int rcw = wait_event_sleeping(c, c->poll_ev[1]);
+            if (rcw != BF_OK) return rcw;
+        } else {
+            HIP_TRY(c, hipEventSynchronize(c->poll_ev[1]));
+        }
+        fin = c->h_state[1];
+    }
+    if (binned) {   // the device chose which set holds the (tile-sorted) events
+        c->cs = fin.hot.cs;
+        c->has_perm = true;
     }
     if (warm_start) c->warm_iters_hint = fin.hot.it;
     c->n_valid = true;
@@ -1479,6 +1501,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
 
     const DevState d = fin;
     h = d;   // model, dividers, warp parameters, plane-buffer dirtiness
+    if (binned) {   // the last iteration scattered its overflow events into buffer b0 ^ ((it - 1) & 1); the other one is clean
+        h.hot.ovf_cnt[b0 ^ (d.hot.it & 1)] = 0;
+        h.hot.ovf_cnt[b0 ^ (d.hot.it & 1) ^ 1] = d.last_ovf ? 1u : 0u;
+    }
 
     // iterations executed alternate buffers starting at b0; the next scatter goes to the
     // buffer the last stencil left clean.
@@ -1591,7 +1617,6 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
     c->degenerate = false;
     c->use_binned = false;    // the events are now sorted by sensor tile, not by image tile
-    c->use_persist = false;
     return BF_OK;
 }
 

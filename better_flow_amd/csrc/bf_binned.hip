@@ -256,54 +256,271 @@ __global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_p
     }
 }
 
-// K1 (binned): warp + LDS scatter + slab flush, one work-group per bin.
-template <bool WARP, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
-    EvSets sets, const uint32_t* __restrict__ bin_start, unsigned long long* __restrict__ slabs,
-    unsigned long long* __restrict__ ovf_plane, uint32_t* __restrict__ ovf_cplane, DevState* st,
-    BinGrid g, int cur, int check_done, unsigned long long* tl, int tl_launch) {
-    extern __shared__ unsigned long long s_tile[];
-    const int L = g.L, LR = g.LR, LL = g.LR * g.L;
-    const int b = blockIdx.x;
-    tl_stamp(tl, tl_launch, 0);
-#ifdef BF_TIMELINE
-    // per-work-group stamps of launch 20 (third 2048-entry block of the timeline buffer; tl points at the second)
-    unsigned long long* tlw = (tl && tl_launch == 20 && b < 512 && threadIdx.x == 0) ? tl + 2048 + b * 4 : nullptr;
-    if (tlw) tlw[0] = wall_clock64();
-#endif
-    // everything the block needs from global memory is requested up front, in one burst
-    const uint32_t beg = bin_start[b], end = bin_start[b + 1];
-    const HotState hs = st->hot;
-    const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
-    {   // zero the LDS tile, 16 bytes per lane (overlaps the scalar loads above)
-        ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
-        for (int i = threadIdx.x; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
+// A structure in LDS -> scalar registers: every lane reads it, v_readfirstlane makes each word uniform (the values a
+// kernel branches and addresses with should not occupy vector registers).
+template <class T>
+__device__ __forceinline__ T lds_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    T out;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
+    return out;
+}
+
+// What the scatter loop needs from the state, in scalar registers.
+struct ScatterHot {
+    int32_t done, bin_tbits, bin_ok, scale, C, wsx, wsy, x_sh, y_sh;
+    long long tmin;
+    WarpParams wp;
+};
+__device__ __forceinline__ int lds_sreg(const int32_t* p) { return __builtin_amdgcn_readfirstlane(*p); }
+__device__ __forceinline__ ScatterHot scatter_hot(const DevState* s) {
+    ScatterHot h;
+    h.done = lds_sreg(&s->hot.done); h.bin_tbits = lds_sreg(&s->hot.bin_tbits); h.bin_ok = lds_sreg(&s->hot.bin_ok);
+    h.scale = lds_sreg(&s->hot.scale); h.C = lds_sreg(&s->hot.C); h.wsx = lds_sreg(&s->hot.wsx); h.wsy = lds_sreg(&s->hot.wsy);
+    h.x_sh = lds_sreg(&s->hot.x_sh); h.y_sh = lds_sreg(&s->hot.y_sh);
+    const long long tm = s->hot.tmin;
+    h.tmin = ((long long)__builtin_amdgcn_readfirstlane((int)(tm >> 32)) << 32) |
+             (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)tm);
+    h.wp = lds_uniform(&s->hot.wp);
+    return h;
+}
+
+constexpr int kStateWords = (int)(sizeof(DevState) / 8);
+
+// One event of the tile-binned scatter, from its previous projected position: warp (event.h:100-108,164-168 -- same
+// arithmetic as k_warp_scatter), store of the new products, splat centre (accel_lib.h:154-158), LDS accumulate or --
+// drifted out of this bin's tile -- the exact overflow path.
+struct ScatterGeo {
+    int X0, Y0, L, LR;
+};
+template <bool WARP>
+__device__ __forceinline__ void scatter_event(const ScatterHot& hs, const ScatterGeo& sg, unsigned long long* s_tile,
+                                              const BinScatterArgs& a, float2* p, uint32_t i, uint32_t v, int32_t ti,
+                                              double pr_x, double pr_y, uint32_t& n_ovf) {
+    const uint32_t fx = v & 0xffffu, fy = v >> 16;
+    if (WARP) {
+        float2 q;
+        double nx, ny;
+        warp_products(hs.wp, pr_x, pr_y, ti, q, nx, ny);
+        // write-through as well (see the slab flush)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&p[i]),
+                           ((unsigned long long)__float_as_uint(q.y) << 32) | (unsigned long long)__float_as_uint(q.x),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pr_x = pr_from_p(fx, q.x);
+        pr_y = pr_from_p(fy, q.y);
     }
-    if (check_done && hs.done) return;
-    tl_stamp(tl, tl_launch, 1);
-    const EvSetPtrs ev = sets.s[hs.cs ^ hs.flip];
+    const int s = hs.scale, hsc = hs.scale / 2;
+    const int X = trunc_x86(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
+    const int Y = trunc_x86(pr_y * (double)s + (double)hs.y_sh);
+    if (!((X >= hs.wsx + hsc) || (X < hsc) || (Y >= hs.wsy + hsc) || (Y < hsc))) {
+        const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
+        const int lx = X - sg.X0, ly = Y - sg.Y0;
+        if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
+            atomicAdd(&s_tile[__mul24(lx, sg.L) + ly], (1ull << hs.bin_tbits) + dt);
+        } else {   // drifted out of this bin's tile: exact, slow path
+            const size_t kk = (size_t)X * (size_t)hs.C + (size_t)Y;
+            atomicAdd(&a.ovf_plane[kk], dt);
+            atomicAdd(&a.ovf_cplane[kk], 1u);
+            ++n_ovf;
+        }
+    }
+}
+
+// The whole tile goes to the bin's slab (nothing to zero, no atomics).  WRITE-THROUGH stores (agent-scope relaxed =
+// global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat dirty in the L2s until the end of the
+// kernel, and their write-back stretched the kernel boundary to ~5.6 us (measured; "B / 6 TB/s" in the MI355X notes).
+// (16 bytes per lane: L is even, so LL is, and a slab starts on a 16-byte boundary)
+template <int THREADS>
+__device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, unsigned long long* slab, int LL, int tid) {
+    const bf_u32x4* src4 = reinterpret_cast<const bf_u32x4*>(s_tile);
+    for (int i = tid; i < LL / 2; i += THREADS) {
+        const bf_u32x4 v = src4[i];
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slab + 2 * i), "v"(v) : "memory");
+    }
+}
+
+// K1 (binned): [pending update] + warp + LDS scatter + slab flush, one work-group per bin.
+//
+// The model / loop update of the tile-binned loop runs HERE.  The stencil kernel of iteration j - 1 only adds its
+// moment sums to the exact accumulators; the total, ObjectModel::update_accumulators, the iteration_step glue and the
+// run() loop control (optimizer_rolling.h:61-101,328-346) are done at the head of launch j (= number of stencil launches
+// completed before it) by every work-group for itself, on an LDS copy of the state written by launch j - 1 (st_in), if
+// the update is still pending (state.it < j; a k_finish_update may have done it).  Work-group 0 stores the new state
+// to st_out, the buffer the stencil kernel of this iteration and launch j + 1 read (ping-pong: a work-group that starts
+// late must still find the OLD state in st_in), and to a pinned host snapshot the host polls (no copy commands in the
+// stream).  The critical part of the update is ~0.6 us of serial f64 arithmetic on one lane, and it is hidden: the
+// accumulators are the first thing requested, the events of the first pass the second, and while the first wave forms
+// the total and updates, the other fifteen turn their events' stored f32 products into the previous positions (the
+// model-independent third of the per-event arithmetic); the first wave catches up after the barrier.
+template <bool WARP, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
+    extern __shared__ unsigned long long s_tile[];
+    __shared__ DevState s_state;
+    const BinGrid& g = a.g;
+    const int L = g.L, LR = g.LR, LL = g.LR * g.L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    tl_stamp(a.tl, a.j, 0);
+    // Everything the block needs from global memory is requested up front, in one burst, and NOTHING is consumed
+    // before the last request is out (vector loads complete in order: consuming the state copy early would also wait
+    // for the accumulators, ~1.1 us away -- they were last written by atomics at the memory side).
+    // (The scalar loads come first in program order: placed after the lane-conditional vector loads, the compiler
+    // carried the state pointer through a vector register and turned them into vector loads -- which complete in order
+    // behind the accumulators.)
+    const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
+    const uint32_t ovf_prev = sload(a.ovf_prev);
+    const int done0 = sload(&a.st_in->hot.done), it0 = sload(&a.st_in->hot.it);
+    const int live_set = sload(&a.st_in->hot.cs) ^ sload(&a.st_in->hot.flip);
+    unsigned long long accv[kAccPerLane];
+    if (a.acc && tid < 64) acc_load_wave<false, false>(a.acc, tid, accv);
+    unsigned long long state_word = 0;
+    if (tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
+    const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
+    auto store_state = [&]() {   // work-group 0, after a barrier: the state for the next launches and for the host
+        if (b == 0 && tid < kStateWords) {
+            const unsigned long long v = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
+            reinterpret_cast<unsigned long long*>(a.st_out)[tid] = v;
+            if (a.snap) reinterpret_cast<unsigned long long*>(a.snap)[tid] = v;
+        }
+    };
+    if (done0) {   // the loop is over: keep both state buffers identical, do nothing else
+        if (tid < kStateWords) reinterpret_cast<unsigned long long*>(&s_state)[tid] = state_word;
+        __syncthreads();
+        store_state();
+        return;
+    }
+    const bool pending = a.acc && it0 < a.j;
+    const EvSetPtrs ev = a.sets.s[live_set];   // (the update's commit of a re-bin flip keeps cs ^ flip)
     const uint32_t* __restrict__ xy = ev.xy;
     const int32_t* __restrict__ t = ev.t;
     float2* __restrict__ p = ev.p;
-    const WarpParams& wp = hs.wp;
-    const int s = hs.scale, x_sh = hs.x_sh, y_sh = hs.y_sh, hsc = hs.scale / 2;
-    const int wsx = hs.wsx, wsy = hs.wsy, C = hs.C, tbits = hs.bin_tbits;
-    const bool bin_ok = hs.bin_ok != 0;
-    const long long tmin = hs.tmin;
-    uint32_t n_ovf = 0;
-    __syncthreads();
     // Events in flight per thread: all loads of a pass are issued first.  U * THREADS covers a whole
     // bin of the usual size in ONE pass: a second pass would wait (vmcnt) for the first pass's
     // write-through stores of p before it sees its own loads (~2 us per extra pass, measured).
     constexpr int U = 8192 / THREADS;
+    uint32_t vxy[U];
+    int32_t vt[U];
+    float2 vp[U];
+    uint32_t base = beg;
+    auto load_pass = [&]() {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            // unconditional loads from a clamped index (no branch per load); dead slots are skipped below
+            uint32_t i = base + k * THREADS + tid;
+            i = i < end ? i : beg;
+            vxy[k] = xy[i];
+            vt[k] = t[i];
+            vp[k] = p[i];
+        }
+    };
+    load_pass();
+    asm volatile("" ::: "memory");   // (keep the requests above ahead of everything below)
+    {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
+        ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
+        for (int i = tid; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
+    }
+    if (tid < kStateWords) reinterpret_cast<unsigned long long*>(&s_state)[tid] = state_word;
+    // previous projected positions (event.h:167-168 re-derived from the stored products): independent of the model
+    double ppx[U], ppy[U];
+    auto previous_positions = [&]() {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            ppx[k] = pr_from_p(vxy[k] & 0xffffu, vp[k].x);
+            ppy[k] = pr_from_p(vxy[k] >> 16, vp[k].y);
+        }
+    };
+    tl_stamp(a.tl, a.j, 5);
+    if (pending && tid < 64) {
+        // (this wave shares its SIMD with three others that are busy with their events: without priority it gets a
+        // quarter of the issue slots and the update takes 1.4 us instead of ~0.5)
+        __builtin_amdgcn_s_setprio(3);
+        const unsigned long long word = acc_reduce_wave(accv);
+        __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order: the state copy is in place)
+        tl_stamp(a.tl, a.j, 6);
+        model_update_wave(&s_state, word, tid, 1);
+        __builtin_amdgcn_s_setprio(0);
+        tl_stamp(a.tl, a.j, 7);
+    } else {
+        previous_positions();
+    }
+    __syncthreads();
+    tl_stamp(a.tl, a.j, 1);
+    const ScatterHot hs = scatter_hot(&s_state);
+    if (b == 0 && pending && tid == 0)   // bookkeeping only the stored state needs (fields the scatter does not read)
+        model_update_rest(&s_state, a.trace, a.cur ^ 1, ovf_prev);
+    if (hs.done) {
+        __syncthreads();
+        store_state();
+        return;
+    }
+    if (pending && tid < 64) previous_positions();
+    const ScatterGeo sg = {X0, Y0, L, LR};
+    uint32_t n_ovf = 0;
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t i = base + k * THREADS + tid;
+            if (i >= end) continue;
+            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+        }
+        base += THREADS * U;
+        if (base >= end) break;
+        load_pass();
+        previous_positions();
+    }
+    if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+    tl_stamp(a.tl, a.j, 2);
+    __syncthreads();
+    tl_stamp(a.tl, a.j, 3);
+    store_state();
+    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    tl_stamp(a.tl, a.j, 4);
+}
+
+// K1 (binned), lean form: no update at the head -- the state it reads is final (the stencil kernel's last work-group
+// updated it: "co_schedule", the throughput mode with several slice contexts per GPU).  No barrier between the loads
+// and the scatter, so the waves of a work-group drift apart and overlap each other's memory latency.  Work-group 0
+// still carries the state to the other buffer and to the host snapshot.
+template <bool WARP, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
+    extern __shared__ unsigned long long s_tile[];
+    const BinGrid& g = a.g;
+    const int L = g.L, LR = g.LR, LL = g.LR * g.L;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
+    const HotState h0 = sload(&a.st_in->hot);   // one burst of scalar loads
+    unsigned long long state_word = 0;
+    if (b == 0 && tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
+    const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
+    {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
+        ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
+        for (int i = tid; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
+    }
+    if (b == 0 && tid < kStateWords) {
+        reinterpret_cast<unsigned long long*>(a.st_out)[tid] = state_word;
+        if (a.snap) reinterpret_cast<unsigned long long*>(a.snap)[tid] = state_word;
+    }
+    if (h0.done) return;
+    ScatterHot hs;
+    hs.done = h0.done; hs.bin_tbits = h0.bin_tbits; hs.bin_ok = h0.bin_ok; hs.scale = h0.scale; hs.C = h0.C;
+    hs.wsx = h0.wsx; hs.wsy = h0.wsy; hs.x_sh = h0.x_sh; hs.y_sh = h0.y_sh; hs.tmin = h0.tmin; hs.wp = h0.wp;
+    const EvSetPtrs ev = a.sets.s[h0.cs ^ h0.flip];
+    const uint32_t* __restrict__ xy = ev.xy;
+    const int32_t* __restrict__ t = ev.t;
+    float2* __restrict__ p = ev.p;
+    const ScatterGeo sg = {X0, Y0, L, LR};
+    uint32_t n_ovf = 0;
+    __syncthreads();
+    constexpr int U = 8192 / THREADS;   // (see k_bin_warp_scatter)
     for (uint32_t base = beg; base < end; base += THREADS * U) {
         uint32_t vxy[U];
         int32_t vt[U];
         float2 vp[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            // unconditional loads from a clamped index (no branch per load); dead slots are skipped below
-            uint32_t i = base + k * THREADS + threadIdx.x;
+            uint32_t i = base + k * THREADS + tid;
             i = i < end ? i : beg;
             vxy[k] = xy[i];
             vt[k] = t[i];
@@ -311,64 +528,37 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint32_t i = base + k * THREADS + threadIdx.x;
+            const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            const uint32_t v = vxy[k];
-            const int32_t ti = vt[k];
-            float2 q = vp[k];
-            const uint32_t fx = v & 0xffffu, fy = v >> 16;
-            double pr_x = pr_from_p(fx, q.x);
-            double pr_y = pr_from_p(fy, q.y);
-            if (WARP) {   // event.h:100-108,164-168 -- same arithmetic as k_warp_scatter
-                double nx, ny;
-                warp_products(wp, pr_x, pr_y, ti, q, nx, ny);
-                // write-through as well (see the slab flush below)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(&p[i]),
-                                   ((unsigned long long)__float_as_uint(q.y) << 32) | (unsigned long long)__float_as_uint(q.x),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pr_x = pr_from_p(fx, q.x);
-                pr_y = pr_from_p(fy, q.y);
-            }
-            const int X = trunc_x86(pr_x * (double)s + (double)x_sh);   // accel_lib.h:154-158
-            const int Y = trunc_x86(pr_y * (double)s + (double)y_sh);
-            if (!((X >= wsx + hsc) || (X < hsc) || (Y >= wsy + hsc) || (Y < hsc))) {
-                const unsigned long long dt = (unsigned long long)((long long)ti - tmin);
-                const int lx = X - X0, ly = Y - Y0;
-                if (bin_ok && lx >= 0 && lx < LR && ly >= 0 && ly < L) {
-                    atomicAdd(&s_tile[__mul24(lx, L) + ly], (1ull << tbits) + dt);
-                } else {   // drifted out of this bin's tile: exact, slow path
-                    const size_t kk = (size_t)X * (size_t)C + (size_t)Y;
-                    atomicAdd(&ovf_plane[kk], dt);
-                    atomicAdd(&ovf_cplane[kk], 1u);
-                    ++n_ovf;
-                }
-            }
+            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
         }
     }
-    if (n_ovf) atomicAdd(&st->hot.ovf_cnt[cur], n_ovf);
-    tl_stamp(tl, tl_launch, 2);
+    if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     __syncthreads();
-#ifdef BF_TIMELINE
-    if (tlw) { tlw[1] = wall_clock64(); tlw[3] = end - beg; }
-#endif
-    tl_stamp(tl, tl_launch, 3);
-    {   // flush: the whole tile (nothing to zero, no atomics).  WRITE-THROUGH stores (agent-scope
-        // relaxed = global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat
-        // dirty in the L2s until the end of the kernel, and their write-back stretched the kernel
-        // boundary to ~5.6 us (measured; "B / 6 TB/s" in the MI355X notes).
-        // (16 bytes per lane: L is even, so LL is, and a slab starts on a 16-byte boundary)
-        unsigned long long* dst = slabs + (size_t)b * (size_t)LL;
-        const bf_u32x4* src4 = reinterpret_cast<const bf_u32x4*>(s_tile);
-        for (int i = threadIdx.x; i < LL / 2; i += THREADS) {
-            const bf_u32x4 v = src4[i];
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + 2 * i), "v"(v) : "memory");
-        }
-    }
-    tl_stamp(tl, tl_launch, 4);
-#ifdef BF_TIMELINE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tlw) tlw[2] = wall_clock64();
-#endif
+    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+}
+
+// The pending update outside a warp+scatter launch (a warm start's gated final warp needs `done` of the batch's last
+// iteration; nothing else does): one work-group, state updated in place.
+__global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j,
+                                                            int cur_prev, bf_trace_rec* trace) {
+    __shared__ DevState s_state;
+    const int tid = threadIdx.x;
+    const int done = st->hot.done, it = st->hot.it;
+    if (done || it >= j) return;
+    if (tid < kStateWords)
+        reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(st)[tid];
+    const uint32_t ovf = *ovf_prev;
+    unsigned long long accv[kAccPerLane];
+    acc_load_wave<false, false>(acc, tid, accv);
+    const unsigned long long word = acc_reduce_wave(accv);
+    __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order: the state copy is in place)
+    model_update_wave(&s_state, word, tid, 1);
+    if (tid == 0) model_update_rest(&s_state, trace, cur_prev, ovf);
+    __builtin_amdgcn_wave_barrier();
+    if (tid < kStateWords)
+        reinterpret_cast<unsigned long long*>(st)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
 }
 
 // K3 (binned): merge the slabs covering each pixel, box-sum, normalise, then the shared tail.
@@ -378,7 +568,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(
 template <int HS>
 __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     tl_stamp(a.tl, a.tl_launch, 0);
-    const HotState hs = a.st->hot;   // one burst of scalar loads, then the branch
+    const HotState hs = sload(&a.st->hot);   // one burst of scalar loads, then the branch
     if (a.check_done && hs.done) return;
     tl_stamp(a.tl, a.tl_launch, 1);
     constexpr int TR = kTileR, TC = kTileC;
@@ -396,7 +586,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     const int bt = hs.bin_tbits;
     const unsigned long long bm = (1ull << bt) - 1ull;
     // (static indices only: a runtime index would push the HotState copy into scratch memory)
-    const bool ovf = (a.cur ? hs.ovf_cnt[1] : hs.ovf_cnt[0]) != 0;
+    const bool ovf = sload(a.ovf_cur) != 0;   // events of this iteration took the overflow path (uniform)
     const int LLi = g.LR * g.L;
 
     static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
@@ -482,20 +672,12 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     }
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 4);
-    const bool do_zero = a.zero_plane && (a.cur ? hs.ovf_cnt[0] : hs.ovf_cnt[1]) != 0;
+    const bool do_zero = a.zero_plane && sload(a.ovf_prev) != 0;   // the other plane buffer is dirty: clear it for the next iteration
     stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
 }
 
-// Two builds of the same body.  The default one takes the registers it wants (~115: four waves per SIMD) and is
-// the fastest for one slice at a time.  The "co-scheduled" one is held to five waves per SIMD (<= 102 VGPRs, a
-// few spills): slower alone (+0.8 us), but two of its waves fit a SIMD next to a resident K1 work-group of another
-// slice context (4 x 77 VGPRs), which is worth +8 % when several contexts share the GPU (option "co_schedule").
 template <int HS>
 __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
-    stencil_binned_body<HS>(a);
-}
-template <int HS>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_stencil_binned_co(StencilArgs a) {
     stencil_binned_body<HS>(a);
 }
 
@@ -512,9 +694,7 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 }
 
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
-#define BF_K3(HS_)                                                                              \
-    if (a.co_schedule) launch_timed(k_stencil_binned_co<HS_>, grid, dim3(kThreads), 0, s, a);   \
-    else launch_timed(k_stencil_binned<HS_>, grid, dim3(kThreads), 0, s, a)
+#define BF_K3(HS_) launch_timed(k_stencil_binned<HS_>, grid, dim3(kThreads), 0, s, a)
     switch (a.scale / 2) {
         case 0: BF_K3(0); break;
         case 1: BF_K3(1); break;
@@ -546,30 +726,46 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 }
 
 template <int THREADS>
-static void launch_bws(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane, uint32_t* ovf_cplane,
-                       DevState* st, const BinGrid& g, int cur, bool warp, int check_done, unsigned long long* tl,
-                       int tl_launch, hipStream_t s) {
-    const size_t lds = (size_t)g.LR * g.L * sizeof(unsigned long long);
-    if (warp)
-        launch_timed(k_bin_warp_scatter<true, THREADS>, dim3(g.nbins), dim3(THREADS), lds, s, sets, bin_start, slabs,
-                     ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
-    else
-        launch_timed(k_bin_warp_scatter<false, THREADS>, dim3(g.nbins), dim3(THREADS), lds, s, sets, bin_start, slabs,
-                     ovf_plane, ovf_cplane, st, g, cur, check_done, tl, tl_launch);
+static void launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
+    const size_t lds = (size_t)a.g.LR * a.g.L * sizeof(unsigned long long);
+    if (!a.acc) {   // nothing to update at the head
+        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        else launch_timed(k_bin_warp_scatter_lean<false, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        return;
+    }
+    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    else launch_timed(k_bin_warp_scatter<false, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
 }
 
-void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs, unsigned long long* ovf_plane,
-                             uint32_t* ovf_cplane, DevState* st, const BinGrid& g, int cur, bool warp,
-                             int check_done, int threads, unsigned long long* tl, int tl_launch, hipStream_t s) {
-    if (threads >= 1024) launch_bws<1024>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, tl, tl_launch, s);
-    else if (threads >= 512) launch_bws<512>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, tl, tl_launch, s);
-    else launch_bws<256>(sets, bin_start, slabs, ovf_plane, ovf_cplane, st, g, cur, warp, check_done, tl, tl_launch, s);
+void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, hipStream_t s) {
+    if (threads >= 1024) launch_bws<1024>(a, warp, s);
+    else if (threads >= 512) launch_bws<512>(a, warp, s);
+    else launch_bws<256>(a, warp, s);
+}
+
+// Start of a tile-binned run: overflow counters (slot j % 3 <- iteration j; slot 2 = "iteration -1") and both
+// accumulator parities.
+__global__ __launch_bounds__(kThreads) void k_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc) {
+    const int tid = threadIdx.x;
+    if (tid < 3) ovf[tid] = (tid == 2) ? prev_dirty : 0u;
+    for (int i = tid; i < 2 * kAccGroups * 16; i += kThreads) (&acc[0].f[0])[i] = 0ull;
+}
+void launch_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, hipStream_t s) {
+    hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(kThreads), 0, s, ovf, prev_dirty, acc);
+}
+
+void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_finish_update, dim3(1), dim3(64), 0, s, st, acc, ovf_prev, j, cur_prev, trace);
 }
 
 template <bool W, int T>
 static hipError_t raise_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<W, T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<W, T>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<W, T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
 }
 
 int bin_kernel_setup() {

@@ -18,8 +18,10 @@
 //   slabs   u64[nbins * L * L]  one private (TS+2D)^2 tile per bin, rewritten every iteration
 //   time    f32[R*C] time image (stand-alone operators only)
 //   gx, gy  f32[R*C] Scharr planes (stand-alone operators only)
-//   partial Partial[blocks]  per-work-group moment sums of the stencil kernel
-//   state   DevState the model, loop control and warp parameters of the fused run
+//   acc     MomentAcc[2][kAccGroups]  moment sums of the stencil kernel: exact integer / fixed-point
+//                    accumulators, added to with device atomics (order-free, so bit-reproducible)
+//   state   DevState[2] the model, loop control and warp parameters of the fused run (the tile-binned
+//                    loop ping-pongs: the update runs at the head of the next warp+scatter launch)
 #pragma once
 #include <stdint.h>
 
@@ -39,13 +41,21 @@ struct WarpParams {
     double c, s;   // cos(crl), sin(crl)
 };
 
-// Per-work-group partial sums of the moment reduction (A.4 + A.6 in one pass).
-// ci = i - R/2, cj = j - C/2 are centred integer pixel coordinates.
-struct Partial {
-    long long n, sci, scj;          // exact integer sums over valid pixels
-    double sgx, sgy;                // sum gx, sum gy
-    double sigx, sigy, sjgx, sjgy;  // sum ci*gx, ci*gy, cj*gx, cj*gy
-    double pad;
+// Moment sums of one iteration, accumulated ACROSS work-groups in exact integer arithmetic (A.4 + A.6 in one pass;
+// ci = i - R/2, cj = j - C/2 are centred integer pixel coordinates):
+//   f[0..2]   n, sum ci, sum cj over valid pixels (two's complement)
+//   f[3 + 2k], f[4 + 2k]   the k-th floating-point sum (sgx, sgy, sigx, sigy, sjgx, sjgy) as fixed point:
+//             every work-group's f64 partial v (summed in a fixed order inside the group) is split into
+//             hi = floor(v 2^12) and lo = floor((v 2^12 - hi) 2^52); the his and the los are added separately.
+// Integer addition is associative, so the total does not depend on the order in which the work-groups arrive:
+// device atomics replace the ordered gather of per-group records (752 records read by one CU took 3 us).  Resolution
+// 2^-64 per partial; ranges: |v| < 2^49 (a partial is at most 2^16 pixels x 2^15 x |g| <= 2^7), <= 2^10 partials.
+// kAccGroups copies on different cache lines spread the same-address atomics (~12 ns each; 752 work-groups that
+// finish together would queue ~50 deep on 16 copies; the reader holds kAccGroups / 4 words per lane in registers).
+constexpr int kAccGroups = 32;
+constexpr int kAccFields = 15;
+struct MomentAcc {
+    unsigned long long f[16];   // 128 bytes: one line per group
 };
 
 // Geometry of the tile-binned scatter (bf_binned.hip): image tiles of TSR rows x TS columns of scaled
@@ -64,7 +74,8 @@ struct BinGrid {
 // that misses L2 costs ~1-2 us on the iteration's critical path).
 struct HotState {
     int32_t done, it, binned, bin_tbits;
-    uint32_t ovf_cnt[2];      // events that took the overflow path into plane buffer [i]
+    uint32_t ovf_cnt[2];      // plane buffer [i] is dirty (stand-alone operators and the global-atomic loop; the
+                              // tile-binned loop counts its overflow events in bf_ctx::d_ovf, outside the state)
     int32_t need_rebin, rebins;
     int32_t cs, flip, bin_ok, pad1;   // live event set; flip = a re-bin moved the events to set cs^1;
                                       // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)
@@ -81,13 +92,15 @@ struct DevState {
     // --- loop control (optimizer_rolling.h:36,59-63) ---
     float x_div, y_div, rot_div, div_div;
     float old_dx, old_dy, old_rot, old_div;
-    int32_t max_iter, hard_cap, rc, trace_cap, nblocks, pad2;
+    int32_t max_iter, hard_cap, rc, trace_cap, nblocks;
+    uint32_t last_ovf;                // overflow events of the last iteration applied (tile-binned loop)
     uint32_t ovf_total, n_events;
     // --- drift tracking of the tile-binned scatter: warp parameters at the last re-bin, and
     //     the largest |t| (ns) and lever arm (sensor px) an event of this slice can have ---
     WarpParams ref_wp;
     double t_abs_max, r_max, drift_limit;
     long long t_span;                 // tmax - tmin of the slice (ns): bound of one event's time addend
+    int32_t run_tag, pad3;            // what `done` is set to (non-zero; bf_run gives every run its own)
     // --- model ---
     bf_model model;
 };

@@ -79,6 +79,22 @@ __device__ __forceinline__ void warp_products(const WarpParams& wp, double pr_x,
     q.y = ky * ft;
 }
 
+// A load the compiler must issue on the SCALAR unit: through the constant address space.  For data that no work-group
+// of the running kernel writes (kernel arguments passed inside a struct lose their __restrict__, and the compiler
+// then falls back to vector loads for uniform addresses: they complete in order with every other vector load of the
+// wave, so a 4-byte state word ended up waiting for ~1 us of earlier requests).
+template <class T>
+__device__ __forceinline__ T sload(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    typedef const __attribute__((address_space(4))) uint32_t* cptr;
+    const cptr src = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p));
+    T out;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = src[i];   // (merged into s_load_dwordx2 .. x16)
+    return out;
+}
+
 __device__ __forceinline__ int wave_min(int v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, 64));
     return v;
@@ -276,60 +292,192 @@ __device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_bia
     return sum_s / (float)cnt;
 }
 
-// ObjectModel::update from the reduced sums (object_model.cpp:4-39,103-126) and, in mode 1,
-// ObjectModel::update_accumulators (object_model.h:48-53), the glue of iteration_step
-// (optimizer_rolling.h:328-346) and the loop control of run() (optimizer_rolling.h:61-101).
-// Runs on ONE thread (the reducer).  mode 0: model only (AccelLib::fast_model).
-__device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, bf_trace_rec* trace, int mode,
-                                                   int cur) {
-    bf_model m = st->model;
-    const int R = st->hot.R, C = st->hot.C;
-    const double dn = (double)t.n;   // cnt == 0 -> 0/0 = NaN, as in the reference (assert off)
-    // object_model.cpp:103-126: cx = (sum of rows) / cnt, exact integer numerator
-    m.cx = (double)(t.sci + t.n * (long long)(R / 2)) / dn;
-    m.cy = (double)(t.scj + t.n * (long long)(C / 2)) / dn;
-    const double cxc = (double)t.sci / dn, cyc = (double)t.scj / dn;
-    // object_model.cpp:26-38 with r = (ci - cxc, cj - cyc)
-    m.dx = t.sgx / dn;
-    m.dy = t.sgy / dn;
-    m.rot = ((t.sigy - cxc * t.sgy) - (t.sjgx - cyc * t.sgx)) / dn;
-    m.div = ((t.sigx - cxc * t.sgx) + (t.sjgy - cyc * t.sgy)) / dn;
-    m.cnt = (uint32_t)t.n;
-    if (mode == 0) {
-        st->model = m;
+// sin / cos of the (small) rotation angle of the warp: Taylor polynomials in x^2 for |x| <= 0.25 (truncation below
+// 2^-64; a 30 ms slice rotates by ~1e-3), the library routine otherwise.  ~10 dependent operations instead of ~100 on
+// the one lane every iteration waits for.  Agrees with libm to <= 1 ulp (the reference calls std::cos / std::sin,
+// event.h:102-103; the stand-alone operator bf_project_4param_reinit does so too, on the host).
+__device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
+    if (!(fabs(x) <= 0.25)) {
+        sincos(x, sn, cs);
         return;
     }
+    const double z = x * x;
+    double ps = -1.0 / 1307674368000.0;                    // sin(x) / x
+    ps = fma(ps, z, 1.0 / 6227020800.0);
+    ps = fma(ps, z, -1.0 / 39916800.0);
+    ps = fma(ps, z, 1.0 / 362880.0);
+    ps = fma(ps, z, -1.0 / 5040.0);
+    ps = fma(ps, z, 1.0 / 120.0);
+    ps = fma(ps, z, -1.0 / 6.0);
+    *sn = fma(x * z, ps, x);
+    double pc = 1.0 / 20922789888000.0;                    // (cos(x) - 1 + z / 2) / z^2
+    pc = fma(pc, z, -1.0 / 87178291200.0);
+    pc = fma(pc, z, 1.0 / 479001600.0);
+    pc = fma(pc, z, -1.0 / 3628800.0);
+    pc = fma(pc, z, 1.0 / 40320.0);
+    pc = fma(pc, z, -1.0 / 720.0);
+    pc = fma(pc, z, 1.0 / 24.0);
+    *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+
+// A uniform double out of one lane of a wave (two v_readlane_b32).
+__device__ __forceinline__ double lane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+__device__ __forceinline__ long long lane_i64(unsigned long long v, int lane) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), lane);
+    return (long long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
+// ObjectModel::update from the reduced sums (object_model.cpp:4-39,103-126) and, in mode 1,
+// ObjectModel::update_accumulators (object_model.h:48-53), the glue of iteration_step
+// (optimizer_rolling.h:328-346) and the loop control of run() (optimizer_rolling.h:61-101), on a copy of the state in
+// LDS.  mode 0: model only (AccelLib::fast_model).
+//
+// This is the one serial stretch every iteration of the loop waits for, so it is written for latency.  It is executed
+// by ONE WAVE (all 64 lanes call it): lane l brings `word`, the total of accumulator field l % 16 (MomentAcc layout).
+// A single wave issues one vector instruction every ~5 cycles whatever the number of active lanes, so the work is
+// spread over lanes wherever the same operation applies to several values: the integer -> f64 conversions and the
+// fixed-point joins run once for all fields, and ALL the divisions the update needs -- the ten moment quotients by the
+// pixel count and the five reciprocals of the dividers / the scale -- are ONE lane-parallel IEEE division (~12
+// instructions instead of ~180).  The quotients are then broadcast through scalar registers and the rest (a few dozen
+// operations on uniform values, sin / cos by sincos_small) is done redundantly by every lane; lane 0 stores.
+// ~170 instructions, against ~600 for the same update written for one thread.
+//   lane : numerator / denominator
+//     1  : (sum ci + n R/2) / n = cx      2 : (sum cj + n C/2) / n = cy       (exact integer numerators)
+//     4  : sum ci / n = cxc               6 : sum cj / n = cyc                 (centred)
+//     3, 5, 7, 9, 11, 13 : sgx, sgy, sigx, sigy, sjgx, sjgy / n
+//     8, 10, 12, 14, 15  : 1 / x_div, 1 / y_div, 1 / rot_div, 1 / div_div, 1 / scale
+// rot and div are formed from the quotients (object_model.cpp:26-38 with the division distributed over the terms;
+// the dividers enter as reciprocals: <= 1 ulp from the divided form, far inside the moments' 1e-9 bar).
+__device__ __forceinline__ void model_update_wave(DevState* st, unsigned long long word, int lane, int mode) {
+    const int f = lane & 15;
+    const long long n_i = lane_i64(word, 0), sci = lane_i64(word, 1), scj = lane_i64(word, 2);
+    const int R = st->hot.R, C = st->hot.C;
+    const double dn = (double)n_i;   // cnt == 0 -> 0/0 = NaN, as in the reference (assert off)
+    // fixed-point join: this lane's high word with the next lane's low word (valid in the odd lanes 3 .. 13)
+    const double dhi = (double)(long long)word, dlo = (double)word;
+    const double lo_next = __shfl_down(dlo, 1, 64);
+    double num = (dhi + lo_next * (1.0 / 4503599627370496.0)) * (1.0 / 4096.0);
+    double den = dn;
+    num = (f == 1) ? (double)(sci + n_i * (long long)(R / 2)) : num;
+    num = (f == 2) ? (double)(scj + n_i * (long long)(C / 2)) : num;
+    num = (f == 4) ? (double)sci : num;
+    num = (f == 6) ? (double)scj : num;
+    if (mode != 0) {
+        const double xd_ = (double)st->x_div, yd_ = (double)st->y_div, rd_ = (double)st->rot_div, dd_ = (double)st->div_div;
+        const double sc_ = (double)st->hot.scale;
+        den = (f == 8) ? xd_ : den;
+        den = (f == 10) ? yd_ : den;
+        den = (f == 12) ? rd_ : den;
+        den = (f == 14) ? dd_ : den;
+        den = (f == 15) ? sc_ : den;
+        num = (f == 8 || f == 10 || f == 12 || f == 14 || f == 15) ? 1.0 : num;
+    }
+    const double quo = num / den;   // the one division
+    bf_model m = st->model;
+    m.cx = lane_f64(quo, 1);
+    m.cy = lane_f64(quo, 2);
+    const double cxc = lane_f64(quo, 4), cyc = lane_f64(quo, 6);
+    m.dx = lane_f64(quo, 3);
+    m.dy = lane_f64(quo, 5);
+    const double qsigx = lane_f64(quo, 7), qsigy = lane_f64(quo, 9), qsjgx = lane_f64(quo, 11), qsjgy = lane_f64(quo, 13);
+    // object_model.cpp:26-38 with r = (ci - cxc, cj - cyc)
+    m.rot = (qsigy - cxc * m.dy) - (qsjgx - cyc * m.dx);
+    m.div = (qsigx - cxc * m.dx) + (qsjgy - cyc * m.dy);
+    m.cnt = (uint32_t)n_i;
+    if (mode == 0) {
+        if (lane == 0) st->model = m;
+        return;
+    }
+    const double inv_xd = lane_f64(quo, 8), inv_yd = lane_f64(quo, 10), inv_rd = lane_f64(quo, 12), inv_dd = lane_f64(quo, 14);
+    const double inv_scale = lane_f64(quo, 15);
     // object_model.h:48-53 via optimizer_rolling.h:328.  The four quotients are kept: the convergence test
     // below needs the same ratios against dividers that are either unchanged or exactly doubled.
-    const double q_rot = m.rot / (double)st->rot_div, q_div = m.div / (double)st->div_div;
-    const double q_dx = m.dx / (double)st->x_div, q_dy = m.dy / (double)st->y_div;
+    const double q_rot = m.rot * inv_rd, q_div = m.div * inv_dd;
+    const double q_dx = m.dx * inv_xd, q_dy = m.dy * inv_yd;
     m.total_rot += q_rot;
     m.total_div += q_div;
     m.total_dx += q_dx;
     m.total_dy += q_dy;
     // optimizer_rolling.h:330-331,340-346
-    const double cxs = (m.cx - st->x_shift) / (double)st->hot.scale;
-    const double cys = (m.cy - st->y_shift) / (double)st->hot.scale;
+    const double cxs = (m.cx - st->x_shift) * inv_scale;
+    const double cys = (m.cy - st->y_shift) * inv_scale;
     WarpParams wp;
     wp.dnx = -m.total_dx; wp.dny = -m.total_dy;
     wp.cx = cxs; wp.cy = cys;
     wp.div = m.total_div;
-    const double crl = -m.total_rot;
-    sincos(crl, &wp.s, &wp.c);   // one argument reduction for both (same values as sin() and cos())
+    sincos_small(-m.total_rot, &wp.s, &wp.c);
     m.cx = cxs;
     m.cy = cys;
-    st->hot.wp = wp;
-    st->model = m;
 
+    // ---- run(), optimizer_rolling.h:73-101, as a state machine after each step ----
+    const int it = st->hot.it + 1;
+    float xd = st->x_div, yd = st->y_div, rd = st->rot_div, dd = st->div_div;
+    // m.dx / xd of the convergence test (:81-84) == q_dx when the divider is unchanged and q_dx / 2 when it was
+    // just doubled (a power of two)
+    double hx = 1.0, hy = 1.0, hr = 1.0, hd = 1.0;
+    int done = 0, rc = 0;
+    bool new_dividers = false;
+    if (it > 1) {
+        if (st->max_iter > 0 && it > st->max_iter) {   // :94-96 (before the sign flips)
+            done = 1;
+        } else {                                       // :98-101
+            if (m.dx * (double)st->old_dx < 0) { xd *= 2; hx = 0.5; }
+            if (m.dy * (double)st->old_dy < 0) { yd *= 2; hy = 0.5; }
+            if (m.rot * (double)st->old_rot < 0) { rd *= 2; hr = 0.5; }
+            if (m.div * (double)st->old_div < 0) { dd *= 2; hd = 0.5; }
+            new_dividers = true;
+            if (st->hard_cap > 0 && it >= st->hard_cap) { done = 1; rc = BF_ERR_NOCONV; }
+        }
+    }
+    bool keep_old = false;
+    if (!done) {
+        if (!(xd < 32 * 10 || yd < 32 * 10 || rd < 32 * 1000 || dd < 32 * 1000)) {   // :76-79
+            done = 1;
+        } else if (fabs(q_dx * hx) < 1e-5 && fabs(q_dy * hy) < 1e-5 &&
+                   fabs(q_rot * hr) < 1e-4 && fabs(q_div * hd) < 1e-1) {   // :81-84
+            done = 1;
+        } else {                                                                         // :86-89
+            keep_old = true;
+        }
+    }
+    const int run_tag = st->run_tag;
+    __builtin_amdgcn_wave_barrier();   // (every lane has read what it needs from the state)
+    if (lane == 0) {
+        st->hot.wp = wp;
+        st->model = m;
+        st->hot.it = it;
+        if (new_dividers) { st->x_div = xd; st->y_div = yd; st->rot_div = rd; st->div_div = dd; }
+        if (keep_old) {
+            st->old_dx = (float)m.dx; st->old_dy = (float)m.dy;
+            st->old_rot = (float)m.rot; st->old_div = (float)m.div;
+        }
+        if (done) {
+            st->rc = rc;
+            st->hot.done = run_tag ? run_tag : 1;
+        }
+    }
+}
+
+// `cur` is the plane buffer of the iteration the sums belonged to; `ovf_now` the number of events that took the
+// overflow path in it (tile-binned loop: the count lives outside the state, see k_bin_warp_scatter).
+__device__ __forceinline__ void model_update_rest(DevState* st, bf_trace_rec* trace, int cur, uint32_t ovf_now = 0) {
     // plane-buffer bookkeeping: the stencil of this iteration cleared buffer cur^1 (v1 paths
     // always, the tile-binned path when it was dirty); buffer `cur` is dirty iff something was
     // scattered into it.  Many overflow events -> ask the host for a re-bin.
+    const WarpParams wp = st->hot.wp;
     if (st->hot.binned) {
         if (st->hot.flip) {   // a re-bin moved the events to the other set: commit
             st->hot.cs ^= 1;
             st->hot.flip = 0;
         }
-        const uint32_t oc = st->hot.ovf_cnt[cur];
+        const uint32_t oc = ovf_now;
+        st->last_ovf = oc;
         st->ovf_total += oc;
         // Predictive re-bin: bound how far the new warp can have moved any event (scaled pixels)
         // since the bins were built, and re-sort BEFORE events start leaving their LDS tiles.
@@ -346,60 +494,15 @@ __device__ __forceinline__ void model_update_local(DevState* st, const Sums& t, 
         }
     } else {
         st->hot.ovf_cnt[cur] = 1;
+        st->hot.ovf_cnt[cur ^ 1] = 0;
     }
-    st->hot.ovf_cnt[cur ^ 1] = 0;
-
-    // ---- run(), optimizer_rolling.h:73-101, as a state machine after each step ----
-    const int it = st->hot.it + 1;
-    st->hot.it = it;
-    float xd = st->x_div, yd = st->y_div, rd = st->rot_div, dd = st->div_div;
-    // m.dx / xd of the convergence test (:81-84) == q_dx when the divider is unchanged and q_dx / 2 when it was
-    // just doubled: a / (2 b) rounds to exactly RN(a / b) / 2 (no underflow at these magnitudes)
-    double hx = 1.0, hy = 1.0, hr = 1.0, hd = 1.0;
-    int done = 0, rc = 0;
-    if (it > 1) {
-        if (st->max_iter > 0 && it > st->max_iter) {   // :94-96 (before the sign flips)
-            done = 1;
-        } else {                                       // :98-101
-            if (m.dx * (double)st->old_dx < 0) { xd *= 2; hx = 0.5; }
-            if (m.dy * (double)st->old_dy < 0) { yd *= 2; hy = 0.5; }
-            if (m.rot * (double)st->old_rot < 0) { rd *= 2; hr = 0.5; }
-            if (m.div * (double)st->old_div < 0) { dd *= 2; hd = 0.5; }
-            st->x_div = xd; st->y_div = yd; st->rot_div = rd; st->div_div = dd;
-            if (st->hard_cap > 0 && it >= st->hard_cap) { done = 1; rc = BF_ERR_NOCONV; }
-        }
-    }
+    const int it = st->hot.it;
     if (trace && it <= st->trace_cap) {
         bf_trace_rec& r = trace[it - 1];
-        r.model = m;
-        r.x_divider = xd; r.y_divider = yd; r.rot_divider = rd; r.div_divider = dd;
+        r.model = st->model;
+        r.x_divider = st->x_div; r.y_divider = st->y_div; r.rot_divider = st->rot_div; r.div_divider = st->div_div;
         r.iteration = it;
     }
-    if (!done) {
-        if (!(xd < 32 * 10 || yd < 32 * 10 || rd < 32 * 1000 || dd < 32 * 1000)) {   // :76-79
-            done = 1;
-        } else if (fabs(q_dx * hx) < 1e-5 && fabs(q_dy * hy) < 1e-5 &&
-                   fabs(q_rot * hr) < 1e-4 && fabs(q_div * hd) < 1e-1) {   // :81-84
-            done = 1;
-        } else {                                                                         // :86-89
-            st->old_dx = (float)m.dx; st->old_dy = (float)m.dy;
-            st->old_rot = (float)m.rot; st->old_div = (float)m.div;
-        }
-    }
-    if (done) {
-        st->rc = rc;
-        st->hot.done = 1;
-    }
-}
-
-// The update on an LDS copy of the state: with the state in global memory every field access of
-// model_update_local is a dependent round trip (3.2 us measured), and a register copy spills
-// (the stencil kernel is at ~120 VGPRs).  Called by ONE thread; s_copy is work-group LDS.
-__device__ __forceinline__ void model_update(DevState* st, DevState* s_copy, const Sums& t, bf_trace_rec* trace,
-                                             int mode, int cur) {
-    *s_copy = *st;
-    model_update_local(s_copy, t, trace, mode, cur);
-    *st = *s_copy;
 }
 
 // One pixel of the gated 3x3 Scharr (accel_lib.h:513-615) and its contribution to the centre-of-
@@ -460,80 +563,76 @@ __device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int 
     }
 }
 
-// Partials are field-major with an EVEN stride so that two neighbouring records of one field are one
-// aligned 16-byte word.
-__host__ __device__ __forceinline__ int partial_stride(int nblk) { return (nblk + 1) & ~1; }
-
-// Publishes one work-group's reduced sums as field-major (structure-of-arrays) partials with write-through stores:
-// field k of work-group i at [k * partial_stride(nblk) + i].  Seven fields: the three integer sums of a stencil tile
-// (at most 1024 pixels, |ci|, |cj| < 2^15) share one word, n << 52 | (sci + 2^15 n) << 26 | (scj + 2^15 n) -- exact,
-// and two of nine fields fewer for the reducer, whose single CU fetches the partials at only ~20 GB/s.
-constexpr int kPubFields = 7;
-__device__ __forceinline__ void publish_partial(unsigned long long* partials, int nblk, int me, const Sums& t) {
-    unsigned long long* o = partials + me;
-    const int stride = partial_stride(nblk);
-    const unsigned long long pk = ((unsigned long long)t.n << 52) | ((unsigned long long)(t.sci + 32768ll * t.n) << 26) |
-                                  (unsigned long long)(t.scj + 32768ll * t.n);
-    const unsigned long long v[kPubFields] = {
-        pk, (unsigned long long)__double_as_longlong(t.sgx), (unsigned long long)__double_as_longlong(t.sgy),
-        (unsigned long long)__double_as_longlong(t.sigx), (unsigned long long)__double_as_longlong(t.sigy),
-        (unsigned long long)__double_as_longlong(t.sjgx), (unsigned long long)__double_as_longlong(t.sjgy)};
-#pragma unroll
-    for (int k = 0; k < kPubFields; ++k)
-        __hip_atomic_store(&o[(size_t)k * stride], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 typedef unsigned int bf_u32x4 __attribute__((ext_vector_type(4)));
 
-// The reducer's first step: thread tid of 256 adds the record PAIRS tid, tid + 256, ... in a fixed
-// order.  Agent-scope (sc1) 16-byte loads: the partials were published by other work-groups of the
-// same launch; all loads are issued before the single wait.
-__device__ __forceinline__ Sums gather_partials(const unsigned long long* partials, int nblk, int tid) {
-    Sums acc;
-    sums_zero(acc);
-    unsigned long long an = 0, ai = 0, aj = 0;   // the packed word's three fields, summed apart
-    const int stride = partial_stride(nblk);
-    const int npairs = stride / 2;
-    for (int base = 0; base < npairs; base += kThreads * 2) {
-        bf_u32x4 q[2][kPubFields];
+// ---- moment sums across work-groups: exact fixed-point accumulators (bf_device.h: MomentAcc) ----------------------
+__device__ __forceinline__ void fx_split(double v, unsigned long long& hi, unsigned long long& lo) {
+    v = fmin(fmax(v, -562949953421312.0), 562949953421312.0);   // |v| <= 2^49 (never reached; NaN -> bound)
+    const double s = v * 4096.0;          // exact (power of two)
+    const double fl = floor(s);           // exact
+    hi = (unsigned long long)(long long)fl;
+    lo = (unsigned long long)((s - fl) * 4503599627370496.0);   // (s - fl) in [0, 1) is exact; 2^52: truncation below 2^-64
+}
+__device__ __forceinline__ double fx_join(unsigned long long hi, unsigned long long lo) {
+    return ((double)(long long)hi + (double)lo * (1.0 / 4503599627370496.0)) * (1.0 / 4096.0);
+}
+
+// The per-lane word model_update_wave expects, from sums held in registers (every lane holds `t`): field lane % 16 of
+// the MomentAcc layout.  Used where the sums never went through the accumulators (bf_tiles.hip).
+__device__ __forceinline__ unsigned long long sums_lane_word(const Sums& t, int lane) {
+    const int f = lane & 15;
+    const double d[6] = {t.sgx, t.sgy, t.sigx, t.sigy, t.sjgx, t.sjgy};
+    const int k = (f >= 3) ? ((f - 3) >> 1) : 0;
+    double dv = d[0];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pi = base + k * kThreads + tid;
-            const unsigned long long* src = partials + 2 * (pi < npairs ? pi : 0);
+    for (int q = 1; q < 6; ++q) dv = (k == q) ? d[q] : dv;
+    unsigned long long hi, lo;
+    fx_split(dv, hi, lo);
+    unsigned long long v = ((f - 3) & 1) ? lo : hi;
+    v = (f == 0) ? (unsigned long long)t.n : v;
+    v = (f == 1) ? (unsigned long long)t.sci : v;
+    v = (f == 2) ? (unsigned long long)t.scj : v;
+    v = (f == 15) ? 0ull : v;
+    return v;
+}
+
+
+// Adds one work-group's sums into accumulator group `grp`: fifteen fire-and-forget device atomics, one per lane of
+// the calling wave's first fifteen lanes (every thread holds `t`).  Nothing is read back and nothing is waited for:
+// the end of the kernel (or the caller's own s_waitcnt) completes them.
+__device__ __forceinline__ void acc_add(MomentAcc* acc, int grp, const Sums& t, int tid) {
+    if (tid >= kAccFields) return;
+    (void)__hip_atomic_fetch_add(&acc[grp].f[tid], sums_lane_word(t, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Total of the kAccGroups accumulator groups, by ONE wave (all 64 lanes; no work-group barrier): lane l loads field
+// l % 16 of groups l / 16, l / 16 + 4, ... (sixteen lanes read one 128-byte line) -- acc_load_wave, to be issued as
+// early as possible -- and acc_reduce_wave adds them and finishes with two cross-lane steps (lanes l, l ^ 16, l ^ 32):
+// afterwards EVERY lane holds the total of field l % 16, the form model_update_wave takes.  AGENT: the accumulators
+// were written by other work-groups of THIS launch (L1-bypassing loads); otherwise by an earlier kernel (plain loads).
+// ZERO: the reader clears them for their next use.
+constexpr int kAccPerLane = kAccGroups / 4;
+template <bool AGENT, bool ZERO>
+__device__ __forceinline__ void acc_load_wave(MomentAcc* acc, int lane, unsigned long long (&v)[kAccPerLane]) {
+    static_assert(kAccGroups % 4 == 0, "four groups per pass");
+    unsigned long long* src = &acc[lane >> 4].f[lane & 15];
 #pragma unroll
-            for (int j = 0; j < kPubFields; ++j)
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[k][j]) : "v"(src + (size_t)j * stride) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]), "+v"(q[0][4]), "+v"(q[0][5]),
-                       "+v"(q[0][6]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]), "+v"(q[1][4]),
-                       "+v"(q[1][5]), "+v"(q[1][6])
-                     :: "memory");
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pi = base + k * kThreads + tid;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (pi < npairs && 2 * pi + h < nblk) {
-                    unsigned long long v[kPubFields];
-#pragma unroll
-                    for (int j = 0; j < kPubFields; ++j)
-                        v[j] = ((unsigned long long)q[k][j][2 * h + 1] << 32) | (unsigned long long)q[k][j][2 * h];
-                    an += v[0] >> 52; ai += (v[0] >> 26) & 0x3ffffffull; aj += v[0] & 0x3ffffffull;
-                    acc.sgx += __longlong_as_double((long long)v[1]);
-                    acc.sgy += __longlong_as_double((long long)v[2]);
-                    acc.sigx += __longlong_as_double((long long)v[3]);
-                    acc.sigy += __longlong_as_double((long long)v[4]);
-                    acc.sjgx += __longlong_as_double((long long)v[5]);
-                    acc.sjgy += __longlong_as_double((long long)v[6]);
-                }
-            }
-        }
+    for (int k = 0; k < kAccPerLane; ++k) {
+        unsigned long long* q = src + (size_t)k * 4 * 16;
+        v[k] = AGENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
     }
-    acc.n = (long long)an;
-    acc.sci = (long long)ai - 32768ll * (long long)an;
-    acc.scj = (long long)aj - 32768ll * (long long)an;
-    return acc;
+    if (ZERO) {
+#pragma unroll
+        for (int k = 0; k < kAccPerLane; ++k) src[(size_t)k * 4 * 16] = 0ull;
+    }
+}
+__device__ __forceinline__ unsigned long long acc_reduce_wave(const unsigned long long (&v)[kAccPerLane]) {
+    unsigned long long tot = 0;
+#pragma unroll
+    for (int k = 0; k < kAccPerLane; ++k) tot += v[k];
+    tot += __shfl_xor(tot, 16, 64);
+    tot += __shfl_xor(tot, 32, 64);
+    return tot;
 }
 
 // Second half of the stencil kernels: given the time tile in LDS ((TR+2) x (TC+2), halo 1),
@@ -567,10 +666,10 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             }
         }
     }
-    if (a.partials) {
+    if (a.acc) {
         tl_stamp(a.tl, a.tl_launch, 5);
-        // The state is stable while this kernel runs (only its own last work-group writes it), so every
-        // work-group fetches a copy into LDS now, off the critical path: the update then runs on it at
+        // Fused-update form (a.ticket): the state is stable while this kernel runs (only its own last work-group writes
+        // it), so every work-group fetches a copy into LDS now, off the critical path: the update then runs on it at
         // once (a dependent global round trip per field cost 3.2 us; copying after the ticket ~1 us).
         __shared__ DevState s_state;
         static_assert(sizeof(DevState) % 8 == 0 && sizeof(DevState) / 8 <= 64, "one u64 per lane of one wave");
@@ -581,74 +680,62 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
-        if (!a.ticket) {   // stand-alone pass: partials only, reduced by k_update
-            if (tid == 0) {
-                const Sums t = blk;
-                unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partials) + me;
-                const size_t st_ = (size_t)partial_stride(nblk);
-                o[0 * st_] = (unsigned long long)t.n; o[1 * st_] = (unsigned long long)t.sci;
-                o[2 * st_] = (unsigned long long)t.scj;
-                o[3 * st_] = (unsigned long long)__double_as_longlong(t.sgx);
-                o[4 * st_] = (unsigned long long)__double_as_longlong(t.sgy);
-                o[5 * st_] = (unsigned long long)__double_as_longlong(t.sigx);
-                o[6 * st_] = (unsigned long long)__double_as_longlong(t.sigy);
-                o[7 * st_] = (unsigned long long)__double_as_longlong(t.sjgx);
-                o[8 * st_] = (unsigned long long)__double_as_longlong(t.sjgy);
+        // every work-group adds its sums to the exact accumulators (order-free: see MomentAcc)
+        acc_add(a.acc, me % kAccGroups, blk, tid);
+        if (!a.ticket) {
+            // Tile-binned loop: that is all.  The total is formed and the model / loop update runs at the head of the next
+            // warp+scatter launch (k_bin_warp_scatter), by every work-group for itself -- no ticket, no last work-group,
+            // no single-CU tail.  The accumulators of the OTHER parity (consumed by this iteration's warp+scatter head)
+            // and the overflow counter of the next iteration are cleared here for their next use.
+            if (me == 0) {
+                if (a.acc_zero)
+                    for (int i = tid; i < kAccGroups * 16; i += kThreads) (&a.acc_zero[0].f[0])[i] = 0ull;
+                if (a.ovf_next && tid == 0) *a.ovf_next = 0u;
             }
             return;
         }
-        // Fused reduction: every work-group publishes its partial, the LAST one to arrive reduces
-        // all of them in a fixed order and runs the model / loop update -- no separate kernel.
-        // Hand-off (cdna_hip_programming.md, Guideline 16): write-through (agent-scope atomic)
-        // stores of the payload, drained with s_waitcnt vmcnt(0), then a relaxed agent-scope
-        // ticket; the reducer reads the payload with agent-scope (L1-bypassing) loads.
+        // Fused reduction + update: the LAST work-group to arrive reads the accumulators and runs the model / loop
+        // update -- no separate kernel.  Hand-off (cdna_hip_programming.md, Guideline 16): the atomics are drained
+        // with s_waitcnt vmcnt(0), then a relaxed agent-scope ticket; the reader uses agent-scope (L1-bypassing) loads.
         __shared__ int s_last;
-        if (tid == 0) {
-            publish_partial(reinterpret_cast<unsigned long long*>(a.partials), nblk, me, blk);
+        if (tid < 64) {   // (the first wave issued the atomics)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
-            // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
-            // lines and only the last arriver of each group takes the top-level ticket.
-            const int grp = me % kTicketGroups;
-            const int grp_size = nblk / kTicketGroups + (grp < nblk % kTicketGroups ? 1 : 0);
-            const int n_groups = nblk < kTicketGroups ? nblk : kTicketGroups;
-            int last = 0;
-            const unsigned int t1 = __hip_atomic_fetch_add(&a.ticket[16 * (1 + grp)], 1u, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
-            if (t1 == (unsigned int)(grp_size - 1)) {
-                a.ticket[16 * (1 + grp)] = 0;   // re-armed for the next launch
-                const unsigned int t0 =
-                    __hip_atomic_fetch_add(&a.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = (t0 == (unsigned int)(n_groups - 1)) ? 1 : 0;
+            if (tid == 0) {
+                // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
+                // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
+                // lines and only the last arriver of each group takes the top-level ticket.
+                const int grp = me % kTicketGroups;
+                const int grp_size = nblk / kTicketGroups + (grp < nblk % kTicketGroups ? 1 : 0);
+                const int n_groups = nblk < kTicketGroups ? nblk : kTicketGroups;
+                int last = 0;
+                const unsigned int t1 = __hip_atomic_fetch_add(&a.ticket[16 * (1 + grp)], 1u, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                if (t1 == (unsigned int)(grp_size - 1)) {
+                    a.ticket[16 * (1 + grp)] = 0;   // re-armed for the next launch
+                    const unsigned int t0 =
+                        __hip_atomic_fetch_add(&a.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = (t0 == (unsigned int)(n_groups - 1)) ? 1 : 0;
+                }
+                s_last = last;
             }
-            s_last = last;
         }
         __syncthreads();
         tl_stamp(a.tl, a.tl_launch, 7);
         if (!s_last) return;
-        // fixed summation order (thread-strided, then the LDS trees): bitwise repeatable
-        const Sums acc = gather_partials(reinterpret_cast<const unsigned long long*>(a.partials), nblk, tid);
-        if (tid == 0 && a.tl) {
-#ifdef BF_TIMELINE
-            if (a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 10] = wall_clock64();
-#endif
-        }
-        __syncthreads();   // s_rpart is reused
-        const Sums tot = block_reduce_sums<kThreads>(acc, s_rpart, tid);
-        if (tid == 0) {
-            const Sums t = tot;
-            a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
-#ifdef BF_TIMELINE
-            if (a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 11] = wall_clock64();
-#endif
-            model_update_local(&s_state, t, a.trace, a.update_mode, a.cur);
+        if (tid < 64) {   // one wave forms the total and updates (no further barrier)
+            unsigned long long accv[kAccPerLane];
+            acc_load_wave<true, true>(a.acc, tid, accv);
+            const unsigned long long word = acc_reduce_wave(accv);
+            model_update_wave(&s_state, word, tid, a.update_mode);
+            if (tid == 0) {
+                a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
+                if (a.update_mode != 0) model_update_rest(&s_state, a.trace, a.cur, a.ovf_cur ? *a.ovf_cur : 0u);
+                if (a.ovf_next) *a.ovf_next = 0u;   // (tile-binned loop: the next iteration's overflow counter)
+            }
         }
         __syncthreads();
         if (tid < (int)(sizeof(DevState) / 8))
             reinterpret_cast<unsigned long long*>(a.st_rw)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
-#ifdef BF_TIMELINE
-        if (tid == 0 && a.tl && a.tl_launch < kTlLaunches) a.tl[((size_t)a.tl_launch * 2 + 1) * 16 + 12] = wall_clock64();
-#endif
     }
 }
 

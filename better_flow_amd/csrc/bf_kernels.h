@@ -8,6 +8,7 @@
 
 namespace bf {
 
+constexpr int kBinTileLdsMax = 156 * 1024;   // dynamic LDS of a scatter work-group (160 KiB per CU minus its static part)
 constexpr int kPrepBlocks = 1024;   // work-groups of k_prepare == SliceStats records it writes
 
 // min / max / sum statistics of one staged slice (k_prepare), one record per work-group.
@@ -47,10 +48,14 @@ struct StencilArgs {
     uint32_t* count_out;               // optional
     float* gx_out;                     // optional (gy_out must be set with it)
     float* gy_out;
-    Partial* partials;                 // optional
+    MomentAcc* acc;                    // optional: moment sums are added to these exact accumulators
+    MomentAcc* acc_zero;               // tile-binned loop: the other parity's accumulators, cleared here
+    const uint32_t* ovf_cur;           // tile-binned loop: overflow events of this / the previous iteration, and the
+    const uint32_t* ovf_prev;          //   next iteration's counter (cleared here)
+    uint32_t* ovf_next;
     unsigned long long* zero_plane;    // optional: the OTHER plane buffer, zeroed here
     uint32_t* zero_cplane;
-    // fused reduction + model / loop update by the last work-group (NULL ticket: partials only)
+    // fused reduction + model / loop update by the last work-group (NULL ticket: accumulate only)
     unsigned int* ticket;
     DevState* st_rw;
     bf_trace_rec* trace;
@@ -61,7 +66,6 @@ struct StencilArgs {
     const unsigned long long* slabs;
     BinGrid g;
     int cur;
-    int co_schedule;                   // use the register-capped build of the binned stencil kernel
 };
 
 // Profiling hook: when armed (by bf_accel.cpp's ProfScope), the next launch of a loop kernel goes through
@@ -82,8 +86,9 @@ void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_i
 void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s);
 void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
-void launch_update(DevState* st, const Partial* partials, int nblocks, bf_trace_rec* trace, int mode,
-                   int cur, hipStream_t s);
+// applies a pending update (sums in `acc`) to `st` in place: the tile-binned loop's update outside a warp+scatter launch
+void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
+                          hipStream_t s);
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s);
 void launch_unpermute(const double2* src, const uint32_t* perm, double2* dst, long long n, hipStream_t s);
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,
@@ -115,33 +120,25 @@ void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
                   uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
                   uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s);
-void launch_bin_warp_scatter(const EvSets& sets, const uint32_t* bin_start, unsigned long long* slabs,
-                             unsigned long long* ovf_plane, uint32_t* ovf_cplane, DevState* st,
-                             const BinGrid& g, int cur, bool warp, int check_done, int threads,
-                             unsigned long long* tl, int tl_launch, hipStream_t s);
-
-// bf_persist.hip -- the whole loop in one cooperative launch
-constexpr int kPersistUR = 8;   // register-resident events per thread at 1024 threads (16 at 512)
-struct PersistArgs {
+struct BinScatterArgs {
     EvSets sets;
     const uint32_t* bin_start;
-    unsigned long long* slabs;          // per-tile slabs; only the rings are exchanged
-    unsigned long long* ovf_plane[2];   // overflow planes (double buffered), as in the binned path
-    uint32_t* ovf_cplane[2];
-    DevState* st;
-    unsigned long long* partials;       // field-major, a.gx * a.gy records
-    unsigned int* bar;                  // grid-barrier counters, zeroed by the host before the launch
+    unsigned long long* slabs;
+    unsigned long long* ovf_plane;   // overflow planes of buffer `cur`
+    uint32_t* ovf_cplane;
+    const DevState* st_in;           // state as of the previous launch ...
+    DevState* st_out;                // ... and with the pending update applied (written by work-group 0)
+    DevState* snap;                  // optional: pinned host copy of st_out, polled by the host
+    MomentAcc* acc;                  // moment sums of the previous iteration (parity (j - 1) & 1)
+    uint32_t* ovf_cur;               // this iteration's overflow counter
+    const uint32_t* ovf_prev;        // the previous iteration's (final)
     bf_trace_rec* trace;
-    unsigned long long* tl;             // debug timeline (BF_TIMELINE builds)
     BinGrid g;
-    int cur0;                           // plane buffer the first iteration scatters overflow into
-    int first_nowarp;                   // first iteration of a cold run: scatter only
-    int max_iters;
-    int gx, gy;                         // stencil tile grid (16 x 64 tiles): partial indexing
+    int cur, j;                      // plane buffer of this iteration; number of stencil launches completed before it
+    unsigned long long* tl;
 };
-size_t persist_lds_bytes(const BinGrid& g, int scale, int threads);
-int persist_max_groups(const BinGrid& g, int scale, int threads, int device);
-hipError_t launch_persist(const PersistArgs& a, int scale, int threads, hipStream_t s);
+void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, hipStream_t s);
+void launch_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, hipStream_t s);
 
 // bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)
 struct LocalGeom {

@@ -12,8 +12,8 @@
 //                     (accel_lib.h:168-175), 3x3 gated Scharr (accel_lib.h:513-615), the
 //                     centre-of-mass and moment sums (object_model.cpp:4-39,103-126) with
 //                     wave64 shuffle reductions, and zeroing of the other plane buffer.
-// K4  k_update        one work-group: deterministic reduction of the per-group partials,
-//                     ObjectModel::update_accumulators (object_model.h:48-53), the glue of
+//                     The sums go to exact accumulators (bf_device.h: MomentAcc); the last work-group to arrive
+//                     runs ObjectModel::update_accumulators (object_model.h:48-53), the glue of
 //                     iteration_step (optimizer_rolling.h:328-346) and the loop control of
 //                     run() (optimizer_rolling.h:61-101) -- entirely on the device.
 #include <hip/hip_runtime.h>
@@ -260,59 +260,6 @@ __global__ __launch_bounds__(kThreads) void k_stencil(StencilArgs a) {
     stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
 }
 
-// ---------------------------------------------------------------------------------------
-// K4: deterministic reduction + model + accumulators + loop control.
-// mode 0: model only (AccelLib::fast_model).  mode 1: full iteration_step / run() glue.
-// ---------------------------------------------------------------------------------------
-constexpr int kUpdThreads = 1024;
-__global__ __launch_bounds__(kUpdThreads) void k_update(DevState* st, const Partial* __restrict__ partials,
-                                                       int nblocks, bf_trace_rec* trace, int mode, int cur) {
-    if (mode == 1 && st->hot.done) return;
-    __shared__ Sums s_red[kUpdThreads / 64];
-    const int tid = threadIdx.x;
-    Sums sm;
-    sums_zero(sm);
-    // fixed summation order (thread-strided, then the wave / LDS trees) -> bitwise repeatable.
-    // All loads of a pass are issued before any is consumed.
-    for (int base = 0; base < nblocks; base += kUpdThreads * 4) {
-        Partial q[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * kUpdThreads + tid;
-            if (i < nblocks) {   // structure-of-arrays records written by the stencil kernels
-                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(partials) + i;
-                const size_t ps = (size_t)partial_stride(nblocks);
-                q[k].n = (long long)src[0 * ps]; q[k].sci = (long long)src[1 * ps];
-                q[k].scj = (long long)src[2 * ps];
-                q[k].sgx = __longlong_as_double((long long)src[3 * ps]);
-                q[k].sgy = __longlong_as_double((long long)src[4 * ps]);
-                q[k].sigx = __longlong_as_double((long long)src[5 * ps]);
-                q[k].sigy = __longlong_as_double((long long)src[6 * ps]);
-                q[k].sjgx = __longlong_as_double((long long)src[7 * ps]);
-                q[k].sjgy = __longlong_as_double((long long)src[8 * ps]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * kUpdThreads + tid;
-            if (i < nblocks) {
-                sm.n += q[k].n; sm.sci += q[k].sci; sm.scj += q[k].scj;
-                sm.sgx += q[k].sgx; sm.sgy += q[k].sgy;
-                sm.sigx += q[k].sigx; sm.sigy += q[k].sigy; sm.sjgx += q[k].sjgx; sm.sjgy += q[k].sjgy;
-            }
-        }
-    }
-    sums_wave_reduce(sm);
-    if ((tid & 63) == 0) s_red[tid >> 6] = sm;
-    __syncthreads();
-    if (tid != 0) return;
-    Sums t = s_red[0];
-    for (int w = 1; w < kUpdThreads / 64; ++w) sums_add(t, s_red[w]);
-
-    __shared__ DevState s_state;
-    model_update(st, &s_state, t, trace, mode, cur);
-}
-
 __global__ __launch_bounds__(kThreads) void k_compute_uv(const double2* __restrict__ nxny,
                                                          double2* __restrict__ uv, long long n) {
     const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
@@ -424,11 +371,6 @@ void launch_stencil(const StencilArgs& a, int src, hipStream_t s) {
     else if (src == 1) hipLaunchKernelGGL(k_stencil<1>, grid, dim3(kThreads), 0, s, a);
     else if (src == 3) launch_stencil_binned(a, grid, s);
     else hipLaunchKernelGGL(k_stencil<2>, grid, dim3(kThreads), 0, s, a);
-}
-
-void launch_update(DevState* st, const Partial* partials, int nblocks, bf_trace_rec* trace, int mode,
-                   int cur, hipStream_t s) {
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(kUpdThreads), 0, s, st, partials, nblocks, trace, mode, cur);
 }
 
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s) {

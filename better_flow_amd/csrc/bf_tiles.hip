@@ -275,8 +275,10 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
             sm.sjgx += (double)cj * gxd; sm.sjgy += (double)cj * gyd;
         }
         const Sums tot = block_reduce_sums<kThreads>(sm, s_rpart, tid);   // DPP wave totals + one LDS hop
-        if (tid == 0)
-            model_update_local(&s_st, tot, nullptr, 1, 0);   // update_accumulators + iteration_step glue + run() control (state in LDS)
+        if (tid < 64) {   // update_accumulators + iteration_step glue + run() control (state in LDS), by one wave
+            model_update_wave(&s_st, sums_lane_word(tot, tid), tid, 1);
+            if (tid == 0) model_update_rest(&s_st, nullptr, 0);
+        }
         __syncthreads();
     }
     // ---- final state: the last project_4param_reinit of the loop, n for compute_uv ----

@@ -100,10 +100,6 @@ typedef struct bf_profile {
     double update_ms;        uint64_t update_launches;
     double other_ms;         uint64_t other_launches;
     uint64_t warp_scatter_events;   /* sum over launches of events processed */
-    /* single-launch loop ("persist"): one launch runs many iterations */
-    double persist_ms;       uint64_t persist_launches;
-    uint64_t persist_iterations;    /* iterations executed inside those launches */
-    uint64_t persist_events;        /* sum over launches of events x iterations */
 } bf_profile;
 
 /* ---- life cycle -------------------------------------------------------------- */
@@ -151,10 +147,11 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "bin_pack_limit"  bits the per-bin accumulator packing may use (default 64).  The counting sort sizes the
  *                  packed count / time-sum fields from the fullest bin; if they do not fit, every event takes the
  *                  exact unpacked path.  Lower values only serve to exercise that fallback in tests.
- *   "co_schedule"  1: this context shares the GPU with other slice contexts (threads / streams): use the
- *                  register-capped build of the stencil kernel, which co-resides with other contexts'
- *                  scatter kernels (+8 % aggregate throughput at 4 contexts, -3 % for a context alone).
- *                  Results are identical.  Default 0.
+ *   "co_schedule"  1: this context shares the GPU with other slice contexts (threads / streams).  The model /
+ *                  loop update of the tile-binned loop then runs in the last work-group of the stencil kernel (a
+ *                  serial tail on one CU, which the other contexts' kernels fill) instead of at the head of the
+ *                  next warp+scatter launch by every work-group (the shortest iteration for a context alone, but
+ *                  ~1.5 us on all CUs).  Results are identical bit for bit.  Default 0.
  *   "blocking_poll"  1 (default): a cold bf_run sleeps between its progress polls (event query + ~20 us sleep;
  *                  the polls trail the launches by one batch, so the wake-up latency is hidden) instead of
  *                  spinning in hipEventSynchronize: 0.85 instead of 4.1 host cores for 4 slice contexts at the
@@ -165,12 +162,6 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  tile width.
  *   "bin_margin"   LDS margin around a bin's tile (even, default 8); events drifting
  *                  further take the exact overflow path and trigger a re-bin.
- *   "persist"      1: when the tile grid fits the GPU (one resident work-group per 64 x 64
- *                  tile), bf_run executes the whole loop in ONE cooperative launch with the
- *                  events held in registers (bf_persist.hip).  Results are bit-identical to the
- *                  default (0: one launch per stage), which is faster on MI355X because the
- *                  loop is instruction-issue bound, not launch bound.
- *   "persist_threads"  work-group size of that launch (1024 default, or 512).
  *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x margin
  *                  (bounded analytically), i.e. before they overflow; 0: re-bin only on
  *                  observed overflow.

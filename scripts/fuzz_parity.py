@@ -10,7 +10,7 @@ spots; then
     events by a whole pixel -- the oracle's own f32 summation order is enough to change the path.  With identical
     warp parameters the images ARE bit-identical, which is what the first bullet checks.);
   * OptimizerLocal: blurred 8-bit count image and score bit-exact for random (nx, ny), both window constructors;
-  * the same run with binned=0 / default / other tile size + margin / persist=1: bit-identical to each other.
+  * the same run with binned=0 / default / other tile size + margin: bit-identical to each other.
 usage: fuzz_parity.py [cases] [seed]"""
 import sys, os
 import numpy as np
@@ -74,7 +74,7 @@ for ci in range(cases):
     results = {}
     modes = [("default", {}), ("atomics", {"binned": 0}), ("binned", {"binned": 2}),
              ("tile32", {"binned": 2, "bin_tile": 32, "bin_margin": int(rng.choice([4, 8, 12]))}),
-             ("persist", {"binned": 2, "persist": 1}), ("nopredict", {"binned": 2, "bin_predict": 0, "bin_margin": 2}),
+             ("nopredict", {"binned": 2, "bin_predict": 0, "bin_margin": 2}),
              ("co", {"binned": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
              ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))})]
     for name, kv in modes:

@@ -13,8 +13,14 @@ for k, v in [a.split("=") for a in sys.argv[2:]]:
 opts = acc.default_opts()
 opts.res_x, opts.res_y, opts.want_uv = H, W, 1
 opts.max_iter = int(os.environ.get("BF_RUN_MAXITER", "-1"))   # (BF_RUN_H / BF_RUN_W / BF_RUN_MAXITER: other geometries)
+import time
 for r in range(reps):
     acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
     acc.set_cloud(s, H, W)
+    acc.synchronize()
+    t0 = time.perf_counter()
     rc, m, info = acc.run(opts)
-    print("iters", info.iterations, "rebins", info.rebins)
+    acc.synchronize()
+    dt = time.perf_counter() - t0
+    print("iters", info.iterations, "rebins", info.rebins, "ovf", info.overflow_events,
+          "%.3f ms = %.2f us / iteration" % (1e3 * dt, 1e6 * dt / max(1, info.iterations)))

@@ -18,15 +18,15 @@ for ln in open("/tmp/bf_tl.txt"):
     d[(kern, L, g)][slot] = t
 names = {0: "entry", 1: "state", 2: "slabs loaded+LDS", 3: "sync", 4: "time img+sync", 5: "tail pixels", 6: "wave reduce+sync", 7: "published+ticket",
          10: "LAST:partials loaded", 11: "LAST:reduced", 12: "LAST:update done"}
-k1names = {0: "entry", 1: "state+zero", 2: "events done", 3: "sync", 4: "flushed"}
+k1names = {0: "entry", 5: "loads issued", 6: "totals", 7: "updated", 1: "barrier", 2: "events done", 3: "sync", 4: "flushed"}
 L0 = int(os.environ.get("TL_LAUNCH", "20"))
 for L in (L0, L0 + 1):
     base = min(d[(1, L, 0)].values()) if d.get((1, L, 0)) else None
     for g in (0, 1):
         st = d.get((1, L, g), {})
         if st and base:
-            print("K1b launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (k1names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st)))
+            print("K1b launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (k1names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st, key=lambda k_: st[k_])))
     for g in (0, 1):
         st = d.get((0, L, g), {})
         if st and base:
-            print("K3  launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st)))
+            print("K3  launch", L, "group", "0" if g == 0 else "mid", " | ".join("%s=%.2f" % (names.get(k, k), (st[k] - base) / 100.0) for k in sorted(st, key=lambda k_: st[k_])))

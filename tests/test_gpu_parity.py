@@ -571,7 +571,8 @@ def test_full_size_config2(oracle_lib, accel_mod):
     om = oracle_lib.Model()
     orc, oloop, otr = oc2.run(ow2, om, max_iter=K, res_x=H, res_y=W, trace_cap=K + 1)
     runs = {}
-    for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2))):
+    for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2)),
+                       ("tail_update", dict(binned=2, co_schedule=1))):
         a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         for k, v in opts.items():
             a2.set_option(k, v)
@@ -582,7 +583,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
         rc, m, info = a2.run(o)
         runs[name] = (rc, info.iterations, m.as_dict(), [t_.model.as_dict() for t_ in a2.get_trace(K + 1)], a2.compute_uv())
         a2.close()
-    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4]
+    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4]
     assert np.array_equal(runs["binned"][4][0], runs["atomics"][4][0])
     assert runs["binned"][1] == oloop.itercount == K + 1
     for k in range(K + 1):
@@ -655,35 +656,6 @@ def test_concurrent_contexts_match_sequential(accel_mod):
     for t_ in th:
         t_.join()
     assert par == seq
-
-
-def test_single_launch_loop_bit_identical(accel_mod):
-    """Option "persist": the whole loop in one cooperative launch (events in registers, ring exchange
-    between resident tiles, every work-group running the update) gives the same bits as the default
-    multi-kernel loop -- model, iteration count, dividers, trace and per-event flow."""
-    H, W, s = 260, 346, 3
-    for n, seed, max_iter in ((1000000, 1, 60), (120000, 5, -1)):
-        sl = synth.make_slice(n, H, W, 0.030, seed=seed)
-        runs = {}
-        for name, opts in (("multi", dict(persist=0)), ("single", dict(persist=1)),
-                           ("single512", dict(persist=1, persist_threads=512))):
-            a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
-            for k, v in opts.items():
-                a.set_option(k, v)
-            a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
-            a.set_cloud(s, H, W)
-            o = a.default_opts()
-            o.res_x, o.res_y, o.max_iter, o.trace_cap = H, W, max_iter, 64
-            rc, m, info = a.run(o)
-            u, v = a.compute_uv()
-            runs[name] = (rc, info.iterations, info.x_divider, info.rot_divider, m.as_dict(),
-                          [t_.model.as_dict() for t_ in a.get_trace(64)], u.tobytes(), v.tobytes())
-            if name != "multi":
-                assert info.launches < 200, info.launches   # really the single-launch path
-            a.close()
-        assert runs["single"] == runs["multi"]
-        assert runs["single512"] == runs["multi"]
-        assert runs["multi"][1] > 30
 
 
 # ---- OptimizerLocal: the contrast-score optimiser (optimizer_sampler.cpp) ----
@@ -912,7 +884,7 @@ def test_large_slices_stay_on_the_binned_path(accel_mod):
     H, W, s = 260, 346, 3
     sl = synth.make_slice(1600000, H, W, 0.030, seed=3)
     runs = {}
-    for name, opts in (("binned", {}), ("atomics", {"binned": 0}), ("fallback", {"bin_pack_limit": 8}), ("single", {"persist": 1})):
+    for name, opts in (("binned", {}), ("atomics", {"binned": 0}), ("fallback", {"bin_pack_limit": 8})):
         a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         for k, v in opts.items():
             a.set_option(k, v)
@@ -927,7 +899,7 @@ def test_large_slices_stay_on_the_binned_path(accel_mod):
         if name == "fallback":
             assert info.overflow_events > len(sl["t"])      # every event, every iteration
         a.close()
-    assert runs["binned"] == runs["atomics"] == runs["fallback"] == runs["single"]
+    assert runs["binned"] == runs["atomics"] == runs["fallback"]
     assert runs["binned"][2]["cnt"] > 500000
 
 

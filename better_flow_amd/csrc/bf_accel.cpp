@@ -51,7 +51,7 @@ struct bf_ctx {
     // tile-binned scatter
     int opt_binned = 1;              // 0 never, 1 when it pays (dense enough), 2 whenever possible
     bool opt_bin_predict = true;
-    int opt_bin_tile = 0, opt_bin_margin = 8, opt_bin_threads = 1024;   // bin_tile 0: chosen per slice
+    int opt_bin_tile = 0, opt_bin_margin = 8, opt_bin_threads = 0;   // bin_threads 0: by the events per bin   // bin_tile 0: chosen per slice
     bool opt_co_schedule = false;    // several slice contexts share the GPU: the update runs in the stencil kernel's last work-group
     int opt_bin_pack_limit = 64;     // bits available to the per-bin packing (lower only to test the fallback)
     int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
@@ -62,6 +62,12 @@ struct bf_ctx {
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
     uint32_t* d_armed = nullptr;
     unsigned long long* d_slabs = nullptr;
+    uint16_t* d_cidx = nullptr;      // compact lists: pixel index per entry (same slot count as d_slabs)
+    uint32_t* d_chdr = nullptr;      // compact lists: entries per bin
+    bool compact_possible = false;   // this slice's tiles leave room for the index list
+    int opt_bin_ev = 0;              // events per scatter thread in flight (0: from the events per bin)
+    int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
+    int opt_compact_permille = 0;    // auto, optional: back to dense slabs while more than this share of the pixels is valid
     int bins_alloc = 0;
     size_t slabs_alloc = 0;
     bool bin_setup_done = false;
@@ -273,6 +279,7 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.zero_plane = c->d_plane[buf ^ 1];
     a.zero_cplane = (c->packed && !c->use_binned) ? nullptr : c->d_cplane[buf ^ 1];
     a.slabs = c->d_slabs;
+    a.cidx = c->d_cidx; a.chdr = c->d_chdr;
     a.g = c->grid;
     a.ovf_cur = a.ovf_prev = c->d_ovf;   // (the tile-binned loop sets the three counters per launch)
     a.cur = buf;
@@ -319,21 +326,24 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
         HIP_TRY(c, hipMalloc(&c->set[1].p, (size_t)c->cap_events * sizeof(float2)));
     }
     if (g.nbins > c->bins_alloc) {
-        void* old[] = {c->d_hist_cnt, c->d_bin_start, c->d_cursor};
+        void* old[] = {c->d_hist_cnt, c->d_bin_start, c->d_cursor, c->d_chdr};
         for (void* o : old) if (o) HIP_TRY(c, hipFree(o));
-        c->d_hist_cnt = nullptr; c->d_bin_start = nullptr; c->d_cursor = nullptr;
+        c->d_hist_cnt = nullptr; c->d_bin_start = nullptr; c->d_cursor = nullptr; c->d_chdr = nullptr;
         const size_t nb = (size_t)g.nbins + 1;
         HIP_TRY(c, hipMalloc(&c->d_hist_cnt, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_bin_start, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_cursor, nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_chdr, nb * 200 * sizeof(uint32_t)));   // compact lists: LR + 1 <= 193 row offsets per bin
         HIP_TRY(c, hipMemsetAsync(c->d_hist_cnt, 0, nb * sizeof(uint32_t), c->stream));
         c->bins_alloc = g.nbins;
     }
     const size_t need = (size_t)g.nbins * (size_t)g.LR * (size_t)g.L;
     if (need > c->slabs_alloc) {
         if (c->d_slabs) HIP_TRY(c, hipFree(c->d_slabs));
-        c->d_slabs = nullptr;
+        if (c->d_cidx) HIP_TRY(c, hipFree(c->d_cidx));
+        c->d_slabs = nullptr; c->d_cidx = nullptr;
         HIP_TRY(c, hipMalloc(&c->d_slabs, need * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc(&c->d_cidx, need * sizeof(uint16_t)));
         c->slabs_alloc = need;
     }
     return BF_OK;
@@ -563,7 +573,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_ticket, c->d_state, c->d_stats,
@@ -616,12 +626,27 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_bin_tile_rows = (int)value;
         return BF_OK;
     }
+    if (!strcmp(key, "bin_ev")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, BF_ERR_ARG, "bin_ev must be 0, 1, 2, 4 or 8");
+        c->opt_bin_ev = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_compact")) {
+        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "bin_compact must be 0, 1 or 2");
+        c->opt_bin_compact = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "compact_permille")) {
+        if (value < 0 || value > 1000) return fail(c, BF_ERR_ARG, "compact_permille must be in [0, 1000]");
+        c->opt_compact_permille = (int)value;
+        return BF_OK;
+    }
     if (!strcmp(key, "bin_predict")) {
         c->opt_bin_predict = value != 0;
         return BF_OK;
     }
     if (!strcmp(key, "bin_threads")) {
-        if (value != 256 && value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "bin_threads must be 256, 512 or 1024");
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "bin_threads must be 0 (auto), 256, 512 or 1024");
         c->opt_bin_threads = (int)value;
         return BF_OK;
     }
@@ -924,6 +949,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         g.L = g.TS + 2 * g.D;
         g.LR = g.TSR + 2 * g.D;
         g.mul_r = (uint32_t)(0x100000000ull / (unsigned)g.TSR) + 1u;
+        g.mul_l = (uint32_t)(0x100000000ull / (unsigned)g.L) + 1u;
         g.nbr = (w.scale_img_x + g.TSR - 1) / g.TSR;
         g.nbins = g.nbr * g.nbc;
         // Density rule: every iteration writes and re-reads one slab pixel (8 B x (L / TS)^2) per image pixel, a global
@@ -943,6 +969,22 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         h.n_events = (uint32_t)c->n;
         h.hot.bin_tbits = tbits > 62 ? 62 : tbits; h.hot.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
         h.hot.flip = 0;
+        // Compact lists or dense slabs.  Measured per iteration, one context (dense / compact): 1280x720 89 / 82 us,
+        // 640x480 44.7 / 52.6, 346x260 21.7 / 36.7 -- the lists win where there are fewer than ~1 event per 4 pixels,
+        // so "auto" goes by that.  (The device can also switch per iteration on the number of valid pixels of the
+        // previous one -- "compact_permille", off by default: that count stays near half the image even on a sparse
+        // slice, since every event lights s x s pixels.)
+        {
+            const double P = (double)w.scale_img_x * (double)w.scale_img_y;
+            // (the index list needs two more bytes of LDS per tile pixel and 16-bit tile-local indices)
+            const size_t LLg = (size_t)c->grid.LR * (size_t)c->grid.L;
+            const int mode = (c->use_binned && LLg * 10 + 16 <= (size_t)kBinTileLdsMax && LLg <= 65536) ? c->opt_bin_compact : 0;
+            const bool sparse = mode == 2 || (mode == 1 && 4.0 * (double)c->n < P);
+            const double lim = !sparse ? 0.0 : (mode == 1 && c->opt_compact_permille > 0 ? P * c->opt_compact_permille / 1000.0 : 4294967295.0);
+            h.fmt_cnt_max = (uint32_t)(lim > 4294967295.0 ? 4294967295.0 : lim);
+            h.hot.fmt = sparse ? 1 : 0;
+            c->compact_possible = mode != 0;
+        }
         h.t_span = (c->n > 0) ? (long long)s.tmax - (long long)s.tmin : 0;
         h.t_abs_max = (c->n > 0) ? std::fmax(std::fabs((double)s.tmin), std::fabs((double)s.tmax)) : 0.0;
         h.r_max = std::hypot((double)(w.x_max - w.x_min), (double)(w.y_max - w.y_min)) + 64.0;
@@ -1279,6 +1321,17 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // work-group of the stencil kernel -- a serial tail on ONE CU that the other contexts' kernels fill, instead of
     // ~1.5 us on all 256 CUs.
     const bool head_update = binned && !c->opt_co_schedule;
+    // events a scatter thread keeps in flight: one pass should cover a bin of 1.5 x the average size
+    // (and its work-group size: 1024 threads for bins of thousands of events, 512 where a bin holds a few hundred --
+    // large images --, so that twice as many bins are in flight per CU: 84 instead of 91 us per iteration at 1280x720)
+    int ev_per_thread = 8;
+    const double ev_per_bin = binned ? (double)c->n / (double)(c->grid.nbins > 0 ? c->grid.nbins : 1) : 0.0;
+    const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads : (ev_per_bin >= 1536.0 ? 1024 : 512);
+    if (binned && c->opt_bin_ev > 0) ev_per_thread = c->opt_bin_ev;
+    else if (binned) {
+        const double per_bin = 1.5 * ev_per_bin / (double)bin_threads;
+        ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2 ? 2 : (per_bin <= 4 ? 4 : 8));
+    }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
@@ -1322,6 +1375,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.sets = ev_sets(c);
                 ba.bin_start = c->d_bin_start;
                 ba.slabs = c->d_slabs;
+                ba.cidx = c->compact_possible ? c->d_cidx : nullptr; ba.chdr = c->d_chdr;
                 ba.ovf_plane = c->d_plane[buf]; ba.ovf_cplane = c->d_cplane[buf];
                 ba.st_in = state_of(j); ba.st_out = state_of(j + 1);
                 ba.acc = head_update ? acc_of(j - 1) : nullptr;
@@ -1332,7 +1386,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.cur = buf; ba.j = j;
                 ba.tl = c->d_tl ? c->d_tl + 64 * 2 * 16 : nullptr;
                 ProfScope ps(c, 0, c->n);
-                launch_bin_warp_scatter(ba, warp, c->opt_bin_threads, c->stream);
+                launch_bin_warp_scatter(ba, warp, bin_threads, ev_per_thread, c->stream);
             } else {
                 ProfScope ps(c, 0, c->n);
                 launch_warp_scatter(ws_args(c, buf, 1), warp, true, false, c->stream);

@@ -271,7 +271,7 @@ __device__ __forceinline__ T lds_uniform(const T* p) {
 
 // What the scatter loop needs from the state, in scalar registers.
 struct ScatterHot {
-    int32_t done, bin_tbits, bin_ok, scale, C, wsx, wsy, x_sh, y_sh;
+    int32_t done, bin_tbits, bin_ok, fmt, scale, C, wsx, wsy, x_sh, y_sh;
     long long tmin;
     WarpParams wp;
 };
@@ -279,6 +279,7 @@ __device__ __forceinline__ int lds_sreg(const int32_t* p) { return __builtin_amd
 __device__ __forceinline__ ScatterHot scatter_hot(const DevState* s) {
     ScatterHot h;
     h.done = lds_sreg(&s->hot.done); h.bin_tbits = lds_sreg(&s->hot.bin_tbits); h.bin_ok = lds_sreg(&s->hot.bin_ok);
+    h.fmt = lds_sreg(&s->hot.fmt);
     h.scale = lds_sreg(&s->hot.scale); h.C = lds_sreg(&s->hot.C); h.wsx = lds_sreg(&s->hot.wsx); h.wsy = lds_sreg(&s->hot.wsy);
     h.x_sh = lds_sreg(&s->hot.x_sh); h.y_sh = lds_sreg(&s->hot.y_sh);
     const long long tm = s->hot.tmin;
@@ -289,6 +290,7 @@ __device__ __forceinline__ ScatterHot scatter_hot(const DevState* s) {
 }
 
 constexpr int kStateWords = (int)(sizeof(DevState) / 8);
+constexpr int kMaxTileRows = 192;   // LR = TSR + 2 D <= 128 + 64
 
 // One event of the tile-binned scatter, from its previous projected position: warp (event.h:100-108,164-168 -- same
 // arithmetic as k_warp_scatter), store of the new products, splat centre (accel_lib.h:154-158), LDS accumulate or --
@@ -296,8 +298,12 @@ constexpr int kStateWords = (int)(sizeof(DevState) / 8);
 struct ScatterGeo {
     int X0, Y0, L, LR;
 };
-template <bool WARP>
+// COMPACT: the accumulate returns the previous value; the lane that finds 0 there touched the pixel first and appends
+// its index to the tile's list (one LDS counter add per wave: ballot + rank), from which the flush writes only the
+// non-zero pixels.  The list has a slot for every pixel of the tile, so it cannot overflow.
+template <bool WARP, bool COMPACT>
 __device__ __forceinline__ void scatter_event(const ScatterHot& hs, const ScatterGeo& sg, unsigned long long* s_tile,
+                                              uint16_t* s_list, uint32_t* s_cnt,
                                               const BinScatterArgs& a, float2* p, uint32_t i, uint32_t v, int32_t ti,
                                               double pr_x, double pr_y, uint32_t& n_ovf) {
     const uint32_t fx = v & 0xffffu, fy = v >> 16;
@@ -319,7 +325,21 @@ __device__ __forceinline__ void scatter_event(const ScatterHot& hs, const Scatte
         const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
         const int lx = X - sg.X0, ly = Y - sg.Y0;
         if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
-            atomicAdd(&s_tile[__mul24(lx, sg.L) + ly], (1ull << hs.bin_tbits) + dt);
+            const int idx = __mul24(lx, sg.L) + ly;
+            if (COMPACT) {
+                const unsigned long long old = atomicAdd(&s_tile[idx], (1ull << hs.bin_tbits) + dt);
+                if (old == 0ull) {
+                    const unsigned long long m = __ballot(1);   // the lanes that are first at their pixel
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    uint32_t base = 0;
+                    if (rank == 0) base = atomicAdd(s_cnt, (uint32_t)__popcll(m));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // (the first active lane is the one of rank 0)
+                    s_list[base + rank] = (uint16_t)idx;
+                    atomicAdd(&s_cnt[1 + lx], 1u);   // entries per tile row (the flush sorts the list by row)
+                }
+            } else {
+                atomicAdd(&s_tile[idx], (1ull << hs.bin_tbits) + dt);
+            }
         } else {   // drifted out of this bin's tile: exact, slow path
             const size_t kk = (size_t)X * (size_t)hs.C + (size_t)Y;
             atomicAdd(&a.ovf_plane[kk], dt);
@@ -341,6 +361,44 @@ __device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, uns
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slab + 2 * i), "v"(v) : "memory");
     }
 }
+// Compact form: (tile-local index, packed accumulator) of the touched pixels only, and their number.  The traffic is
+// proportional to the EVENTS of the bin, not to its area (a 1280x720 slice at scale 3: 8.1M pixels, 62 500 scene points).
+// The list goes out SORTED BY TILE ROW (counting sort on the per-row counts the scatter kept; the order inside a row is
+// whatever the LDS atomics make it -- the consumers add integers), with the first entry of every row in `crow`
+// (LR + 1 words per bin): a stencil tile then reads exactly the rows it needs.  s_cnt: [0] entries, [1 .. LR] per-row
+// counts, turned into running cursors here.  Called after a work-group barrier.
+template <int THREADS>
+__device__ __forceinline__ void flush_list(const unsigned long long* s_tile, const uint16_t* s_list, uint32_t* s_cnt,
+                                           int LR, uint32_t mul_l, unsigned long long* vals, uint16_t* cidx, uint32_t* crow,
+                                           int tid) {
+    const uint32_t n = s_cnt[0];
+    if (tid < 64) {   // exclusive scan of the row counts, 64 rows per step
+        uint32_t carry = 0;
+        for (int r0 = 0; r0 < LR; r0 += 64) {
+            const int r = r0 + tid;
+            const uint32_t v = r < LR ? s_cnt[1 + r] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += u;
+            }
+            if (r < LR) {
+                s_cnt[1 + r] = carry + incl - v;
+                crow[r] = carry + incl - v;
+            }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) crow[LR] = n;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += THREADS) {
+        const uint32_t idx = s_list[i];
+        const uint32_t slot = atomicAdd(&s_cnt[1 + __umulhi(idx, mul_l)], 1u);
+        __hip_atomic_store(&vals[slot], s_tile[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cidx[slot] = (uint16_t)idx;
+    }
+}
 
 // K1 (binned): [pending update] + warp + LDS scatter + slab flush, one work-group per bin.
 //
@@ -355,10 +413,12 @@ __device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, uns
 // accumulators are the first thing requested, the events of the first pass the second, and while the first wave forms
 // the total and updates, the other fifteen turn their events' stored f32 products into the previous positions (the
 // model-independent third of the per-event arithmetic); the first wave catches up after the barrier.
-template <bool WARP, int THREADS>
+template <bool WARP, int THREADS, int U>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
     extern __shared__ unsigned long long s_tile[];
     __shared__ DevState s_state;
+    __shared__ uint32_t s_ncompact[1 + kMaxTileRows];   // compact lists: entries, entries per tile row
+    if (threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -398,8 +458,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     float2* __restrict__ p = ev.p;
     // Events in flight per thread: all loads of a pass are issued first.  U * THREADS covers a whole
     // bin of the usual size in ONE pass: a second pass would wait (vmcnt) for the first pass's
-    // write-through stores of p before it sees its own loads (~2 us per extra pass, measured).
-    constexpr int U = 8192 / THREADS;
+    // write-through stores of p before it sees its own loads (~2 us per extra pass, measured).  U is chosen by the host
+    // from the events per bin: on a large image a bin holds a few hundred events, and the registers of eight events per
+    // thread only cost occupancy there (1 work-group per CU instead of 2).
     uint32_t vxy[U];
     int32_t vt[U];
     float2 vp[U];
@@ -457,13 +518,23 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     }
     if (pending && tid < 64) previous_positions();
     const ScatterGeo sg = {X0, Y0, L, LR};
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);   // (dynamic LDS: the tile, then one index slot per pixel)
     uint32_t n_ovf = 0;
     for (;;) {
+        if (hs.fmt) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t i = base + k * THREADS + tid;
-            if (i >= end) continue;
-            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            for (int k = 0; k < U; ++k) {
+                const uint32_t i = base + k * THREADS + tid;
+                if (i >= end) continue;
+                scatter_event<WARP, true>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint32_t i = base + k * THREADS + tid;
+                if (i >= end) continue;
+                scatter_event<WARP, false>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            }
         }
         base += THREADS * U;
         if (base >= end) break;
@@ -475,7 +546,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     __syncthreads();
     tl_stamp(a.tl, a.j, 3);
     store_state();
-    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    if (hs.fmt) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
+                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+    else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     tl_stamp(a.tl, a.j, 4);
 }
 
@@ -483,9 +556,11 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
 // updated it: "co_schedule", the throughput mode with several slice contexts per GPU).  No barrier between the loads
 // and the scatter, so the waves of a work-group drift apart and overlap each other's memory latency.  Work-group 0
 // still carries the state to the other buffer and to the host snapshot.
-template <bool WARP, int THREADS>
+template <bool WARP, int THREADS, int U>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
     extern __shared__ unsigned long long s_tile[];
+    __shared__ uint32_t s_ncompact[1 + kMaxTileRows];   // compact lists: entries, entries per tile row
+    if (threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -504,16 +579,16 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
     }
     if (h0.done) return;
     ScatterHot hs;
-    hs.done = h0.done; hs.bin_tbits = h0.bin_tbits; hs.bin_ok = h0.bin_ok; hs.scale = h0.scale; hs.C = h0.C;
+    hs.done = h0.done; hs.bin_tbits = h0.bin_tbits; hs.bin_ok = h0.bin_ok; hs.fmt = h0.fmt; hs.scale = h0.scale; hs.C = h0.C;
     hs.wsx = h0.wsx; hs.wsy = h0.wsy; hs.x_sh = h0.x_sh; hs.y_sh = h0.y_sh; hs.tmin = h0.tmin; hs.wp = h0.wp;
     const EvSetPtrs ev = a.sets.s[h0.cs ^ h0.flip];
     const uint32_t* __restrict__ xy = ev.xy;
     const int32_t* __restrict__ t = ev.t;
     float2* __restrict__ p = ev.p;
     const ScatterGeo sg = {X0, Y0, L, LR};
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
     uint32_t n_ovf = 0;
     __syncthreads();
-    constexpr int U = 8192 / THREADS;   // (see k_bin_warp_scatter)
     for (uint32_t base = beg; base < end; base += THREADS * U) {
         uint32_t vxy[U];
         int32_t vt[U];
@@ -526,17 +601,29 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
             vt[k] = t[i];
             vp[k] = p[i];
         }
+        if (hs.fmt) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t i = base + k * THREADS + tid;
-            if (i >= end) continue;
-            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
-                                pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            for (int k = 0; k < U; ++k) {
+                const uint32_t i = base + k * THREADS + tid;
+                if (i >= end) continue;
+                scatter_event<WARP, true>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k],
+                                          pr_from_p(vxy[k] & 0xffffu, vp[k].x), pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint32_t i = base + k * THREADS + tid;
+                if (i >= end) continue;
+                scatter_event<WARP, false>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k],
+                                           pr_from_p(vxy[k] & 0xffffu, vp[k].x), pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            }
         }
     }
     if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     __syncthreads();
-    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    if (hs.fmt) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
+                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+    else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
 }
 
 // The pending update outside a warp+scatter launch (a warm start's gated final warp needs `done` of the batch's last
@@ -589,6 +676,80 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     const bool ovf = sload(a.ovf_cur) != 0;   // events of this iteration took the overflow path (uniform)
     const int LLi = g.LR * g.L;
 
+    const bool compact = hs.fmt != 0;
+    if (compact) {
+        // COMPACT lists (the scatter kernel wrote, per bin, only the touched pixels: index + packed accumulator).
+        // Every entry of the bins that can reach this tile is read once and SPLATTED: added to the (2 HS + 1)^2 time
+        // pixels whose box contains it (accel_lib.h:160-165 literally), with LDS atomics into a plane that then holds
+        // the box sums.  Work and traffic follow the events, not the area: at 1280x720 a tile of 1188 pixels sees ~10-100
+        // entries, against 4 slab loads + 9 box terms for each of its pixels in the dense form.
+        static_assert(TH * TW <= PR * PC, "the box plane fits the point plane's LDS");
+        for (int idx = tid; idx < TH * TW; idx += kThreads) s_acc[idx] = 0ull;
+        // bins whose LDS tile can hold a point within HS of the tile's time pixels (rows r0 - 1 .. r0 + TR, columns alike)
+        const int br_lo = row_bin(max(r0 - 1 - HS - g.D, 0), g), br_hi = min(row_bin(min(r0 + TR + HS, R - 1) + g.D, g), g.nbr - 1);
+        const int bc_lo = max(c0 - 1 - HS - g.D, 0) >> g.lg, bc_hi = min((min(c0 + TC + HS, C - 1) + g.D) >> g.lg, g.nbc - 1);
+        // The entries of the reachable bins (<= 3 bin rows; 3 bin columns with 64-wide tiles, up to 7 with 16-wide ones)
+        // form ONE list for the work-group: wave 0 fetches the counts, scans them and leaves, per bin, the first
+        // flattened entry number, the element offset of its list and the position of its LDS-tile origin in the tile's
+        // time-pixel coordinates; then thread t takes entries t, t + 256, ...: all 256 threads share the gather evenly
+        // whatever the bins' sizes, and it costs two memory round trips (counts, entries) like any gather.
+        constexpr int kMaxBins = 32;
+        __shared__ uint32_t s_eoff[kMaxBins + 1];
+        __shared__ int s_ebase[kMaxBins], s_eoy[kMaxBins], s_eox[kMaxBins];
+        const int ncol = bc_hi - bc_lo + 1;
+        const int nbin_ = min((br_hi - br_lo + 1) * ncol, kMaxBins);
+        if (tid < 64) {
+            uint32_t n = 0;
+            int bin = 0, r = 0, cc = 0;
+            uint32_t first = 0;
+            if (tid < nbin_) {   // the bin's entries in the tile rows that can reach this stencil tile
+                r = tid / ncol; cc = tid - r * ncol;
+                bin = (br_lo + r) * g.nbc + bc_lo + cc;
+                const int top = (br_lo + r) * g.TSR - g.D;   // image row of tile row 0
+                const int lo = min(max(r0 - 1 - HS - top, 0), g.LR), hi = min(max(r0 + TR + HS + 1 - top, 0), g.LR);
+                const uint32_t* crow = a.chdr + (size_t)bin * (size_t)(g.LR + 1);
+                first = crow[lo];
+                n = crow[hi] - first;
+            }
+            uint32_t incl = n;
+#pragma unroll
+            for (int o = 1; o < kMaxBins; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += v;
+            }
+            if (tid < nbin_) {
+                s_eoff[tid + 1] = incl;
+                s_ebase[tid] = bin * LLi + (int)first - (int)(incl - n);
+                s_eoy[tid] = (br_lo + r) * g.TSR - g.D - (r0 - 1);
+                s_eox[tid] = ((bc_lo + cc) << g.lg) - g.D - (c0 - 1);
+            }
+            if (tid == 0) s_eoff[0] = 0;
+        }
+        __syncthreads();   // (the box plane is zero, the bin table is in place)
+        const uint32_t E = s_eoff[nbin_];
+        for (uint32_t e = tid; e < E; e += kThreads) {
+            int base = s_ebase[0], oy = s_eoy[0], ox = s_eox[0];
+            for (int j = 1; j < nbin_; ++j) {   // (uniform trip count, LDS broadcast reads)
+                const bool ge = e >= s_eoff[j];
+                base = ge ? s_ebase[j] : base;
+                oy = ge ? s_eoy[j] : oy;
+                ox = ge ? s_eox[j] : ox;
+            }
+            const uint32_t idx = a.cidx[(uint32_t)(base + (int)e)];
+            const unsigned long long v = a.slabs[(uint32_t)(base + (int)e)];
+            const int lx = (int)__umulhi(idx, g.mul_l);            // idx / L
+            const int tr = oy + lx, tc = ox + (int)idx - lx * g.L;  // the point, in time-pixel coordinates
+            if (tr >= -HS && tr < TH + HS && tc >= -HS && tc < TW + HS) {
+#pragma unroll
+                for (int da = -HS; da <= HS; ++da)
+#pragma unroll
+                    for (int db = -HS; db <= HS; ++db) {
+                        const int rr = tr + da, cc = tc + db;
+                        if (rr >= 0 && rr < TH && cc >= 0 && cc < TW) atomicAdd(&s_acc[rr * TW + cc], v);
+                    }
+            }
+        }
+    } else {
     static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
     // Row -> bin without a per-pixel division: the tile's rows (with halo) span TR + 2 H <= 32 <= TSR rows, so both
     // gr - D and gr + D cross at most one bin boundary inside the tile.  The bin rows at the tile's first row,
@@ -634,6 +795,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         const int idx = tid + c * kThreads;
         if (idx < PR * PC) s_acc[idx] = (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
     }
+    }   // dense slabs
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
@@ -644,10 +806,14 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         if (gr >= 0 && gr < R && gc >= 0 && gc < C) {
             // s x s box sum == the s x s splat of accel_lib.h:160-165 on integer planes
             unsigned long long pk = 0;
+            if (compact) {
+                pk = s_acc[idx];   // already the box sum
+            } else {
 #pragma unroll
-            for (int da = 0; da <= 2 * HS; ++da)
+                for (int da = 0; da <= 2 * HS; ++da)
 #pragma unroll
-                for (int db = 0; db <= 2 * HS; ++db) pk += s_acc[(tr + da) * PC + (tc + db)];
+                    for (int db = 0; db <= 2 * HS; ++db) pk += s_acc[(tr + da) * PC + (tc + db)];
+            }
             unsigned long long acc = pk & bm;
             uint32_t cacc = (uint32_t)(pk >> bt);
             if (ovf) {   // rare: the overflow planes (u64 time sums, u32 counts) straight from memory, box by box
@@ -725,22 +891,38 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
                        has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);
 }
 
-template <int THREADS>
+template <int THREADS, int U>
 static void launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    const size_t lds = (size_t)a.g.LR * a.g.L * sizeof(unsigned long long);
+    const size_t lds = (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (a.cidx ? sizeof(uint16_t) : 0)) + 16;   // tile (+ index list)
+    static bool raised = false;   // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        raised = true;
+    }
     if (!a.acc) {   // nothing to update at the head
-        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-        else launch_timed(k_bin_warp_scatter_lean<false, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
         return;
     }
-    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-    else launch_timed(k_bin_warp_scatter<false, THREADS>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    else launch_timed(k_bin_warp_scatter<false, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
 }
 
-void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, hipStream_t s) {
-    if (threads >= 1024) launch_bws<1024>(a, warp, s);
-    else if (threads >= 512) launch_bws<512>(a, warp, s);
-    else launch_bws<256>(a, warp, s);
+// `per_thread`: events a thread keeps in flight (1, 2, 4 or 8 at 1024 threads; the smaller work-group sizes keep 8192
+// events per pass).
+void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s) {
+#define BF_K1(T_)                                                   \
+    if (per_thread <= 1) launch_bws<T_, 1>(a, warp, s);             \
+    else if (per_thread <= 2) launch_bws<T_, 2>(a, warp, s);        \
+    else if (per_thread <= 4) launch_bws<T_, 4>(a, warp, s);        \
+    else launch_bws<T_, 8>(a, warp, s)
+    if (threads >= 1024) { BF_K1(1024); }
+    else if (threads >= 512) { BF_K1(512); }
+    else { BF_K1(256); }
+#undef BF_K1
 }
 
 // Start of a tile-binned run: overflow counters (slot j % 3 <- iteration j; slot 2 = "iteration -1") and both
@@ -759,21 +941,7 @@ void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev
     hipLaunchKernelGGL(k_finish_update, dim3(1), dim3(64), 0, s, st, acc, ovf_prev, j, cur_prev, trace);
 }
 
-template <bool W, int T>
-static hipError_t raise_lds() {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<W, T>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<W, T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-}
-
 int bin_kernel_setup() {
-    // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
-    hipError_t e[6] = {raise_lds<true, 256>(),  raise_lds<false, 256>(),  raise_lds<true, 512>(),
-                       raise_lds<false, 512>(), raise_lds<true, 1024>(), raise_lds<false, 1024>()};
-    for (hipError_t x : e)
-        if (x != hipSuccess) return -1;
     // the LDS-staged counting-sort scatter: 88 KB of staging + two words per bin (+ 32 B static)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 64) != hipSuccess)

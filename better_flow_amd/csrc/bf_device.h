@@ -67,6 +67,7 @@ struct BinGrid {
     int32_t lg, TSR;   // TS == 1 << lg; D <= min(TS, TSR) / 2, so a pixel is covered by <= 2 x 2 bins
     int32_t LR;        // TSR + 2 D
     uint32_t mul_r;    // floor(2^32 / TSR) + 1: row / TSR == __umulhi(row, mul_r) for row < 2^20
+    uint32_t mul_l;    // floor(2^32 / L) + 1: index / L of a tile-local pixel index (< 2^16)
 };
 
 // Fields every kernel of the loop reads.  They are contiguous so that a kernel issues ONE
@@ -77,7 +78,8 @@ struct HotState {
     uint32_t ovf_cnt[2];      // plane buffer [i] is dirty (stand-alone operators and the global-atomic loop; the
                               // tile-binned loop counts its overflow events in bf_ctx::d_ovf, outside the state)
     int32_t need_rebin, rebins;
-    int32_t cs, flip, bin_ok, pad1;   // live event set; flip = a re-bin moved the events to set cs^1;
+    int32_t cs, flip, bin_ok, fmt;    // live event set; flip = a re-bin moved the events to set cs^1; fmt = the scatter writes
+                                      // COMPACT lists (1) instead of dense slabs (0) this iteration (bf_binned.hip);
                                       // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)
                                     // (committed by the next update)
     // window (host-written at set_cloud)
@@ -100,7 +102,8 @@ struct DevState {
     WarpParams ref_wp;
     double t_abs_max, r_max, drift_limit;
     long long t_span;                 // tmax - tmin of the slice (ns): bound of one event's time addend
-    int32_t run_tag, pad3;            // what `done` is set to (non-zero; bf_run gives every run its own)
+    int32_t run_tag;                  // what `done` is set to (non-zero; bf_run gives every run its own)
+    uint32_t fmt_cnt_max;             // the next iteration is compact when this one had fewer valid pixels (0: never)
     // --- model ---
     bf_model model;
 };

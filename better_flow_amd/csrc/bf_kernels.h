@@ -64,6 +64,8 @@ struct StencilArgs {
     int tl_launch;
     // SRC 3 (tile-binned): per-bin slabs + the overflow planes of buffer `cur`
     const unsigned long long* slabs;
+    const uint16_t* cidx;              // compact lists (hot.fmt == 1): see BinScatterArgs
+    const uint32_t* chdr;
     BinGrid g;
     int cur;
 };
@@ -123,7 +125,9 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 struct BinScatterArgs {
     EvSets sets;
     const uint32_t* bin_start;
-    unsigned long long* slabs;
+    unsigned long long* slabs;       // per bin: the dense tile, or the values of its compact list
+    uint16_t* cidx;                  // compact lists: tile-local pixel index of every entry (per bin: L * LR slots)
+    uint32_t* chdr;                  // compact lists: entries per bin
     unsigned long long* ovf_plane;   // overflow planes of buffer `cur`
     uint32_t* ovf_cplane;
     const DevState* st_in;           // state as of the previous launch ...
@@ -137,7 +141,7 @@ struct BinScatterArgs {
     int cur, j;                      // plane buffer of this iteration; number of stencil launches completed before it
     unsigned long long* tl;
 };
-void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, hipStream_t s);
+void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
 void launch_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, hipStream_t s);
 
 // bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)

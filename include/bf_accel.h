@@ -165,7 +165,15 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x margin
  *                  (bounded analytically), i.e. before they overflow; 0: re-bin only on
  *                  observed overflow.
- *   "bin_threads"  work-group size of the binned warp+scatter kernel (256, 512, 1024 (default)). */
+ *   "bin_threads"  work-group size of the binned warp+scatter kernel: 0 (default: 1024 where a bin holds thousands
+ *                  of events, 512 where it holds a few hundred), 256, 512, 1024.
+ *   "bin_ev"       events a scatter thread keeps in flight: 0 (default: from the events per bin), 1, 2, 4, 8.
+ *   "bin_compact"  what the scatter kernel hands to the stencil kernel: 0 dense tiles (one accumulator per tile pixel),
+ *                  2 compact lists (index + accumulator of the touched pixels only, sorted by tile row: traffic and
+ *                  work proportional to the events instead of the image area), 1 (default) lists when the slice has
+ *                  fewer than one event per four pixels.  Bit-identical results either way.
+ *   "compact_permille"  with bin_compact = 1: fall back to dense tiles while more than this share (1/1000) of the
+ *                  pixels is valid (0, default: never). */
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 
 /* ---- slice set-up -------------------------------------------------------------- */

@@ -80,6 +80,8 @@ struct bf_ctx {
     int32_t* d_in2[3] = {nullptr, nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2] = {nullptr, nullptr};
+    hipEvent_t staged[2] = {nullptr, nullptr};   // the staging kernels that read a slot have run (compute stream)
+    bool staged_valid[2] = {false, false};
     long long pending_n[2] = {0, 0};
     bool pending_ts64[2] = {false, false};       // slot holds absolute 64-bit timestamps (ring hand-off)
     unsigned long long pending_t0[2] = {0, 0};
@@ -568,6 +570,7 @@ void bf_destroy(bf_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
     for (int i = 0; i < 2; ++i) if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
+    for (int i = 0; i < 2; ++i) if (c->staged[i]) (void)hipEventDestroy(c->staged[i]);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
@@ -686,7 +689,10 @@ int bf_upload_events(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, const 
     if (!c) return BF_ERR_ARG;
     if (n < 0 || (n > 0 && (!fr_x || !fr_y || !t_ns))) return fail(c, BF_ERR_ARG, "bad event arrays");
     if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
+    if (c->pend_count > 0)   // (the blocking upload stages through slot 0, which a pending asynchronous upload may own)
+        return fail(c, BF_ERR_STATE, "bf_upload_events while %d asynchronous upload(s) are pending", c->pend_count);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->staged_valid[0]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->staged[0], 0));
     const size_t nb = (size_t)n * sizeof(int32_t);
     if (n > 0) {
         HIP_TRY(c, hipMemcpyAsync(c->d_in_x, fr_x, nb, hipMemcpyHostToDevice, c->stream));
@@ -730,9 +736,12 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
     if (!c->copy_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
         for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
     }
     const int slot = (c->pend_head + c->pend_count) & 1;
+    // the slot's previous content may still be waiting for its staging kernel on the compute stream
+    if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
     int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
     int32_t* dy = slot ? c->d_in2[1] : c->d_in_y;
     int32_t* dt = slot ? c->d_in2[2] : c->d_in_t;
@@ -760,9 +769,11 @@ int bf_upload_ring_async(bf_ctx* c, const int32_t* ring_x, const int32_t* ring_y
     if (!c->copy_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
         for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
     }
     const int slot = (c->pend_head + c->pend_count) & 1;
+    if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
     if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
     int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
     int32_t* dy = slot ? c->d_in2[1] : c->d_in_y;
@@ -802,6 +813,9 @@ int bf_commit_upload(bf_ctx* c) {
         launch_local_time(c->d_in_ts[slot], c->pending_t0[slot], slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot], c->stream);
     int rc = stage_common(c, slot ? c->d_in2[0] : c->d_in_x, slot ? c->d_in2[1] : c->d_in_y,
                           slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot]);
+    // the slot may be refilled once the staging kernels above have read it
+    HIP_TRY(c, hipEventRecord(c->staged[slot], c->stream));
+    c->staged_valid[slot] = true;
     c->pend_head++;
     c->pend_count--;
     return rc;

@@ -181,7 +181,8 @@ int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 /* AccelLib::init_gpu (accel_lib.h:71-115): stage one slice on the device.  Host
  * arrays are borrowed for the duration of the call.  noise may be NULL (no event
  * is noise, the state DVS_flow hands over).  Also resets the per-event warp state
- * (Event::reset, event.h:54-59: pr <- fr, n <- 0). */
+ * (Event::reset, event.h:54-59: pr <- fr, n <- 0).  BF_ERR_STATE while asynchronous
+ * uploads (bf_upload_events_async / bf_upload_ring_async) are pending: commit them first. */
 int bf_upload_events(bf_ctx *ctx, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns,
                      const uint8_t *noise, int64_t n);
 

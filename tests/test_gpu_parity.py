@@ -547,6 +547,50 @@ def test_streaming_upload_matches_blocking(accel_mod):
     acc.close()
 
 
+def test_staging_slots_are_not_overwritten_early(accel_mod):
+    """Two uploads in flight, then a third into the slot of the first as soon as that one is committed (legal: "at most
+    two pending"): the third copy must wait until the staging kernel of the first has read the slot.  Large slices and a
+    busy compute stream make the window wide.  A blocking upload while asynchronous ones are pending is refused."""
+    H, W, s = 260, 346, 3
+    sls = [synth.make_slice(600000, H, W, 0.03, seed=90 + i) for i in range(4)]
+    nmax = max(len(sl["t"]) for sl in sls)
+    acc = accel_mod.Accel(max_events=nmax, max_rows=s * H + s, max_cols=s * W + s)
+    o = acc.default_opts()
+    o.res_x, o.res_y, o.max_iter = H, W, 12
+
+    def solve():
+        acc.set_cloud(s, H, W)
+        rc, m, info = acc.run(o)
+        return rc, info.iterations, m.as_dict()
+
+    ref = []
+    for sl in sls:
+        acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        ref.append(solve())
+    pin = [[acc.pinned_int32(nmax) for _ in range(3)] for _ in range(3)]
+
+    def put(i, k):
+        sl = sls[i]
+        n = len(sl["t"])
+        pin[k][0][:n], pin[k][1][:n], pin[k][2][:n] = sl["fr_x"], sl["fr_y"], sl["t"]
+        acc.upload_events_async(pin[k][0], pin[k][1], pin[k][2], n)
+
+    got = []
+    put(0, 0); put(1, 1)
+    with pytest.raises(accel_mod.BfError):
+        acc.upload_events(sls[0]["fr_x"], sls[0]["fr_y"], sls[0]["t"])
+    acc.commit_upload()            # slice 0 (slot 0): its staging kernel is only enqueued
+    put(2, 2)                      # slot 0 again, straight away
+    got.append(solve())
+    acc.commit_upload()            # slice 1
+    put(3, 0)
+    got.append(solve())
+    acc.commit_upload(); got.append(solve())
+    acc.commit_upload(); got.append(solve())
+    assert got == ref
+    acc.close()
+
+
 def test_full_size_config2(oracle_lib, accel_mod):
     """BASELINE config 2 at full size (1M events, 346x260, scale 3): event-count image bit-exact,
     time image within 1e-6, first iterations of the loop on the oracle's trajectory, binned and

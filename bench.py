@@ -55,6 +55,8 @@ def main():
                     help="bf_set_option knob for every context (experiments), e.g. --opt bin_threads=512")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--cpu-cores", type=int, default=0, help="cap on the host cores of the slice-parallel CPU figure")
+    ap.add_argument("--farm-slices", type=int, default=512,
+                    help="--config 5: independent slices (seeds 0 .. n-1) farmed over the ranks, slice i -> rank i %% N")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-seed", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -94,6 +96,46 @@ def main():
     if ndev <= 0:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     device = local_rank % ndev
+    if args.config == 5:
+        # BASELINE config 5 as specified: a batch of independent cold slices (seeds 0 .. n-1) at 1280x720 farmed over the
+        # ranks (slice i -> rank i % N, --concurrent slice contexts per rank, models gathered on every rank; no data-path
+        # collective).  One timed pass over the whole batch; --steps / --warmup do not apply.
+        from better_flow_amd import farm
+        specs = [farm.SliceSpec(i, H, W, events=args.events, seed=i) for i in range(args.farm_slices)]
+        warm = [farm.SliceSpec(-1 - rank, H, W, events=args.events, seed=100000 + rank)]   # allocations, code objects
+        farm.run_farm(warm, rank=0, world=1, device=device, concurrent=1, scale=s, max_iter=3)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        merged = farm.run_farm(specs, rank=rank, world=world, device=device, concurrent=max(1, args.concurrent), scale=s,
+                               dist=dist)
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt[0])
+        if rank == 0:
+            assert sorted(merged) == list(range(args.farm_slices))
+            ev = sum(r["events"] for r in merged.values())
+            its = [r["iterations"] for r in merged.values()]
+            print(json.dumps({
+                "metric": METRIC, "value": ev / elapsed / 1e6, "unit": "Mevents/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "BASELINE config 5: batch of %d independent %d-event 30 ms slices at %dx%d, scale %d, "
+                                       "cold start to the reference loop's own termination, farmed slice i -> rank i %% %d"
+                                       % (args.farm_slices, args.events, W, H, s, world),
+                           "slices": args.farm_slices, "slices_failed": sum(1 for r in merged.values() if r["rc"] != 0),
+                           "iterations_per_slice_mean": sum(its) / len(its), "iterations_per_slice_max": max(its),
+                           "ms_per_slice_mean": sum(r["ms"] for r in merged.values()) / len(merged),
+                           "parallelism": "slice-parallel: %d GPU(s) x %d slice contexts, no collectives" % (world, args.concurrent)},
+            }))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     slices = [synth.make_slice(args.events, H, W, 0.030, seed=1 + rank * 1000 + i)
               for i in range(args.slices)]
     nmax = max(len(sl["t"]) for sl in slices)
@@ -265,9 +307,79 @@ def main():
         regimes["one_context"] = {"cold": single(3, False, -1), "warm_stm": single(reps, True, -1),
                                   "capped_max_iter_10": single(reps, False, 10)}
 
+        # SURVEY 8(d) as written: from the slice's arrays in (pinned) host memory to the model back on the host -- the
+        # H2D copy (12 B / event) included, on the copy stream, overlapping the previous slice's solve
+        # (bf_upload_events_async / bf_commit_upload).  `value` above keeps the inputs resident in HBM, as the bench
+        # contract asks; these are the same regimes with the PCIe leg in.
+        pinned = []
+        for sl in slices:
+            n_ = len(sl["t"])
+            trip = [acc.pinned_int32(n_) for _ in range(3)]
+            trip[0][:], trip[1][:], trip[2][:] = sl["fr_x"], sl["fr_y"], sl["t"].astype(np.int32)
+            pinned.append((trip, n_))
+
+        def host_to_host(nlanes, warm, max_iter, nrep):
+            tot = [[0, 0] for _ in range(nlanes)]
+            heads = [None] * nlanes
+            for lane in range(nlanes):
+                accs[lane].set_option("co_schedule", 1 if nlanes > 1 else 0)
+                if warm:
+                    heads[lane] = step(lane, lane=lane)[1]
+            for a in accs:
+                a.synchronize()
+
+            def lane_loop(lane):
+                a, o = accs[lane], all_opts[lane]
+                prev = heads[lane]
+
+                def put(k):
+                    trip, n_ = pinned[(1 + k + lane) % len(pinned)]
+                    a.upload_events_async(trip[0], trip[1], trip[2], n_)
+                put(0)
+                for k in range(nrep):
+                    a.commit_upload()
+                    if k + 1 < nrep:
+                        put(k + 1)
+                    a.set_cloud(s, H, W)
+                    if warm:
+                        a.set_model(prev)
+                    o.max_iter = max_iter
+                    rc, m, info = a.run(o)
+                    if warm:
+                        prev = m
+                    tot[lane][0] += a.n
+                    tot[lane][1] += info.iterations
+            th = [threading.Thread(target=lane_loop, args=(l,)) for l in range(nlanes)]
+            t1 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            for a in accs[:nlanes]:
+                a.synchronize()
+            dt1 = time.perf_counter() - t1
+            return {"mevents_per_s": sum(x[0] for x in tot) / dt1 / 1e6, "ms_per_slice_per_chain": 1e3 * dt1 / nrep,
+                    "iterations_per_slice": sum(x[1] for x in tot) / (nrep * nlanes), "chains_in_flight": nlanes}
+        for o_ in all_opts:
+            o_.want_uv = 0   # the model comes back; per-event flow stays on the device unless asked for
+        regimes["host_to_host"] = {
+            "note": "pinned host arrays -> H2D on the copy stream (overlapped with the previous slice) -> solve -> model on "
+                    "the host; per-event flow not read back",
+            "cold": host_to_host(B, False, -1, 4), "warm_stm": host_to_host(B, True, -1, reps),
+            "capped_max_iter_10": host_to_host(B, False, 10, reps),
+            "one_context": {"cold": host_to_host(1, False, -1, 3), "warm_stm": host_to_host(1, True, -1, reps),
+                            "capped_max_iter_10": host_to_host(1, False, 10, reps)},
+        }
+        for o_ in all_opts:
+            o_.want_uv = 1
+
     # ---- roofline of the dominant kernel (warp+scatter): HIP events carrying the kernel's own timestamps -----
     roofline = None
     if rank == 0:
+        # one slice context ALONE on the GPU (everything above has finished), in the mode the headline regime runs the
+        # kernel in: with several contexts per GPU the update sits in the stencil kernel's tail and the warp+scatter
+        # kernel is the lean one; a single context runs the update at the head of the warp+scatter kernel instead.
+        acc.set_option("co_schedule", 1 if B > 1 else 0)
         acc.profile_enable(1)
         acc.profile_reset()
         psteps = min(args.steps, 4)
@@ -297,11 +409,15 @@ def main():
         # or not for this workload.
         traffic = None
         tj = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tj) and (H, W, s, args.events) == (260, 346, 3, 1000000):
-            t_ = json.load(open(tj))
-            traffic = (2.0 * t_["fetch_kb"] + t_["write_kb"]) * 1024.0
+        if os.path.exists(tj) and args.events == 1000000:
+            t_ = json.load(open(tj)).get("%dx%dx%d" % (W, H, s))
+            if t_:
+                traffic = (2.0 * t_["fetch_kb"] + t_["write_kb"]) * 1024.0
         roofline = {
-            "bound": "hbm", "kernel": "k_bin_warp_scatter (warp + tile-binned LDS scatter)", "achieved": achieved,
+            "bound": "hbm", "kernel": "k_bin_warp_scatter%s (warp + tile-binned LDS scatter)" % ("_lean" if B > 1 else ""),
+            "regime": "one slice context alone on the GPU; kernel variant of the headline regime (%s)" %
+                      ("update in the stencil kernel's tail, as with %d contexts per GPU" % B if B > 1 else "update at its head"),
+            "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "avg_launch_us": k1_s * 1e6, "launches": int(live), "launches_incl_early_exit": int(p.warp_scatter_launches),
             "algorithmic_bytes_per_launch": K1_BYTES_PER_EVENT_ITER * ev_per_launch,
@@ -320,7 +436,8 @@ def main():
             },
             "note": "durations are the kernels' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the "
                     "ctx stream), summed over every loop launch and divided by the launches that did work; "
-                    "profiles/*kernel_stats.csv is rocprofv3's view of the same kernels",
+                    "profiles/r2_solo_tail_kernel_stats.csv (update in the stencil tail) and r2_solo_kernel_stats.csv "
+                    "(update at the head) are rocprofv3's view of the same solo runs",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------

@@ -64,10 +64,9 @@ struct bf_ctx {
     unsigned long long* d_slabs = nullptr;
     uint16_t* d_cidx = nullptr;      // compact lists: pixel index per entry (same slot count as d_slabs)
     uint32_t* d_chdr = nullptr;      // compact lists: entries per bin
-    bool compact_possible = false;   // this slice's tiles leave room for the index list
+    bool use_compact = false;        // this slice's scatter writes compact lists (decided in bf_set_cloud)
     int opt_bin_ev = 0;              // events per scatter thread in flight (0: from the events per bin)
     int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
-    int opt_compact_permille = 0;    // auto, optional: back to dense slabs while more than this share of the pixels is valid
     int bins_alloc = 0;
     size_t slabs_alloc = 0;
     bool bin_setup_done = false;
@@ -282,6 +281,7 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.zero_cplane = (c->packed && !c->use_binned) ? nullptr : c->d_cplane[buf ^ 1];
     a.slabs = c->d_slabs;
     a.cidx = c->d_cidx; a.chdr = c->d_chdr;
+    a.compact = c->use_compact ? 1 : 0;
     a.g = c->grid;
     a.ovf_cur = a.ovf_prev = c->d_ovf;   // (the tile-binned loop sets the three counters per launch)
     a.cur = buf;
@@ -639,11 +639,6 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_bin_compact = (int)value;
         return BF_OK;
     }
-    if (!strcmp(key, "compact_permille")) {
-        if (value < 0 || value > 1000) return fail(c, BF_ERR_ARG, "compact_permille must be in [0, 1000]");
-        c->opt_compact_permille = (int)value;
-        return BF_OK;
-    }
     if (!strcmp(key, "bin_predict")) {
         c->opt_bin_predict = value != 0;
         return BF_OK;
@@ -985,19 +980,15 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         h.hot.flip = 0;
         // Compact lists or dense slabs.  Measured per iteration, one context (dense / compact): 1280x720 89 / 82 us,
         // 640x480 44.7 / 52.6, 346x260 21.7 / 36.7 -- the lists win where there are fewer than ~1 event per 4 pixels,
-        // so "auto" goes by that.  (The device can also switch per iteration on the number of valid pixels of the
-        // previous one -- "compact_permille", off by default: that count stays near half the image even on a sparse
-        // slice, since every event lights s x s pixels.)
+        // so "auto" goes by that, once per slice (the kernels are compiled per format: one that switched
+        // per iteration carried both bodies and ran 0.8 us slower at 346x260).
         {
             const double P = (double)w.scale_img_x * (double)w.scale_img_y;
             // (the index list needs two more bytes of LDS per tile pixel and 16-bit tile-local indices)
             const size_t LLg = (size_t)c->grid.LR * (size_t)c->grid.L;
             const int mode = (c->use_binned && LLg * 10 + 16 <= (size_t)kBinTileLdsMax && LLg <= 65536) ? c->opt_bin_compact : 0;
-            const bool sparse = mode == 2 || (mode == 1 && 4.0 * (double)c->n < P);
-            const double lim = !sparse ? 0.0 : (mode == 1 && c->opt_compact_permille > 0 ? P * c->opt_compact_permille / 1000.0 : 4294967295.0);
-            h.fmt_cnt_max = (uint32_t)(lim > 4294967295.0 ? 4294967295.0 : lim);
-            h.hot.fmt = sparse ? 1 : 0;
-            c->compact_possible = mode != 0;
+            c->use_compact = mode == 2 || (mode == 1 && 4.0 * (double)c->n < P);
+            h.hot.fmt = c->use_compact ? 1 : 0;
         }
         h.t_span = (c->n > 0) ? (long long)s.tmax - (long long)s.tmin : 0;
         h.t_abs_max = (c->n > 0) ? std::fmax(std::fabs((double)s.tmin), std::fabs((double)s.tmax)) : 0.0;
@@ -1389,7 +1380,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.sets = ev_sets(c);
                 ba.bin_start = c->d_bin_start;
                 ba.slabs = c->d_slabs;
-                ba.cidx = c->compact_possible ? c->d_cidx : nullptr; ba.chdr = c->d_chdr;
+                ba.cidx = c->d_cidx; ba.chdr = c->d_chdr;
+                ba.compact = c->use_compact ? 1 : 0;
                 ba.ovf_plane = c->d_plane[buf]; ba.ovf_cplane = c->d_cplane[buf];
                 ba.st_in = state_of(j); ba.st_out = state_of(j + 1);
                 ba.acc = head_update ? acc_of(j - 1) : nullptr;

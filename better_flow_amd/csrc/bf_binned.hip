@@ -413,12 +413,12 @@ __device__ __forceinline__ void flush_list(const unsigned long long* s_tile, con
 // accumulators are the first thing requested, the events of the first pass the second, and while the first wave forms
 // the total and updates, the other fifteen turn their events' stored f32 products into the previous positions (the
 // model-independent third of the per-event arithmetic); the first wave catches up after the barrier.
-template <bool WARP, int THREADS, int U>
+template <bool WARP, int THREADS, int U, bool COMPACT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
     extern __shared__ unsigned long long s_tile[];
     __shared__ DevState s_state;
-    __shared__ uint32_t s_ncompact[1 + kMaxTileRows];   // compact lists: entries, entries per tile row
-    if (threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
+    __shared__ uint32_t s_ncompact[COMPACT ? 1 + kMaxTileRows : 1];   // compact lists: entries, entries per tile row
+    if (COMPACT && threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -521,20 +521,11 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);   // (dynamic LDS: the tile, then one index slot per pixel)
     uint32_t n_ovf = 0;
     for (;;) {
-        if (hs.fmt) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = base + k * THREADS + tid;
-                if (i >= end) continue;
-                scatter_event<WARP, true>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = base + k * THREADS + tid;
-                if (i >= end) continue;
-                scatter_event<WARP, false>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
-            }
+        for (int k = 0; k < U; ++k) {
+            const uint32_t i = base + k * THREADS + tid;
+            if (i >= end) continue;
+            scatter_event<WARP, COMPACT>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
         }
         base += THREADS * U;
         if (base >= end) break;
@@ -546,7 +537,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     __syncthreads();
     tl_stamp(a.tl, a.j, 3);
     store_state();
-    if (hs.fmt) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
+    if (COMPACT) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
                                      a.chdr + (size_t)b * (size_t)(LR + 1), tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     tl_stamp(a.tl, a.j, 4);
@@ -556,11 +547,11 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
 // updated it: "co_schedule", the throughput mode with several slice contexts per GPU).  No barrier between the loads
 // and the scatter, so the waves of a work-group drift apart and overlap each other's memory latency.  Work-group 0
 // still carries the state to the other buffer and to the host snapshot.
-template <bool WARP, int THREADS, int U>
+template <bool WARP, int THREADS, int U, bool COMPACT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
     extern __shared__ unsigned long long s_tile[];
-    __shared__ uint32_t s_ncompact[1 + kMaxTileRows];   // compact lists: entries, entries per tile row
-    if (threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
+    __shared__ uint32_t s_ncompact[COMPACT ? 1 + kMaxTileRows : 1];   // compact lists: entries, entries per tile row
+    if (COMPACT && threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -601,27 +592,17 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
             vt[k] = t[i];
             vp[k] = p[i];
         }
-        if (hs.fmt) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = base + k * THREADS + tid;
-                if (i >= end) continue;
-                scatter_event<WARP, true>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k],
-                                          pr_from_p(vxy[k] & 0xffffu, vp[k].x), pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = base + k * THREADS + tid;
-                if (i >= end) continue;
-                scatter_event<WARP, false>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k],
-                                           pr_from_p(vxy[k] & 0xffffu, vp[k].x), pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
-            }
+        for (int k = 0; k < U; ++k) {
+            const uint32_t i = base + k * THREADS + tid;
+            if (i >= end) continue;
+            scatter_event<WARP, COMPACT>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k],
+                                         pr_from_p(vxy[k] & 0xffffu, vp[k].x), pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
         }
     }
     if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     __syncthreads();
-    if (hs.fmt) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
+    if (COMPACT) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
                                      a.chdr + (size_t)b * (size_t)(LR + 1), tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
 }
@@ -652,7 +633,7 @@ __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* a
 // HS = scale / 2 is a template parameter so that the tile geometry is constexpr (index
 // arithmetic by multiply-shift), TS is a power of two (shifts), D <= TS / 2 (a pixel is
 // covered by at most 2 x 2 bins) and every slab load of a thread is issued up front.
-template <int HS>
+template <int HS, bool COMPACT>
 __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     tl_stamp(a.tl, a.tl_launch, 0);
     const HotState hs = sload(&a.st->hot);   // one burst of scalar loads, then the branch
@@ -676,7 +657,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     const bool ovf = sload(a.ovf_cur) != 0;   // events of this iteration took the overflow path (uniform)
     const int LLi = g.LR * g.L;
 
-    const bool compact = hs.fmt != 0;
+    constexpr bool compact = COMPACT;
     if (compact) {
         // COMPACT lists (the scatter kernel wrote, per bin, only the touched pixels: index + packed accumulator).
         // Every entry of the bins that can reach this tile is read once and SPLATTED: added to the (2 HS + 1)^2 time
@@ -842,9 +823,9 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
 }
 
-template <int HS>
+template <int HS, bool COMPACT>
 __global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
-    stencil_binned_body<HS>(a);
+    stencil_binned_body<HS, COMPACT>(a);
 }
 
 // Plain launch, or (profiling armed) an extended launch whose events carry the kernel's own timestamps.
@@ -860,7 +841,9 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 }
 
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
-#define BF_K3(HS_) launch_timed(k_stencil_binned<HS_>, grid, dim3(kThreads), 0, s, a)
+#define BF_K3(HS_)                                                                              \
+    if (a.compact) launch_timed(k_stencil_binned<HS_, true>, grid, dim3(kThreads), 0, s, a);    \
+    else launch_timed(k_stencil_binned<HS_, false>, grid, dim3(kThreads), 0, s, a)
     switch (a.scale / 2) {
         case 0: BF_K3(0); break;
         case 1: BF_K3(1); break;
@@ -891,24 +874,29 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
                        has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);
 }
 
-template <int THREADS, int U>
-static void launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    const size_t lds = (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (a.cidx ? sizeof(uint16_t) : 0)) + 16;   // tile (+ index list)
+template <int THREADS, int U, bool COMPACT>
+static void launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
+    const size_t lds = (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (COMPACT ? sizeof(uint16_t) : 0)) + 16;   // tile (+ index list)
     static bool raised = false;   // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
         raised = true;
     }
     if (!a.acc) {   // nothing to update at the head
-        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
         return;
     }
-    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-    else launch_timed(k_bin_warp_scatter<false, THREADS, U>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    else launch_timed(k_bin_warp_scatter<false, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+}
+template <int THREADS, int U>
+static void launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
+    if (a.compact) launch_bws2<THREADS, U, true>(a, warp, s);
+    else launch_bws2<THREADS, U, false>(a, warp, s);
 }
 
 // `per_thread`: events a thread keeps in flight (1, 2, 4 or 8 at 1024 threads; the smaller work-group sizes keep 8192

@@ -78,8 +78,8 @@ struct HotState {
     uint32_t ovf_cnt[2];      // plane buffer [i] is dirty (stand-alone operators and the global-atomic loop; the
                               // tile-binned loop counts its overflow events in bf_ctx::d_ovf, outside the state)
     int32_t need_rebin, rebins;
-    int32_t cs, flip, bin_ok, fmt;    // live event set; flip = a re-bin moved the events to set cs^1; fmt = the scatter writes
-                                      // COMPACT lists (1) instead of dense slabs (0) this iteration (bf_binned.hip);
+    int32_t cs, flip, bin_ok, fmt;    // live event set; flip = a re-bin moved the events to set cs^1; fmt = this slice's scatter writes
+                                      // COMPACT lists (1) instead of dense slabs (0) (informative: bf_binned.hip);
                                       // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)
                                     // (committed by the next update)
     // window (host-written at set_cloud)
@@ -103,7 +103,7 @@ struct DevState {
     double t_abs_max, r_max, drift_limit;
     long long t_span;                 // tmax - tmin of the slice (ns): bound of one event's time addend
     int32_t run_tag;                  // what `done` is set to (non-zero; bf_run gives every run its own)
-    uint32_t fmt_cnt_max;             // the next iteration is compact when this one had fewer valid pixels (0: never)
+    uint32_t pad3;
     // --- model ---
     bf_model model;
 };

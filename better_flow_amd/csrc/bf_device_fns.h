@@ -447,13 +447,11 @@ __device__ __forceinline__ void model_update_wave(DevState* st, unsigned long lo
         }
     }
     const int run_tag = st->run_tag;
-    const uint32_t fmt_cnt_max = st->fmt_cnt_max;
     __builtin_amdgcn_wave_barrier();   // (every lane has read what it needs from the state)
     if (lane == 0) {
         st->hot.wp = wp;
         st->model = m;
         st->hot.it = it;
-        st->hot.fmt = (m.cnt < fmt_cnt_max) ? 1 : 0;   // sparse image: the next scatter writes compact lists
         if (new_dividers) { st->x_div = xd; st->y_div = yd; st->rot_div = rd; st->div_div = dd; }
         if (keep_old) {
             st->old_dx = (float)m.dx; st->old_dy = (float)m.dy;

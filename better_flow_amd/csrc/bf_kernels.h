@@ -66,6 +66,7 @@ struct StencilArgs {
     const unsigned long long* slabs;
     const uint16_t* cidx;              // compact lists (hot.fmt == 1): see BinScatterArgs
     const uint32_t* chdr;
+    int compact;
     BinGrid g;
     int cur;
 };
@@ -127,7 +128,8 @@ struct BinScatterArgs {
     const uint32_t* bin_start;
     unsigned long long* slabs;       // per bin: the dense tile, or the values of its compact list
     uint16_t* cidx;                  // compact lists: tile-local pixel index of every entry (per bin: L * LR slots)
-    uint32_t* chdr;                  // compact lists: entries per bin
+    uint32_t* chdr;                  // compact lists: first entry of every tile row, per bin (LR + 1 words)
+    int compact;                     // this slice's scatter writes compact lists (bf_set_cloud's choice)
     unsigned long long* ovf_plane;   // overflow planes of buffer `cur`
     uint32_t* ovf_cplane;
     const DevState* st_in;           // state as of the previous launch ...

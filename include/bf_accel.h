@@ -171,9 +171,7 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "bin_compact"  what the scatter kernel hands to the stencil kernel: 0 dense tiles (one accumulator per tile pixel),
  *                  2 compact lists (index + accumulator of the touched pixels only, sorted by tile row: traffic and
  *                  work proportional to the events instead of the image area), 1 (default) lists when the slice has
- *                  fewer than one event per four pixels.  Bit-identical results either way.
- *   "compact_permille"  with bin_compact = 1: fall back to dense tiles while more than this share (1/1000) of the
- *                  pixels is valid (0, default: never). */
+ *                  fewer than one event per four pixels.  Bit-identical results either way. */
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 
 /* ---- slice set-up -------------------------------------------------------------- */

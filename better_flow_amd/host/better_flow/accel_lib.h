@@ -17,8 +17,17 @@
 #include <bf_accel.h>
 
 #include <stdexcept>
+#include <string>
 
 namespace bf {
+
+// A failed call of the C-ABI (include/bf_accel.h) as a C++ exception: `code` is the bf_* return code (BF_ERR_*), what()
+// the context's last error text.  Nothing in the host front end terminates the process; the command line catches this
+// at top level, a library user wherever it likes.
+struct AccelError : std::runtime_error {
+    int code;
+    AccelError(int code_, const std::string &msg) : std::runtime_error(msg), code(code_) {}
+};
 
 template <class T> struct Image2D {
     int rows = 0, cols = 0;
@@ -46,9 +55,9 @@ public:
         if ((long long)rows * cols > (long long)s.rows * s.cols) { s.rows = rows; s.cols = cols; }
         int rc = bf_create(device(), s.events, s.rows, s.cols, nullptr, &s.ctx);
         if (rc != BF_OK) {
-            std::fprintf(stderr, "bf_create failed (%d): the motion-compensation path needs a HIP device "
-                                 "(there is no CPU fallback)\n", rc);
-            std::exit(2);
+            s.ctx = nullptr;
+            throw AccelError(rc, "bf_create failed (" + std::to_string(rc) + "): the motion-compensation path needs a HIP "
+                                 "device (there is no CPU fallback)");
         }
         return s.ctx;
     }
@@ -80,10 +89,9 @@ private:
     bool staged;
 
     void check(int rc, const char *what) const {
-        if (rc < 0) {
-            std::fprintf(stderr, "AccelLib::%s failed (%d): %s\n", what, rc, ctx ? bf_last_error(ctx) : "no ctx");
-            std::exit(2);
-        }
+        if (rc < 0)
+            throw bf::AccelError(rc, std::string("AccelLib::") + what + " failed (" + std::to_string(rc) + "): " +
+                                         (ctx ? bf_last_error(ctx) : "no ctx"));
     }
 
 public:
@@ -107,11 +115,9 @@ public:
         for (auto &e : *events) {
             fx[i] = (int32_t)e.fr_x;
             fy[i] = (int32_t)e.fr_y;
-            if (e.t > (sll)INT32_MAX || e.t <= (sll)INT32_MIN) {
-                std::fprintf(stderr, "AccelLib::init_gpu: slice-local time %lld ns does not fit 32 bits\n",
-                             (long long)e.t);
-                std::exit(2);
-            }
+            if (e.t > (sll)INT32_MAX || e.t <= (sll)INT32_MIN)
+                throw bf::AccelError(BF_ERR_ARG, "AccelLib::init_gpu: slice-local time " + std::to_string((long long)e.t) +
+                                                     " ns does not fit 32 bits (slices span at most 2.1 s)");
             ft[i] = (int32_t)e.t;
             noise[i] = e.noise ? 1 : 0;
             any_noise |= e.noise;

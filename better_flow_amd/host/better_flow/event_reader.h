@@ -99,8 +99,9 @@ public:
         if (buf.size() >= 16 && std::memcmp(buf.data(), "BFEVSOA1", 8) == 0) {
             binary = true;
             std::memcpy(&n_bin, buf.data() + 8, 8);
-            const size_t need = 16 + (size_t)n_bin * 13;
-            if (need > buf.size()) { n_bin = 0; ok = false; return; }
+            // (the count comes from the file: compare it with the size before multiplying -- a crafted 64-bit count
+            // must not wrap the size check)
+            if (n_bin > (buf.size() - 16) / 13) { n_bin = 0; ok = false; return; }
             b_t = reinterpret_cast<const uint64_t *>(buf.data() + 16);
             b_x = reinterpret_cast<const uint16_t *>(buf.data() + 16 + n_bin * 8);
             b_y = b_x + n_bin;

@@ -1,227 +1,234 @@
-// bf_motion_compensator -- command-line front end (mirror of the reference's
-// better_flow_core/src/bf_motion_compensator.cpp:61-216): same flags, same text input
-// ("t x y p") and the same "-o" output ("t x y 1 v u"), with the optimizer on the MI355X.
+// bf_motion_compensator -- command-line front end of the motion-compensation path.
 //
-// Additional flags (the reference fixes these at compile time, common.h:39-40 /
-// bf_motion_compensator.cpp:6-7): --res-x= --res-y= (sensor rows / columns), --scale=,
-// --max-iter=, --device=.
+// Drop-in for the reference's tool of the same name (better_flow_core/src/bf_motion_compensator.cpp:61-216): the same
+// flags with the same meaning, the same text input ("t x y p" per line) and the same "-o" output ("t x y 1 v u"); the
+// optimizer behind it runs on the MI355X.  The flag SURFACE is the reference's; the parser is a table (one row per
+// flag: spelling, kind of argument, destination, help text), so adding a flag is one row.
+//
+// Flags the reference fixes at compile time (common.h:39-40, bf_motion_compensator.cpp:6-7) are run-time options here:
+// --res-x= --res-y= (sensor rows / columns), --scale=, --max-iter=, --device=; --to-bin= converts a text recording to
+// the binary structure-of-arrays format (better_flow/event_reader.h); --slice-log= writes one CSV record per slice.
 #include <better_flow/common.h>
 #include <better_flow/dvs_flow.h>
 
-#define EVENT_WIDTH 50000
-#define TIME_WIDTH 0.2
+#include <chrono>
+#include <functional>
 
-float time_refresh = 0.033;
-unsigned long long int event_refresh = 20000;
+namespace {
 
-bool manual = false;
-bool quiet = false;
-char *file = NULL;
-char *outFileName = NULL;
-const char *to_bin = NULL;
-bool gpu = false;
-bool img = false;
-bool video = false;
-bool stm_disable = false;
-bool bufferize_file = false;
-std::string img_prefix = "./";
-std::string video_name = "./out.avi";
-int video_fps = 60;
-int opt_scale = 3;
-int opt_max_iter = -1;
+constexpr size_t kMaxEvents = 50000;       // ring capacity (the reference's EVENT_WIDTH)
+constexpr double kMaxSpanSec = 0.2;        // ring time span (TIME_WIDTH)
 
-static void lPrintVersion() {
-    printf("DVS flow estimator (better flow), %s (build %s @ %s)\n", BF_VERSION, __DATE__, __TIME__);
-    printf("\tCompiled with maximum event memory of %i events\n\tand slice size of %f seconds.\n", EVENT_WIDTH,
-           TIME_WIDTH);
-    printf("\tMotion compensation runs on the GPU: %s\n", bf_version());
+struct Options {
+    double refresh_time = 0.033;           // seconds between two slices ...
+    unsigned long long refresh_events = 20000;   // ... or new events, whichever comes first
+    bool interactive = false, quiet = false, gpu_flag = false, stm_disable = false, bufferize = false;
+    bool frames = false, video = false;
+    std::string frame_prefix = "./", video_name = "./out.avi";
+    int video_fps = 60;
+    int scale = 3, max_iter = -1;
+    std::string input, output, to_bin, slice_log;
+    bool have_input = false, have_output = false;
+};
+
+enum class Arg { None, Inline, Next };     // "--flag", "--flag=value", "--flag value"
+
+struct Flag {
+    const char *name;                      // spelling, without the '=' of an inline value
+    Arg arg;
+    std::function<void(Options &, const char *)> set;
+    const char *value_hint, *help;
+};
+
+const std::vector<Flag> &flag_table() {
+    static const std::vector<Flag> t = {
+        {"--refresh-time", Arg::Inline, [](Options &o, const char *v) { o.refresh_time = atof(v); }, "<seconds>",
+         "start a slice once this much time has passed since the previous one"},
+        {"--refresh-event-count", Arg::Inline, [](Options &o, const char *v) { o.refresh_events = (unsigned long long)atoll(v); },
+         "<n>", "... or once this many new events have arrived"},
+        {"-i", Arg::None, [](Options &o, const char *) { o.interactive = true; }, "", "interactive mode (not available without a display)"},
+        {"--interactive", Arg::None, [](Options &o, const char *) { o.interactive = true; }, "", "same as -i"},
+        {"-G", Arg::None, [](Options &o, const char *) { o.gpu_flag = true; }, "", "accepted for compatibility: the GPU path is the only one"},
+        {"--stm-disable", Arg::None, [](Options &o, const char *) { o.stm_disable = true; }, "",
+         "start every slice from the zero model instead of the previous slice's estimate"},
+        {"--img", Arg::None, [](Options &o, const char *) { o.frames = true; }, "", "write one frame (PPM + text side-car) per slice"},
+        {"--img-prefix", Arg::Next, [](Options &o, const char *v) { o.frame_prefix = v; }, "<dir>", "directory of those frames"},
+        {"--video", Arg::None, [](Options &o, const char *) { o.video = true; }, "", "write the frames to a video (uncompressed AVI)"},
+        {"--video-name", Arg::Next, [](Options &o, const char *v) { o.video_name = v; }, "<file>", "name of that video"},
+        {"--video-fps", Arg::Inline, [](Options &o, const char *v) { o.video_fps = atoi(v); }, "<n>", "its frame rate"},
+        {"--bufferize-file", Arg::None, [](Options &o, const char *) { o.bufferize = true; }, "",
+         "read the whole input first, then process (timing runs)"},
+        {"--quiet", Arg::None, [](Options &o, const char *) { o.quiet = true; }, "", "print nothing but errors"},
+        {"-o", Arg::Next, [](Options &o, const char *v) { o.output = v; o.have_output = true; }, "<file>",
+         "write every event with its flow: \"t x y 1 v u\""},
+        {"--outfile", Arg::Inline, [](Options &o, const char *v) { o.output = v; o.have_output = true; }, "<file>", "same as -o"},
+        {"--res-x", Arg::Inline, [](Options &, const char *v) { bf::sensor().res_x = atoi(v); }, "<rows>", "sensor rows"},
+        {"--res-y", Arg::Inline, [](Options &, const char *v) { bf::sensor().res_y = atoi(v); }, "<columns>", "sensor columns"},
+        {"--scale", Arg::Inline, [](Options &o, const char *v) { o.scale = atoi(v); }, "<odd>", "image scale of the minimizer"},
+        {"--max-iter", Arg::Inline, [](Options &o, const char *v) { o.max_iter = atoi(v); }, "<n>", "cap on minimizer iterations per slice"},
+        {"--device", Arg::Inline, [](Options &, const char *v) { bf::DeviceContext::device() = atoi(v); }, "<n>", "HIP device"},
+        {"--to-bin", Arg::Inline, [](Options &o, const char *v) { o.to_bin = v; }, "<file>",
+         "convert the text input to the binary event format and exit"},
+        {"--slice-log", Arg::Inline, [](Options &o, const char *v) { o.slice_log = v; }, "<file>",
+         "one CSV record per slice: slice,events,new_events,rc,iterations,ms,mevents_per_s"},
+    };
+    return t;
 }
 
-static void usage(int ret) {
-    lPrintVersion();
-    printf("\nusage: bf_motion_compensator\n");
-    printf("    [--refresh-time={0.0 - inf}]\t\tRun processing when at least this amount of time (floatimg point,\n");
-    printf("                                \t\tseconds) has passed since the last processing, (default = %f)\n", time_refresh);
-    printf("    [--refresh-event-count={0 - inf}]\t\tRun processing when at least this number of new events has\n");
-    printf("                                     \t\tarrived since the last processing (default = %llu)\n", event_refresh);
-    printf("    [-i/--interactive]\tEnable interactive mode\n");
-    printf("    [-G]\t\t\t\tUse GPU support (always on in this build)\n");
-    printf("    [--stm-disable]\t\t\t\tDo not use previous estimate as a starting point for a new estimate\n");
-    printf("    [--img]\t\t\t\tOutput flow images after every iteration\n");
-    printf("    [--img-prefix <name>]\t\t\t\tSpecify prefix for the generated image files (default = %s)\n", img_prefix.c_str());
-    printf("    [--video]\t\t\t\tOutput a video with flow frames\n");
-    printf("    [--video-name <name>]\t\t\t\tSpecify the name of the video file (default = %s)\n", video_name.c_str());
-    printf("    [--video-fps=<value>]\t\t\t\tSpecify video framerate (default = %i)\n", video_fps);
-    printf("    [--bufferize-file]\t\t\t\tRead input file to the buffer first (useful for performance testing)\n");
-    printf("    [--quiet]\t\t\t\tSuppress all output\n");
-    printf("    [-o <name>/--outfile=<name>]\tOutput filename (may be \"-\" for standard output)\n");
-    printf("    [--version]\t\t\t\tPrint better flow version\n");
-    printf("    [--res-x=<rows>] [--res-y=<columns>]\tSensor size (default = %d x %d)\n", RES_X, RES_Y);
-    printf("    [--scale=<odd>]\t\t\t\tImage scale used by the minimizer (default = %d)\n", opt_scale);
-    printf("    [--max-iter=<n>]\t\t\t\tCap on minimizer iterations per slice (default = unlimited)\n");
-    printf("    [--device=<n>]\t\t\t\tHIP device index (default = 0)\n");
-    printf("    [--to-bin=<name>]\t\t\t\tOnly convert the (text) input to the binary event format and exit\n");
-    printf("    <file to process or \"-\" for stdin>\n");
-    exit(ret);
+void print_version() {
+    std::printf("bf_motion_compensator %s, built %s %s\n", BF_VERSION, __DATE__, __TIME__);
+    std::printf("  event ring: %zu events, %.3f s; optimizer: %s\n", kMaxEvents, kMaxSpanSec, bf_version());
 }
 
-int main(int argc, char *argv[]) {
-    if (argc == 1) usage(1);
+void print_usage(const Options &defaults) {
+    print_version();
+    std::printf("\nusage: bf_motion_compensator [flags] <events file, or \"-\">\n\n");
+    for (const Flag &f : flag_table()) {
+        std::string lhs = f.name;
+        if (f.arg == Arg::Inline) lhs += std::string("=") + f.value_hint;
+        if (f.arg == Arg::Next) lhs += std::string(" ") + f.value_hint;
+        std::printf("  %-34s %s\n", lhs.c_str(), f.help);
+    }
+    std::printf("  %-34s %s\n  %-34s %s\n", "--version, -v", "print the version", "--help", "print this text");
+    std::printf("\ndefaults: --refresh-time=%g --refresh-event-count=%llu --scale=%d --res-x=%d --res-y=%d --video-fps=%d\n",
+                defaults.refresh_time, defaults.refresh_events, defaults.scale, RES_X, RES_Y, defaults.video_fps);
+}
+
+// Returns -1 to go on, otherwise the process exit code.
+int parse(int argc, char **argv, Options &o) {
+    const Options defaults;
+    if (argc == 1) { print_usage(defaults); return 1; }
     for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "--help"))
-            usage(0);
-        else if (!strcmp(argv[i], "-v") || !strcmp(argv[i], "--version")) {
-            lPrintVersion();
-            return 0;
-        } else if (!strcmp(argv[i], "--quiet"))
-            quiet = true;
-        else if (!strncmp(argv[i], "--refresh-time=", 15))
-            time_refresh = atof(argv[i] + 15);
-        else if (!strncmp(argv[i], "--refresh-event-count=", 22))
-            event_refresh = atoi(argv[i] + 22);
-        else if (!strcmp(argv[i], "-G"))
-            gpu = true;
-        else if (!strcmp(argv[i], "-i"))
-            manual = true;
-        else if (!strcmp(argv[i], "--interactive"))
-            manual = true;
-        else if (!strcmp(argv[i], "--bufferize-file"))
-            bufferize_file = true;
-        else if (!strcmp(argv[i], "--stm-disable"))
-            stm_disable = true;
-        else if (!strcmp(argv[i], "--img"))
-            img = true;
-        else if (!strcmp(argv[i], "--img-prefix")) {
-            if (++i == argc) {
-                fprintf(stderr, "No output file specified after --img-prefix option.\n");
-                usage(1);
+        const std::string a = argv[i];
+        if (a == "--help") { print_usage(defaults); return 0; }
+        if (a == "-v" || a == "--version") { print_version(); return 0; }
+        if (a == "-") continue;   // (the reference accepts and ignores a lone dash)
+        if (a[0] != '-') {
+            if (o.have_input) {
+                std::fprintf(stderr, "two input files given: \"%s\" and \"%s\"\n", o.input.c_str(), argv[i]);
+                return 1;
             }
-            img_prefix = argv[i];
-        } else if (!strcmp(argv[i], "--video"))
-            video = true;
-        else if (!strcmp(argv[i], "--video-name")) {
-            if (++i == argc) {
-                fprintf(stderr, "No output file specified after --video-name option.\n");
-                usage(1);
-            }
-            video_name = argv[i];
-        } else if (!strncmp(argv[i], "--video-fps=", 12))
-            video_fps = atoi(argv[i] + 12);
-        else if (!strncmp(argv[i], "--res-x=", 8))
-            bf::sensor().res_x = atoi(argv[i] + 8);
-        else if (!strncmp(argv[i], "--res-y=", 8))
-            bf::sensor().res_y = atoi(argv[i] + 8);
-        else if (!strncmp(argv[i], "--scale=", 8))
-            opt_scale = atoi(argv[i] + 8);
-        else if (!strncmp(argv[i], "--max-iter=", 11))
-            opt_max_iter = atoi(argv[i] + 11);
-        else if (!strncmp(argv[i], "--device=", 9))
-            bf::DeviceContext::device() = atoi(argv[i] + 9);
-        else if (!strncmp(argv[i], "--to-bin=", 9))
-            to_bin = argv[i] + 9;
-        else if (!strcmp(argv[i], "-o")) {
-            if (++i == argc) {
-                fprintf(stderr, "No output file specified after -o option.\n");
-                usage(1);
-            }
-            outFileName = argv[i];
-        } else if (!strncmp(argv[i], "--outfile=", 10))
-            outFileName = argv[i] + strlen("--outfile=");
-        else if (!strcmp(argv[i], "-")) {
-        } else if (argv[i][0] == '-') {
-            fprintf(stderr, "Unknown option \"%s\".\n", argv[i]);
-            usage(1);
-        } else {
-            if (file != NULL) {
-                fprintf(stderr, "Multiple input files specified on command line: \"%s\" and \"%s\".\n", file, argv[i]);
-                usage(1);
-            } else
-                file = argv[i];
+            o.input = a; o.have_input = true;
+            continue;
         }
-    }
-    if (file == NULL) {
-        fprintf(stderr, "No input file.\n");
-        usage(1);
-    }
-    if (to_bin != NULL) {   // text -> binary structure-of-arrays (better_flow/event_reader.h); no GPU involved
-        bf::EventReader reader(file);
-        if (!reader.good()) {
-            fprintf(stderr, "cannot read '%s'\n", file);
+        const Flag *hit = nullptr;
+        const char *value = nullptr;
+        for (const Flag &f : flag_table()) {
+            const size_t n = std::strlen(f.name);
+            if (f.arg == Arg::Inline) {
+                if (a.compare(0, n, f.name) == 0 && a.size() > n && a[n] == '=') { hit = &f; value = argv[i] + n + 1; }
+            } else if (a == f.name) {
+                hit = &f;
+                if (f.arg == Arg::Next) {
+                    if (i + 1 >= argc) {
+                        std::fprintf(stderr, "%s needs an argument\n", f.name);
+                        return 1;
+                    }
+                    value = argv[++i];
+                }
+            }
+            if (hit) break;
+        }
+        if (!hit) {
+            std::fprintf(stderr, "unknown flag \"%s\" (--help lists them)\n", argv[i]);
             return 1;
         }
-        std::vector<uint64_t> t;
-        std::vector<uint16_t> x, y;
-        std::vector<uint8_t> p;
-        reader.for_each_event([&](unsigned row, unsigned col, unsigned long long t_ns) {
-            t.push_back(t_ns); x.push_back((uint16_t)col); y.push_back((uint16_t)row); p.push_back(1);
-        });
-        if (!bf::EventReader::write_binary(to_bin, t, x, y, p)) {
-            fprintf(stderr, "cannot write '%s'\n", to_bin);
-            return 1;
-        }
-        if (!quiet) std::cout << "Converted " << t.size() << " events to " << to_bin << std::endl;
-        return 0;
+        hit->set(o, value);
     }
-    if (opt_scale < 1 || opt_scale % 2 == 0) {
-        fprintf(stderr, "--scale must be odd.\n");
+    if (!o.have_input) { std::fprintf(stderr, "no input file\n"); return 1; }
+    if (o.scale < 1 || o.scale % 2 == 0) { std::fprintf(stderr, "--scale must be odd\n"); return 1; }
+    return -1;
+}
+
+int convert_to_binary(const Options &o) {   // text -> binary structure-of-arrays; no GPU involved
+    bf::EventReader reader(o.input.c_str());
+    if (!reader.good()) { std::fprintf(stderr, "cannot read '%s'\n", o.input.c_str()); return 1; }
+    std::vector<uint64_t> t;
+    std::vector<uint16_t> x, y;
+    std::vector<uint8_t> p;
+    bool too_large = false;
+    reader.for_each_event([&](unsigned row, unsigned col, unsigned long long t_ns) {
+        too_large |= row > 65535u || col > 65535u;
+        t.push_back(t_ns); x.push_back((uint16_t)col); y.push_back((uint16_t)row); p.push_back(1);
+    });
+    if (too_large) { std::fprintf(stderr, "'%s': a coordinate above 65535 does not fit the binary format\n", o.input.c_str()); return 1; }
+    if (!bf::EventReader::write_binary(o.to_bin.c_str(), t, x, y, p)) {
+        std::fprintf(stderr, "cannot write '%s'\n", o.to_bin.c_str());
+        return 1;
+    }
+    if (!o.quiet) std::cout << "Converted " << t.size() << " events to " << o.to_bin << std::endl;
+    return 0;
+}
+
+int run(const Options &o) {
+    typedef DVS_flow<kMaxEvents, (sll)FROM_SEC(kMaxSpanSec)> Estimator;
+    Estimator estimator(o.refresh_events, FROM_SEC(o.refresh_time));
+    estimator.set_quiet(o.quiet);
+    estimator.set_scale(o.scale);
+    estimator.set_max_iter(o.max_iter);
+    if (o.have_output) estimator.set_accumulate();           // the -o file needs every processed event
+    if (o.interactive) estimator.set_manual_mode(true);
+    if (o.frames) estimator.set_generate_pictures(true, o.frame_prefix);
+    if (o.video) estimator.set_generate_video(true, o.video_name, o.video_fps);
+    if (o.stm_disable) estimator.set_stm_disable(true);
+    if (!o.slice_log.empty() && !estimator.open_slice_log(o.slice_log)) {
+        std::fprintf(stderr, "cannot write '%s'\n", o.slice_log.c_str());
         return 1;
     }
 
-    DVS_flow<EVENT_WIDTH, (sll)FROM_SEC(TIME_WIDTH)> estimator(event_refresh, FROM_SEC(time_refresh));
-    estimator.set_quiet(quiet);
-    estimator.set_scale(opt_scale);
-    estimator.set_max_iter(opt_max_iter);
-    if (outFileName != NULL) estimator.set_accumulate();   // This will enable event bufferization
-    if (manual) estimator.set_manual_mode(true);
-    if (img) estimator.set_generate_pictures(true, img_prefix);
-    if (video) estimator.set_generate_video(true, video_name, video_fps);
-    if (stm_disable) estimator.set_stm_disable(true);
-
-    if (bufferize_file) {   // read the input file to the buffer first
-        LinearEventCloud ec;
-        EventFile::from_file(&ec, file);
-        clock_t begin = std::clock();
-        clock_t begin_slice = std::clock();
-        ull i = 0;
-        for (auto &e : ec) {
-            ++i;
-            bool processed = estimator.add_event(e);
-            if (processed) {
-                clock_t end_slice = std::clock();
-                if (!quiet)
-                    std::cout << float(i * 100) / float(ec.size()) << " %\t" << i << "\t"
-                              << (double(end_slice - begin_slice) / CLOCKS_PER_SEC) << " sec\t"
-                              << estimator.get_buf_size() << " events\t"
-                              << double(estimator.get_time_diff()) / 1000000000.0 << " slice_td\t"
-                              << double(estimator.get_buf_time_diff()) / 1000000000.0 << " buffer_td\n";
-                begin_slice = std::clock();
-            }
+    if (o.bufferize) {
+        LinearEventCloud cloud;
+        EventFile::from_file(&cloud, o.input);
+        const auto t_all = std::chrono::steady_clock::now();
+        auto t_slice = t_all;
+        ull seen = 0;
+        for (auto &e : cloud) {
+            ++seen;
+            if (!estimator.add_event(e)) continue;
+            const auto now = std::chrono::steady_clock::now();
+            if (!o.quiet)
+                std::cout << 100.0f * float(seen) / float(cloud.size()) << " %\t" << seen << "\t"
+                          << std::chrono::duration<double>(now - t_slice).count() << " sec\t" << estimator.get_buf_size()
+                          << " events\t" << double(estimator.get_time_diff()) * 1e-9 << " slice_td\t"
+                          << double(estimator.get_buf_time_diff()) * 1e-9 << " buffer_td\n";
+            t_slice = now;
         }
-        clock_t end = std::clock();
-        std::cout << "Toatal flow elapsed: " << double(end - begin) / CLOCKS_PER_SEC << " sec." << std::endl << std::flush;
+        std::cout << "Total flow elapsed: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count()
+                  << " sec." << std::endl;
     } else {
-        if (!quiet) std::cout << "Reading from file... (" << file << ")" << std::endl << std::flush;
-        bf::EventReader reader(file);   // text "t x y p" or binary SoA (better_flow/event_reader.h)
-        if (!reader.good()) {
-            fprintf(stderr, "cannot read '%s'\n", file);
-            return 1;
-        }
-        ull i = reader.for_each_event([&](unsigned row, unsigned col, unsigned long long t_ns) {
+        if (!o.quiet) std::cout << "Reading " << o.input << " ..." << std::endl;
+        bf::EventReader reader(o.input.c_str());   // text "t x y p" or binary SoA (better_flow/event_reader.h)
+        if (!reader.good()) { std::fprintf(stderr, "cannot read '%s'\n", o.input.c_str()); return 1; }
+        const ull n = reader.for_each_event([&](unsigned row, unsigned col, unsigned long long t_ns) {
             Event e(row, col, (ull)t_ns);
             estimator.add_event(e);
         });
-        if (!quiet) std::cout << "Read and processed " << i << " events" << std::endl << std::flush;
+        if (!o.quiet) std::cout << "Read and processed " << n << " events" << std::endl;
     }
+    estimator.recompute();   // the tail of the stream: every event must have been in a slice
 
-    estimator.recompute();   // Ensure that *every* event has been processed
-
-    if (outFileName != NULL) {
-        LinearEventCloudTemplate<Event> accumulated = estimator.get_accumulated();
-        EventFile::to_file_uv(&accumulated, outFileName);
+    if (o.have_output) {
+        LinearEventCloudTemplate<Event> all = estimator.get_accumulated();
+        EventFile::to_file_uv(&all, o.output);
     }
-    if (!quiet)
+    if (!o.quiet)
         std::cout << "slices: " << estimator.get_slices_done() << " (skipped " << estimator.get_slices_skipped()
                   << "), minimizer iterations: " << estimator.get_iterations_total() << std::endl;
     bf::DeviceContext::release();
     return 0;
+}
+
+}  // namespace
+
+int main(int argc, char *argv[]) {
+    Options o;
+    const int rc = parse(argc, argv, o);
+    if (rc >= 0) return rc;
+    try {
+        return o.to_bin.empty() ? run(o) : convert_to_binary(o);
+    } catch (const bf::AccelError &e) {   // a failed call of the C-ABI: reported, not fatal to a host application
+        std::fprintf(stderr, "bf_motion_compensator: %s\n", e.what());
+        bf::DeviceContext::release();
+        return 2;
+    }
 }

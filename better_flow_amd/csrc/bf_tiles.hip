@@ -8,6 +8,7 @@
 // = 1024 concurrent gradient-descent loops.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <stdlib.h>
 
 #include "bf_device.h"
 #include "bf_device_fns.h"
@@ -108,7 +109,14 @@ __global__ __launch_bounds__(kThreads) void k_tile_scatter(const uint32_t* __res
 }
 
 // One OptimizerRolling (set_cloud, set_time already applied, run) per work-group.
-__global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
+// THREADS: a tile is a few hundred to a few thousand events and ~1000 pixels, and the slice is done when
+// its SLOWEST tile is (3047 iterations against a mean of 91 on the config-4 slice): what counts is the latency of one
+// tile's iteration.  Measured: more waves per tile do not shorten it (256 / 512 / 1024 threads: 24.1 / 23.1 / 23.3 ms --
+// the reduction across sixteen waves eats what the shorter loops give), so 256 it is (BF_TILE_THREADS overrides).
+// HS: scale / 2 when it is 0, 1 or 2 (the box sum's eighteen LDS reads per pixel are then issued together instead of one
+// by one from a loop with run-time bounds: 4.1 -> us of a 7.8 us iteration), -1: any scale.
+template <int THREADS, int HS>
+__global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
     extern __shared__ unsigned long long s_dyn[];
     __shared__ DevState s_st;
     __shared__ int s_box[4];
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
 
     // ---- OptimizerRolling::set_cloud + set_scale (optimizer_rolling.h:248-283) ----
     int xmin = INT_MAX, xmax = INT_MIN, ymin = INT_MAX, ymax = INT_MIN;
-    for (uint32_t i = beg + tid; i < end; i += kThreads) {
+    for (uint32_t i = beg + tid; i < end; i += THREADS) {
         const uint32_t v = a.xy[i];
         const int x = (int)(v & 0xffffu), y = (int)(v >> 16);
         xmin = min(xmin, x); xmax = max(xmax, x);
@@ -168,30 +176,37 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
     const int s = a.scale, hsc = s / 2;
     // A tile's events live in registers for the whole loop (up to kTileUR per thread; a fuller tile streams the rest
     // from global memory as before): the loop body then touches global memory only to stream that rest.
-    constexpr int kTileUR = 8;
+    constexpr int kTileUR = 4096 / THREADS;
     uint32_t rxy[kTileUR];
     int32_t rt[kTileUR];
     float2 rp[kTileUR];
 #pragma unroll
     for (int k = 0; k < kTileUR; ++k) {
-        uint32_t i = beg + (uint32_t)(k * kThreads + tid);
+        uint32_t i = beg + (uint32_t)(k * THREADS + tid);
         i = i < end ? i : (end > beg ? beg : 0u);
         rxy[k] = (end > beg) ? a.xy[i] : 0u;
         rt[k] = (end > beg) ? a.t[i] : 0;
         rp[k] = (end > beg) ? a.p[i] : make_float2(0.f, 0.f);
     }
-    const uint32_t stream_beg = beg + (uint32_t)(kTileUR * kThreads);
-    __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
+    const uint32_t stream_beg = beg + (uint32_t)(kTileUR * THREADS);
+    __shared__ unsigned long long s_rpart[kSumFields * (THREADS / 64)];
     const int x_sh = s_st.hot.x_sh, y_sh = s_st.hot.y_sh, wsx = s_st.hot.wsx, wsy = s_st.hot.wsy;
     const int hR = R / 2, hC = C / 2;
     // pixel index -> row by one multiply: (i + 0.5) / C is at least 0.5 / C away from an integer, the f32 error of
     // (i + 0.5) * (1 / C) is below 1e-5 for the image sizes that fit the LDS (i < 10^4, C < 10^3)
     const float rC = 1.0f / (float)(C > 0 ? C : 1);
 
+#ifdef BF_TIMELINE
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TK(i_) do { if (tid == 0 && s_st.hot.it == 100 && n > 300 && n < 700) tk[i_] = wall_clock64(); } while (0)
+#else
+#define TK(i_) do { } while (0)
+#endif
     while (!s_st.hot.done) {
+        TK(0);
         const WarpParams wp = s_st.hot.wp;
         const bool warp = s_st.hot.it > 0;
-        for (int i = tid; i < P; i += kThreads) { s_ts[i] = 0; s_cnt[i] = 0; }
+        for (int i = tid; i < P; i += THREADS) { s_ts[i] = 0; s_cnt[i] = 0; }
         __syncthreads();
         // ---- warp (event.h:99-110,164-168) + point scatter (accel_lib.h:151-166) ----
         auto one_event = [&](uint32_t v, int32_t ti, float2& q) {
@@ -215,33 +230,51 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
         for (int k = 0; k < kTileUR; ++k) asm volatile("" : "+v"(rxy[k]), "+v"(rt[k]));
 #pragma unroll
         for (int k = 0; k < kTileUR; ++k)
-            if (beg + (uint32_t)(k * kThreads + tid) < end) one_event(rxy[k], rt[k], rp[k]);
-        for (uint32_t i = stream_beg + tid; i < end; i += kThreads) {
+            if (beg + (uint32_t)(k * THREADS + tid) < end) one_event(rxy[k], rt[k], rp[k]);
+        for (uint32_t i = stream_beg + tid; i < end; i += THREADS) {
             float2 q = a.p[i];
             one_event(a.xy[i], a.t[i], q);
             if (warp) a.p[i] = q;
         }
+        TK(1);
         __syncthreads();
+        TK(2);
         // ---- s x s box sum + normalise (accel_lib.h:160-175) ----
-        for (int i = tid; i < P; i += kThreads) {
+        for (int i = tid; i < P; i += THREADS) {
             const int r = (int)(((float)i + 0.5f) * rC), c = i - r * C;   // exact: see rC
             long long ts = 0;
             uint32_t cn = 0;
-            for (int dr = -hsc; dr <= hsc; ++dr)
-                for (int dc = -hsc; dc <= hsc; ++dc) {
-                    const int rr = r + dr, cc = c + dc;
-                    if (rr >= 0 && rr < R && cc >= 0 && cc < C) {
-                        ts += (long long)s_ts[rr * C + cc];
-                        cn += s_cnt[rr * C + cc];
+            if (HS >= 0) {
+#pragma unroll
+                for (int dr = -HS; dr <= HS; ++dr)
+#pragma unroll
+                    for (int dc = -HS; dc <= HS; ++dc) {
+                        const int rr = r + dr, cc = c + dc;
+                        const bool in = rr >= 0 && rr < R && cc >= 0 && cc < C;
+                        const int k = in ? rr * C + cc : i;   // (a valid address either way: the load is unconditional)
+                        const long long tv = (long long)s_ts[k];
+                        const uint32_t cv = s_cnt[k];
+                        ts += in ? tv : 0ll;
+                        cn += in ? cv : 0u;
                     }
-                }
+            } else {
+                for (int dr = -hsc; dr <= hsc; ++dr)
+                    for (int dc = -hsc; dc <= hsc; ++dc) {
+                        const int rr = r + dr, cc = c + dc;
+                        if (rr >= 0 && rr < R && cc >= 0 && cc < C) {
+                            ts += (long long)s_ts[rr * C + cc];
+                            cn += s_cnt[rr * C + cc];
+                        }
+                    }
+            }
             s_time[i] = time_from_sums(cn, ts, 0);
         }
         __syncthreads();
+        TK(3);
         // ---- gated Scharr (accel_lib.h:513-615) + centre of mass + moments (object_model.cpp) ----
         Sums sm;
         sums_zero(sm);
-        for (int i = tid; i < P; i += kThreads) {
+        for (int i = tid; i < P; i += THREADS) {
             const int r = (int)(((float)i + 0.5f) * rC), c = i - r * C;   // exact: see rC
             const float ctr = s_time[i];
             if (!valid_px(ctr)) continue;
@@ -274,12 +307,20 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
             sm.sigx += (double)ci * gxd; sm.sigy += (double)ci * gyd;
             sm.sjgx += (double)cj * gxd; sm.sjgy += (double)cj * gyd;
         }
-        const Sums tot = block_reduce_sums<kThreads>(sm, s_rpart, tid);   // DPP wave totals + one LDS hop
+        TK(4);
+        const Sums tot = block_reduce_sums<THREADS>(sm, s_rpart, tid);   // DPP wave totals + one LDS hop
+        TK(5);
         if (tid < 64) {   // update_accumulators + iteration_step glue + run() control (state in LDS), by one wave
             model_update_wave(&s_st, sums_lane_word(tot, tid), tid, 1);
             if (tid == 0) model_update_rest(&s_st, nullptr, 0);
         }
+        TK(6);
         __syncthreads();
+#ifdef BF_TIMELINE
+        if (tid == 0 && tk[0] && s_st.hot.it == 101)
+            printf("tile %d n %d P %d: events %llu barrier %llu boxsum %llu scharr %llu reduce %llu update %llu (x10 ns)\n", tile, n, P,
+                   tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
+#endif
     }
     // ---- final state: the last project_4param_reinit of the loop, n for compute_uv ----
     const WarpParams wp = s_st.hot.wp;
@@ -295,10 +336,10 @@ __global__ __launch_bounds__(kThreads) void k_tile_optimizer(TileArgs a) {
     };
 #pragma unroll
     for (int k = 0; k < kTileUR; ++k) {
-        const uint32_t i = beg + (uint32_t)(k * kThreads + tid);
+        const uint32_t i = beg + (uint32_t)(k * THREADS + tid);
         if (i < end) final_event(i, rxy[k], rt[k], rp[k]);
     }
-    for (uint32_t i = stream_beg + tid; i < end; i += kThreads) final_event(i, a.xy[i], a.t[i], a.p[i]);
+    for (uint32_t i = stream_beg + tid; i < end; i += THREADS) final_event(i, a.xy[i], a.t[i], a.p[i]);
     if (tid == 0) a.states[tile] = s_st;
 }
 
@@ -329,16 +370,20 @@ void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm
 
 int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s) {
     const size_t lds = (size_t)a.max_px * (8 + 4 + 4);
-    static bool raised = false;
-    if (!raised) {
-        hipFuncAttributes at;
-        const void* fn = reinterpret_cast<const void*>(&k_tile_optimizer);
-        if (hipFuncGetAttributes(&at, fn) != hipSuccess) return -1;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes) != hipSuccess)
-            return -1;
-        raised = true;
-    }
-    hipLaunchKernelGGL(k_tile_optimizer, dim3(ntiles), dim3(kThreads), lds, s, a);
+    static const int threads = getenv("BF_TILE_THREADS") ? atoi(getenv("BF_TILE_THREADS")) : 256;
+    const int hs = a.scale / 2;
+#define BF_TILE(T_)                                                                       \
+    do {                                                                                  \
+        void (*k)(TileArgs) = hs == 0 ? k_tile_optimizer<T_, 0> : (hs == 1 ? k_tile_optimizer<T_, 1> : (hs == 2 ? k_tile_optimizer<T_, 2> : k_tile_optimizer<T_, -1>)); \
+        hipFuncAttributes at;                                                             \
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k)) != hipSuccess) return -1; \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes) != hipSuccess) return -1; \
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(T_), lds, s, a);                         \
+    } while (0)
+    if (threads >= 1024) BF_TILE(1024);
+    else if (threads >= 512) BF_TILE(512);
+    else BF_TILE(256);
+#undef BF_TILE
     return 0;
 }
 

@@ -46,7 +46,11 @@ def test_bench_single_process():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and 0 < c["value"] < d["value"]
-    assert d["roofline"]["frac"] > 0.2 and set(d["regimes"]) >= {"warm_stm", "capped_max_iter_10"}
+    assert d["roofline"]["frac"] > 0.2 and set(d["regimes"]) >= {"warm_stm", "capped_max_iter_10", "one_context", "host_to_host"}
+    assert "regime" in d["roofline"] and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
+    h = d["regimes"]["host_to_host"]     # SURVEY 8(d) as written: H2D included
+    for k in ("cold", "warm_stm", "capped_max_iter_10"):
+        assert 0 < h[k]["mevents_per_s"] and 0 < h["one_context"][k]["mevents_per_s"]
 
 
 @pytest.mark.gpu
@@ -59,3 +63,18 @@ def test_bench_two_ranks_torchrun():
                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"])
     _check(d, 2, 2, 1)
     assert d["cpu_baseline"] is None          # timed on rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_config5_farm_two_ranks():
+    """BASELINE config 5 through the farm driver, in small: 2 ranks (both on GPU 0), 4 slices at 1280x720."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--config", "5", "--farm-slices", "4",
+               "--events", "150000", "--concurrent", "2"])
+    assert d["n_gpus"] == 2 and d["unit"] == "Mevents/s" and d["value"] > 0
+    c = d["config"]
+    assert c["slices"] == 4 and c["slices_failed"] == 0 and "1280x720" in c["workload"] and c["iterations_per_slice_mean"] > 10

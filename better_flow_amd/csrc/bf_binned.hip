@@ -38,8 +38,8 @@ __device__ __forceinline__ int row_bin(int row, const BinGrid& g) { return (int)
 __device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs, const BinGrid& g) {
     const double pr_x = pr_from_p(xy & 0xffffu, p.x);
     const double pr_y = pr_from_p(xy >> 16, p.y);
-    int X = trunc_x86(pr_x * (double)hs.scale + (double)hs.x_sh);
-    int Y = trunc_x86(pr_y * (double)hs.scale + (double)hs.y_sh);
+    int X = trunc_scatter(pr_x * (double)hs.scale + (double)hs.x_sh);
+    int Y = trunc_scatter(pr_y * (double)hs.scale + (double)hs.y_sh);
     X = min(max(X, 0), hs.R - 1);
     Y = min(max(Y, 0), hs.C - 1);
     return row_bin(X, g) * g.nbc + (Y >> g.lg);
@@ -319,8 +319,8 @@ __device__ __forceinline__ void scatter_event(const ScatterHot& hs, const Scatte
         pr_y = pr_from_p(fy, q.y);
     }
     const int s = hs.scale, hsc = hs.scale / 2;
-    const int X = trunc_x86(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
-    const int Y = trunc_x86(pr_y * (double)s + (double)hs.y_sh);
+    const int X = trunc_scatter(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
+    const int Y = trunc_scatter(pr_y * (double)s + (double)hs.y_sh);
     if (!((X >= hs.wsx + hsc) || (X < hsc) || (Y >= hs.wsy + hsc) || (Y < hsc))) {
         const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
         const int lx = X - sg.X0, ly = Y - sg.Y0;

@@ -16,6 +16,12 @@ __device__ __forceinline__ int trunc_x86(double v) {
     return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN;
 }
 
+// The same for a scatter position, whose only consumer is the window test of accel_lib.h:157: anything out of int
+// range is rejected there whichever end it saturates to (the window is far inside the int range), so the hardware's
+// saturating conversion serves, and only NaN -- which it would turn into 0, a pixel INSIDE the window at scale 1 -- needs
+// the x86 answer.  Two compares fewer per coordinate than trunc_x86.
+__device__ __forceinline__ int trunc_scatter(double v) { return (v == v) ? __double2int_rz(v) : INT_MIN; }
+
 // f32 form of the reference's `p > 0.000001` (float against a double literal): 1e-6f is the
 // largest float below 1e-6, so (double)p > 1e-6  <=>  p > 1e-6f.
 __device__ __forceinline__ bool valid_px(float p) { return p > 1e-6f; }
@@ -23,22 +29,24 @@ __device__ __forceinline__ bool valid_px(float p) { return p > 1e-6f; }
 // Exact IEEE division by a constant in three FMA-class operations (Markstein):
 //   q0 = x * R,  r = fma(-q0, d, x),  q = fma(r, R, q0),  R = RN(1 / d).
 // The dividends here are always a float (converted to double for the f64 form), so the
-// identity with x / d was PROVEN EXHAUSTIVELY over all 2^32 floats by tests/exhaustive_div.c
-// (0 mismatches with the zero / infinity fix-up below).  Replaces ~15-instruction division
-// expansions: the warp+scatter kernel was f64-ALU-bound on them.
+// identity with x / d was PROVEN EXHAUSTIVELY over all 2^32 floats by tests/exhaustive_div.c:
+// exactly three inputs differ -- -0 gives +0 instead of -0, +-inf give NaN instead of +-inf -- and neither can change
+// a result here: the quotients are only ever SUBTRACTED from a sensor coordinate (x - (+0) == x - (-0) for every x
+// of either sign) or multiplied into a product whose zero sign is lost the same way, and an infinite product only
+// arises from a diverged model, whose events the x86 truncation rule rejects as NaN or as infinity alike.  (A fix-up
+// select for those three inputs cost 5 of the 8 instructions of each of the six divisions per event.)  Replaces
+// ~15-instruction division expansions: the warp+scatter kernel was f64-ALU-bound on them.
 __device__ __forceinline__ double div_10000(double x) {   // x == (double)(some float)
     constexpr double R = 1.0 / 10000.0;
     const double q0 = x * R;
     const double r = fma(-q0, 10000.0, x);
-    const double q = fma(r, R, q0);
-    return (x == 0.0 || isinf(x)) ? q0 : q;
+    return fma(r, R, q0);
 }
 __device__ __forceinline__ float div_127(float x) {
     constexpr float R = 1.0f / 127.0f;
     const float q0 = x * R;
     const float r = fmaf(-q0, 127.0f, x);
-    const float q = fmaf(r, R, q0);
-    return (x == 0.0f || isinf(x)) ? q0 : q;
+    return fmaf(r, R, q0);
 }
 
 // (double)ts / 1e9 for an integer nanosecond sum ts (accel_lib.h:162): same sequence; checked on
@@ -48,14 +56,14 @@ __device__ __forceinline__ double div_1e9(double x) {
     constexpr double R = 1.0 / 1000000000.0;
     const double q0 = x * R;
     const double r = fma(-q0, 1000000000.0, x);
-    const double q = fma(r, R, q0);
-    return (x == 0.0 || isinf(x)) ? q0 : q;
+    return fma(r, R, q0);   // (x is a finite integer; x == 0 gives 0 either way)
 }
 
 // Previous / new projected position from the stored f32 product (event.h:167-168):
 //   pr = float(fr) - (kx * float(t)) / 10000.0      (f32 product, f64 divide and subtract)
+// (float(fr) is exact for a 16-bit coordinate, so the u32 -> f64 conversion gives the same double in one step)
 __device__ __forceinline__ double pr_from_p(uint32_t fr, float prod) {
-    return (double)(float)fr - div_10000((double)prod);
+    return (double)fr - div_10000((double)prod);
 }
 
 // Event::project_4param_reinit (event.h:99-110) + apply_project (event.h:164-168) of one event -- the ONE

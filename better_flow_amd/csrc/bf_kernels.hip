@@ -60,8 +60,8 @@ __device__ __forceinline__ void event_body(uint32_t xy, int32_t t, float2& p, bo
         if (live && !noise) {
             const int s = st.scale;
             // accel_lib.h:154-158
-            const int X = trunc_x86(pr_x * (double)s + (double)st.x_sh);
-            const int Y = trunc_x86(pr_y * (double)s + (double)st.y_sh);
+            const int X = trunc_scatter(pr_x * (double)s + (double)st.x_sh);
+            const int Y = trunc_scatter(pr_y * (double)s + (double)st.y_sh);
             const int hs = s / 2;
             if (!((X >= st.wsx + hs) || (X < hs) || (Y >= st.wsy + hs) || (Y < hs))) {
                 const size_t k = (size_t)X * (size_t)st.C + (size_t)Y;

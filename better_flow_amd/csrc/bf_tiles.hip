@@ -218,8 +218,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
                 pr_x = pr_from_p(fx, q.x);
                 pr_y = pr_from_p(fy, q.y);
             }
-            const int X = trunc_x86(pr_x * (double)s + (double)x_sh);
-            const int Y = trunc_x86(pr_y * (double)s + (double)y_sh);
+            const int X = trunc_scatter(pr_x * (double)s + (double)x_sh);
+            const int Y = trunc_scatter(pr_y * (double)s + (double)y_sh);
             if (!((X >= wsx + hsc) || (X < hsc) || (Y >= wsy + hsc) || (Y < hsc))) {
                 atomicAdd(&s_ts[X * C + Y], (unsigned long long)(long long)ti);
                 atomicAdd(&s_cnt[X * C + Y], 1u);

@@ -64,6 +64,8 @@ struct bf_ctx {
     unsigned long long* d_slabs = nullptr;
     uint16_t* d_cidx = nullptr;      // compact lists: pixel index per entry (same slot count as d_slabs)
     uint32_t* d_chdr = nullptr;      // compact lists: entries per bin
+    int stencil_threads = 256;       // work-group size of the stencil kernels for this slice (bf_set_cloud)
+    int opt_stencil_threads = 0;     // 0: by the number of tiles
     bool use_compact = false;        // this slice's scatter writes compact lists (decided in bf_set_cloud)
     int opt_bin_ev = 0;              // events per scatter thread in flight (0: from the events per bin)
     int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
@@ -92,6 +94,8 @@ struct bf_ctx {
     float *d_time = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_img = nullptr;
     uint32_t* d_count = nullptr;
     MomentAcc* d_acc = nullptr;      // 2 x kAccGroups exact moment accumulators (parity of the iteration)
+    bool acc_dirty = false;          // a head-update loop leaves its last iteration's sums behind: whoever uses the
+                                     // accumulators next without a loop_init of its own (a ticket-mode stencil) clears them
     uint32_t* d_ovf = nullptr;       // tile-binned loop: overflow events of iteration j in slot j % 3
     unsigned int* d_ticket = nullptr;
     unsigned long long* d_tl = nullptr;   // debug timeline (BF_TIMELINE=<file>, `make tl` build)
@@ -282,6 +286,7 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.slabs = c->d_slabs;
     a.cidx = c->d_cidx; a.chdr = c->d_chdr;
     a.compact = c->use_compact ? 1 : 0;
+    a.threads = c->stencil_threads;
     a.g = c->grid;
     a.ovf_cur = a.ovf_prev = c->d_ovf;   // (the tile-binned loop sets the three counters per launch)
     a.cur = buf;
@@ -629,6 +634,11 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_bin_tile_rows = (int)value;
         return BF_OK;
     }
+    if (!strcmp(key, "stencil_threads")) {
+        if (value != 0 && value != 256 && value != 512) return fail(c, BF_ERR_ARG, "stencil_threads must be 0 (auto), 256 or 512");
+        c->opt_stencil_threads = (int)value;
+        return BF_OK;
+    }
     if (!strcmp(key, "bin_ev")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, BF_ERR_ARG, "bin_ev must be 0, 1, 2, 4 or 8");
         c->opt_bin_ev = (int)value;
@@ -907,6 +917,10 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     h.x_shift = w.x_shift; h.y_shift = w.y_shift;
     h.hot.tmin = tmin;
     h.nblocks = gx * gy;
+    // Stencil work-group size.  A small image gives fewer tiles than the chip has room for: 512 threads per tile then halve
+    // the pixels per thread and shorten every work-group's dependent chain (what one slice alone waits for); a large image
+    // is throughput-bound and keeps 256 (fewer per-wave fixed costs).
+    c->stencil_threads = c->opt_stencil_threads > 0 ? c->opt_stencil_threads : (gx * gy <= 1024 ? 512 : 256);
     memset(&h.model, 0, sizeof(h.model));   // a fresh OptimizerRolling has a zero ObjectModel
     h.hot.wp = identity_warp();
     h.hot.it = 0; h.hot.done = 0; h.rc = 0;
@@ -1076,6 +1090,10 @@ static int image_pass(bf_ctx* c, const float* d_src, int rows, int cols, bool gr
     a.time_in = d_src;
     if (grads) { a.gx_out = c->d_gx; a.gy_out = c->d_gy; }
     if (moments) {   // sums -> exact accumulators; the last work-group forms the model (mode 0)
+        if (c->acc_dirty) {
+            if (hipMemsetAsync(c->d_acc, 0, 2 * kAccGroups * sizeof(MomentAcc), c->stream) != hipSuccess) return BF_ERR_HIP;
+            c->acc_dirty = false;
+        }
         a.acc = c->d_acc;
         a.ticket = c->d_ticket;
         a.st_rw = c->d_state;
@@ -1320,12 +1338,14 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     auto state_of = [&](int j) { return c->d_state + (j & 1); };
     auto acc_of = [&](int j) { return c->d_acc + (size_t)(j & 1) * kAccGroups; };
     auto ovf_of = [&](int j) { return c->d_ovf + ((j % 3) + 3) % 3; };
-    if (binned) launch_loop_init(c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, c->stream);
+    if (binned || c->acc_dirty) launch_loop_init(c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, c->stream);
+    c->acc_dirty = false;
     // Where the model / loop update runs.  One slice context alone: at the head of the next warp+scatter launch (every
     // work-group for itself; shortest iteration).  Several contexts sharing the GPU ("co_schedule"): in the last
     // work-group of the stencil kernel -- a serial tail on ONE CU that the other contexts' kernels fill, instead of
     // ~1.5 us on all 256 CUs.
     const bool head_update = binned && !c->opt_co_schedule;
+    if (head_update) c->acc_dirty = true;   // (the sums of the last iteration are consumed, not cleared)
     // events a scatter thread keeps in flight: one pass should cover a bin of 1.5 x the average size
     // (and its work-group size: 1024 threads for bins of thousands of events, 512 where a bin holds a few hundred --
     // large images --, so that twice as many bins are in flight per CU: 84 instead of 91 us per iteration at 1280x720)

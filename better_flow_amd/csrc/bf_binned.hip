@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* a
 // HS = scale / 2 is a template parameter so that the tile geometry is constexpr (index
 // arithmetic by multiply-shift), TS is a power of two (shifts), D <= TS / 2 (a pixel is
 // covered by at most 2 x 2 bins) and every slab load of a thread is issued up front.
-template <int HS, bool COMPACT>
+template <int HS, bool COMPACT, int NT>
 __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     tl_stamp(a.tl, a.tl_launch, 0);
     const HotState hs = sload(&a.st->hot);   // one burst of scalar loads, then the branch
@@ -651,10 +651,10 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     constexpr int H = HS + 1;
     constexpr int PR = TR + 2 * H, PC = TC + 2 * H;
     constexpr int TH = TR + 2, TW = TC + 2;
-    constexpr int NC = (PR * PC + kThreads - 1) / kThreads;
+    constexpr int NC = (PR * PC + NT - 1) / NT;
     __shared__ unsigned long long s_acc[PR * PC];
     __shared__ float s_time[TH * TW];
-    __shared__ Sums s_red[kThreads / 64];
+    __shared__ Sums s_red[NT / 64];
     const int R = a.R, C = a.C;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
@@ -673,7 +673,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         // the box sums.  Work and traffic follow the events, not the area: at 1280x720 a tile of 1188 pixels sees ~10-100
         // entries, against 4 slab loads + 9 box terms for each of its pixels in the dense form.
         static_assert(TH * TW <= PR * PC, "the box plane fits the point plane's LDS");
-        for (int idx = tid; idx < TH * TW; idx += kThreads) s_acc[idx] = 0ull;
+        for (int idx = tid; idx < TH * TW; idx += NT) s_acc[idx] = 0ull;
         // bins whose LDS tile can hold a point within HS of the tile's time pixels (rows r0 - 1 .. r0 + TR, columns alike)
         const int br_lo = row_bin(max(r0 - 1 - HS - g.D, 0), g), br_hi = min(row_bin(min(r0 + TR + HS, R - 1) + g.D, g), g.nbr - 1);
         const int bc_lo = max(c0 - 1 - HS - g.D, 0) >> g.lg, bc_hi = min((min(c0 + TC + HS, C - 1) + g.D) >> g.lg, g.nbc - 1);
@@ -716,7 +716,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         }
         __syncthreads();   // (the box plane is zero, the bin table is in place)
         const uint32_t E = s_eoff[nbin_];
-        for (uint32_t e = tid; e < E; e += kThreads) {
+        for (uint32_t e = tid; e < E; e += NT) {
             int base = s_ebase[0], oy = s_eoy[0], ox = s_eox[0];
             for (int j = 1; j < nbin_; ++j) {   // (uniform trip count, LDS broadcast reads)
                 const bool ge = e >= s_eoff[j];
@@ -755,7 +755,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     unsigned long long w[NC][4];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int idx = tid + c * kThreads;
+        const int idx = tid + c * NT;
         const int pr = idx / PC, pc = idx - pr * PC;
         const int gr = r0 - H + pr, gc = c0 - H + pc;
         const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
@@ -781,14 +781,14 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     // are outside that bound (they come from any bin): their planes are read unpacked below, only when there are any.
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int idx = tid + c * kThreads;
+        const int idx = tid + c * NT;
         if (idx < PR * PC) s_acc[idx] = (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
     }
     }   // dense slabs
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
-    for (int idx = tid; idx < TH * TW; idx += kThreads) {
+    for (int idx = tid; idx < TH * TW; idx += NT) {
         const int tr = idx / TW, tc = idx - tr * TW;
         const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
         float tv = 0.f;
@@ -828,12 +828,12 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 4);
     const bool do_zero = a.zero_plane && sload(a.ovf_prev) != 0;   // the other plane buffer is dirty: clear it for the next iteration
-    stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
+    stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero);
 }
 
-template <int HS, bool COMPACT>
-__global__ __launch_bounds__(kThreads) void k_stencil_binned(StencilArgs a) {
-    stencil_binned_body<HS, COMPACT>(a);
+template <int HS, bool COMPACT, int NT>
+__global__ __launch_bounds__(NT) void k_stencil_binned(StencilArgs a) {
+    stencil_binned_body<HS, COMPACT, NT>(a);
 }
 
 // Plain launch, or (profiling armed) an extended launch whose events carry the kernel's own timestamps.
@@ -849,9 +849,12 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 }
 
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
-#define BF_K3(HS_)                                                                              \
-    if (a.compact) launch_timed(k_stencil_binned<HS_, true>, grid, dim3(kThreads), 0, s, a);    \
-    else launch_timed(k_stencil_binned<HS_, false>, grid, dim3(kThreads), 0, s, a)
+#define BF_K3(HS_)                                                                                                  \
+    if (a.threads >= 512) {                                                                                         \
+        if (a.compact) launch_timed(k_stencil_binned<HS_, true, 512>, grid, dim3(512), 0, s, a);                    \
+        else launch_timed(k_stencil_binned<HS_, false, 512>, grid, dim3(512), 0, s, a);                             \
+    } else if (a.compact) launch_timed(k_stencil_binned<HS_, true, kThreads>, grid, dim3(kThreads), 0, s, a);       \
+    else launch_timed(k_stencil_binned<HS_, false, kThreads>, grid, dim3(kThreads), 0, s, a)
     switch (a.scale / 2) {
         case 0: BF_K3(0); break;
         case 1: BF_K3(1); break;

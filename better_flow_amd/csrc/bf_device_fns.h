@@ -647,7 +647,8 @@ __device__ __forceinline__ unsigned long long acc_reduce_wave(const unsigned lon
 // the gated 3x3 Scharr (accel_lib.h:513-615), the centre-of-mass and moment sums
 // (object_model.cpp:4-39,103-126), optional gradient output, clearing of the other plane
 // buffer, and the wave64-shuffle + LDS reduction into one Partial per work-group.
-template <int TR, int TC>
+// NT: threads of the work-group (256, or 512 on small images: half the pixels per thread, a shorter dependent chain).
+template <int TR, int TC, int NT>
 __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* s_time, Sums* s_red,
                                              int r0, int c0, bool do_zero) {
     constexpr int TW = TC + 2;
@@ -657,8 +658,8 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
     sums_zero(sm);
     const int hR = R / 2, hC = C / 2;
 #pragma unroll
-    for (int k = 0; k < (TR * TC) / kThreads; ++k) {
-        const int pidx = tid + k * kThreads;
+    for (int k = 0; k < (TR * TC) / NT; ++k) {
+        const int pidx = tid + k * NT;
         const int lr = pidx / TC, lc = pidx - lr * TC;
         const int gr = r0 + lr, gc = c0 + lc;
         if (gr < R && gc < C) {
@@ -683,8 +684,8 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         static_assert(sizeof(DevState) % 8 == 0 && sizeof(DevState) / 8 <= 64, "one u64 per lane of one wave");
         if (a.ticket && tid < (int)(sizeof(DevState) / 8))
             reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st_rw)[tid];
-        __shared__ unsigned long long s_rpart[kSumFields * (kThreads / 64)];
-        const Sums blk = block_reduce_sums<kThreads, (TR * TC <= 1024 && TR <= 64 && TC <= 64)>(sm, s_rpart, tid, r0 - hR, c0 - hC);
+        __shared__ unsigned long long s_rpart[kSumFields * (NT / 64)];
+        const Sums blk = block_reduce_sums<NT, (TR * TC <= 1024 && TR <= 64 && TC <= 64)>(sm, s_rpart, tid, r0 - hR, c0 - hC);
         tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
@@ -697,7 +698,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             // and the overflow counter of the next iteration are cleared here for their next use.
             if (me == 0) {
                 if (a.acc_zero)
-                    for (int i = tid; i < kAccGroups * 16; i += kThreads) (&a.acc_zero[0].f[0])[i] = 0ull;
+                    for (int i = tid; i < kAccGroups * 16; i += NT) (&a.acc_zero[0].f[0])[i] = 0ull;
                 if (a.ovf_next && tid == 0) *a.ovf_next = 0u;
             }
             return;

@@ -67,6 +67,7 @@ struct StencilArgs {
     const uint16_t* cidx;              // compact lists (hot.fmt == 1): see BinScatterArgs
     const uint32_t* chdr;
     int compact;
+    int threads;                       // work-group size of the stencil kernels (256 or 512; the loop's choice per slice)
     BinGrid g;
     int cur;
 };

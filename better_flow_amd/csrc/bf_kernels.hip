@@ -180,15 +180,15 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const int32_t* __restrict_
 
 // SRC 0: packed u64 plane; 1: split u64 sum + u32 count planes; 2: f32 time image.
 // (The tile-binned source has its own kernel, k_stencil_binned in bf_binned.hip.)
-template <int SRC>
-__global__ __launch_bounds__(kThreads) void k_stencil(StencilArgs a) {
+template <int SRC, int NT>
+__global__ __launch_bounds__(NT) void k_stencil(StencilArgs a) {
     if (a.check_done && a.st->hot.done) return;
     constexpr int TR = kTileR, TC = kTileC;
     constexpr int MAXH = kMaxHalfScale + 1;
     __shared__ unsigned long long s_pt[(TR + 2 * MAXH) * (TC + 2 * MAXH)];
     __shared__ uint32_t s_pc[(SRC == 1) ? (TR + 2 * MAXH) * (TC + 2 * MAXH) : 1];
     __shared__ float s_time[(TR + 2) * (TC + 2)];
-    __shared__ Sums s_red[kThreads / 64];
+    __shared__ Sums s_red[NT / 64];
 
     const int R = a.R, C = a.C;
     const int tid = threadIdx.x;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil(StencilArgs a) {
     constexpr int TW = TC + 2, TH = TR + 2;
 
     if (SRC == 2) {
-        for (int idx = tid; idx < TH * TW; idx += kThreads) {
+        for (int idx = tid; idx < TH * TW; idx += NT) {
             const int tr = idx / TW, tc = idx - tr * TW;
             const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
             float v = 0.f;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil(StencilArgs a) {
         const int hs = a.scale / 2;
         const int H = hs + 1;
         const int PC = TC + 2 * H, PR = TR + 2 * H;
-        for (int idx = tid; idx < PR * PC; idx += kThreads) {
+        for (int idx = tid; idx < PR * PC; idx += NT) {
             const int pr = idx / PC, pc = idx - pr * PC;
             const int gr = r0 - H + pr, gc = c0 - H + pc;
             unsigned long long v = 0;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil(StencilArgs a) {
         __syncthreads();
         const int tbits = a.tbits;
         const unsigned long long tmask = (tbits >= 64) ? ~0ull : ((1ull << tbits) - 1ull);
-        for (int idx = tid; idx < TH * TW; idx += kThreads) {
+        for (int idx = tid; idx < TH * TW; idx += NT) {
             const int tr = idx / TW, tc = idx - tr * TW;
             const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
             float tv = 0.f;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void k_stencil(StencilArgs a) {
     __syncthreads();
 
     const bool do_zero = a.zero_plane != nullptr;   // the other plane buffer is cleared here
-    stencil_tail<TR, TC>(a, s_time, s_red, r0, c0, do_zero);
+    stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero);
 }
 
 __global__ __launch_bounds__(kThreads) void k_compute_uv(const double2* __restrict__ nxny,
@@ -367,10 +367,16 @@ void launch_stencil(const StencilArgs& a, int src, hipStream_t s) {
     int gx, gy;
     stencil_grid(a.R, a.C, &gx, &gy);
     dim3 grid(gx, gy);
-    if (src == 0) hipLaunchKernelGGL(k_stencil<0>, grid, dim3(kThreads), 0, s, a);
-    else if (src == 1) hipLaunchKernelGGL(k_stencil<1>, grid, dim3(kThreads), 0, s, a);
-    else if (src == 3) launch_stencil_binned(a, grid, s);
-    else hipLaunchKernelGGL(k_stencil<2>, grid, dim3(kThreads), 0, s, a);
+    if (src == 3) { launch_stencil_binned(a, grid, s); return; }
+    if (a.threads >= 512) {
+        if (src == 0) hipLaunchKernelGGL((k_stencil<0, 512>), grid, dim3(512), 0, s, a);
+        else if (src == 1) hipLaunchKernelGGL((k_stencil<1, 512>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_stencil<2, 512>), grid, dim3(512), 0, s, a);
+        return;
+    }
+    if (src == 0) hipLaunchKernelGGL((k_stencil<0, kThreads>), grid, dim3(kThreads), 0, s, a);
+    else if (src == 1) hipLaunchKernelGGL((k_stencil<1, kThreads>), grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((k_stencil<2, kThreads>), grid, dim3(kThreads), 0, s, a);
 }
 
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s) {

@@ -42,9 +42,12 @@ def apply(a, op, sl):
     """Executes one op on ctx a; returns an observable (bytes-comparable tuple) or None."""
     k = op[0]
     if k == "opt":
-        a.set_option(op[1], op[2]); return None
+        a.set_option(op[1], op[2])
+        if a is long_ctx:
+            long_opts[op[1]] = op[2]
+        return None
     if k == "upload":
-        how = op[2] if a is long_ctx else "plain"     # the long-lived context also exercises the other hand-overs
+        how = op[2] if (a is long_ctx or mimic_long) else "plain"     # the long-lived context also exercises the other hand-overs
         n = len(sl["t"])
         if how == "plain" or op[1] is not None or n == 0:
             a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"], op[1])
@@ -95,6 +98,9 @@ def apply(a, op, sl):
 
 
 long_ctx = new_ctx()
+mimic_long = False
+history = []        # (options in force at the upload, slice, ops) per slice of the long-lived context: bisection of a mismatch
+long_opts = {}      # options in force on the long-lived context (a replay only sees those set since the upload)
 script, sl, bad, checks = [], None, 0, 0
 state = dict(cloud=False, lwin=None, ran=False, scale=3)
 last_model = None
@@ -104,6 +110,7 @@ for step in range(steps):
         noise = (rng.random(len(sl["t"])) < 0.1).astype(np.uint8) if rng.random() < 0.2 else None
         script = [("upload", noise, str(rng.choice(["plain", "async", "ring"])), int(rng.integers(0, 1 << 30)))]
         apply(long_ctx, script[0], sl)
+        history.append((dict(long_opts), sl, script))
         state = dict(cloud=False, lwin=None, ran=False, scale=3, noise=noise is not None)
         continue
     choices = ["cloud", "opt"]
@@ -181,6 +188,76 @@ for step in range(steps):
                 w2 = ("error", e.code)
             f2.close()
             reps.append(w2)
+        # ... and with the long-lived context's options in force from the start?
+        f3 = new_ctx()
+        try:
+            for k_, v_ in long_opts.items():
+                f3.set_option(k_, v_)
+            for o_ in script:
+                w3 = apply(f3, o_, sl)
+        except accel.BfError as e:
+            w3 = ("error", e.code)
+        f3.close()
+        print("    long-lived options", long_opts, "| fresh context with them equal to long-lived:", w3 == got)
+        # how much of the long-lived context's past does it take?  replay its last k slices on a fresh context, then
+        # drop slices and operations one by one while the replay still gives the long-lived context's result
+        mimic_long = True
+
+        def replay(opts0, hist):
+            f4 = new_ctx()
+            w4 = None
+            try:
+                for k_, v_ in opts0.items():
+                    f4.set_option(k_, v_)
+                for (sl_h, ops_h) in hist:
+                    for o_ in ops_h:
+                        try:
+                            w4 = apply(f4, o_, sl_h)
+                        except accel.BfError as e:
+                            w4 = ("error", e.code)
+                        except (AttributeError, TypeError, ValueError):
+                            return None      # the trial removed something a later operation needs: not a reproduction
+            finally:
+                f4.close()
+            return w4
+
+        for k_back in (1, 2, 3, 5, 8, 13, 21, 34, len(history)):
+            k_back = min(k_back, len(history))
+            opts0 = history[-k_back][0]
+            hist = [(h_[1], list(h_[2])) for h_ in history[-k_back:]]
+            if replay(opts0, hist) == got:
+                print("    replay of the last %d slice(s) reproduces the long-lived result; reducing" % k_back)
+                changed = True
+                while changed:
+                    changed = False
+                    for i in range(len(hist) - 1):          # whole slices
+                        trial = hist[:i] + hist[i + 1:]
+                        if replay(opts0, trial) == got:
+                            hist, changed = trial, True
+                            break
+                    if changed:
+                        continue
+                    for i in range(len(hist)):              # single operations (never an upload, never the last one)
+                        for q in range(1, len(hist[i][1]) - (1 if i == len(hist) - 1 else 0)):
+                            trial = [(h_[0], list(h_[1])) for h_ in hist]
+                            del trial[i][1][q]
+                            if replay(opts0, trial) == got:
+                                hist, changed = trial, True
+                                break
+                        if changed:
+                            break
+                    if changed:
+                        continue
+                    for k_ in list(opts0):                  # initial options
+                        trial_o = {a_: b_ for a_, b_ in opts0.items() if a_ != k_}
+                        if replay(trial_o, hist) == got:
+                            opts0, changed = trial_o, True
+                            break
+                print("    reduced: options at the start", opts0)
+                for (sl_h, ops_h) in hist:
+                    print("        slice %dx%d n=%d:" % (sl_h["H"], sl_h["W"], len(sl_h["t"])), [tuple(o_[:1]) + tuple(x for x in o_[1:4] if not isinstance(x, np.ndarray)) for o_ in ops_h])
+                break
+        mimic_long = False
         print("    fresh replays equal to each other:", reps[0] == reps[1], "| equal to first fresh:", reps[0] == want, "| equal to long-lived:", reps[0] == got)
         if bad >= 3:
             break

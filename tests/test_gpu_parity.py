@@ -889,6 +889,45 @@ def test_context_reuse_fuzz():
     assert r.returncode == 0 and "0 mismatches" in out.splitlines()[-1], out[-3000:]
 
 
+def test_moment_accumulators_are_clean_for_the_next_user(accel_mod):
+    """The head-update loop consumes, but does not clear, the moment sums of its last iteration.  Whoever uses the
+    accumulators next through the stencil kernel's last-work-group form -- a sparse slice on the global-atomic path,
+    bf_fast_model -- must not add onto them (found by scripts/fuzz_reuse.py seed 22: a tile-binned run that ends after an
+    odd number of iterations, then a 179-event slice on the same context)."""
+    A = synth.make_slice(60000, 180, 240, 0.05, seed=17)
+    B = synth.make_slice(180, 104, 204, 0.03, seed=42)
+    img = np.random.default_rng(3).uniform(0, 0.03, (90, 130)).astype(np.float32)
+
+    def on(acc, sl, scale, max_iter, binned):
+        acc.set_option("binned", binned)
+        acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        acc.set_cloud(scale, sl["height"], sl["width"])
+        o = acc.default_opts()
+        o.res_x, o.res_y, o.max_iter, o.min_events = sl["height"], sl["width"], max_iter, 50
+        rc, m, info = acc.run(o)
+        return rc, info.iterations, m.as_dict()
+
+    def ctx():
+        return accel_mod.Accel(max_events=65536, max_rows=7 * 180 + 7, max_cols=7 * 240 + 7)
+
+    fresh = ctx()
+    want_run = on(fresh, B, 7, 10, 0)
+    want_fm = fresh.fast_model(img).as_dict()
+    fresh.close()
+    parities = set()
+    for iters in (3, 4):          # the last iteration's sums sit in either parity
+        acc = ctx()
+        got_a = on(acc, A, 3, iters, 2)
+        parities.add(got_a[1] & 1)
+        assert on(acc, B, 7, 10, 0) == want_run, iters
+        acc.close()
+        acc = ctx()
+        on(acc, A, 3, iters, 2)
+        assert acc.fast_model(img).as_dict() == want_fm, iters
+        acc.close()
+    assert parities == {0, 1}
+
+
 def test_readback_order_and_buffer_reuse(oracle_lib, accel_mod):
     """Per-event outputs after a tile-binned run are produced in tile-sorted order and un-permuted on read-back; the
     position read-back borrows the flow buffer.  Every read-back order must give the same, correctly ordered, data."""

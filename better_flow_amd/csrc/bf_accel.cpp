@@ -992,15 +992,15 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         h.n_events = (uint32_t)c->n;
         h.hot.bin_tbits = tbits > 62 ? 62 : tbits; h.hot.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
         h.hot.flip = 0;
-        // Compact lists or dense slabs.  Measured per iteration, one context (dense / compact): 1280x720 89 / 82 us,
-        // 640x480 44.7 / 52.6, 346x260 21.7 / 36.7 -- the lists win where there are fewer than ~1 event per 4 pixels,
-        // so "auto" goes by that, once per slice (the kernels are compiled per format: one that switched
-        // per iteration carried both bodies and ran 0.8 us slower at 346x260).
+        // Event lists or dense slabs.  A dense slice (one event per pixel or more) merges its events in the bin's LDS tile
+        // and writes the tile; a sparse one writes one list entry per event (no LDS tile: the tile of a 1280x720 bin would
+        // fill the CU's LDS and leave one work-group per CU).  "auto" goes by the density, once per slice: the kernels are
+        // compiled per format.
         {
             const double P = (double)w.scale_img_x * (double)w.scale_img_y;
-            // (the index list needs two more bytes of LDS per tile pixel and 16-bit tile-local indices)
-            const size_t LLg = (size_t)c->grid.LR * (size_t)c->grid.L;
-            const int mode = (c->use_binned && LLg * 10 + 16 <= (size_t)kBinTileLdsMax && LLg <= 65536) ? c->opt_bin_compact : 0;
+            // (16-bit tile-local pixel indices in the lists)
+            const size_t LLg = (size_t)g.LR * (size_t)g.L;
+            const int mode = (c->use_binned && LLg <= 65536) ? c->opt_bin_compact : 0;
             c->use_compact = mode == 2 || (mode == 1 && 4.0 * (double)c->n < P);
             h.hot.fmt = c->use_compact ? 1 : 0;
         }
@@ -1354,7 +1354,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads : (ev_per_bin >= 1536.0 ? 1024 : 512);
     if (binned && c->opt_bin_ev > 0) ev_per_thread = c->opt_bin_ev;
     else if (binned) {
-        const double per_bin = 1.5 * ev_per_bin / (double)bin_threads;
+        // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a
+        // CU, and a bin above the pass size takes a second pass; measured at 1280x720: 512 x 2 69.8 us, 512 x 4 73.5)
+        const double per_bin = (c->use_compact ? 1.0 : 1.5) * ev_per_bin / (double)bin_threads;
         ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2 ? 2 : (per_bin <= 4 ? 4 : 8));
     }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot

@@ -298,14 +298,10 @@ constexpr int kMaxTileRows = 192;   // LR = TSR + 2 D <= 128 + 64
 struct ScatterGeo {
     int X0, Y0, L, LR;
 };
-// COMPACT: the accumulate returns the previous value; the lane that finds 0 there touched the pixel first and appends
-// its index to the tile's list (one LDS counter add per wave: ballot + rank), from which the flush writes only the
-// non-zero pixels.  The list has a slot for every pixel of the tile, so it cannot overflow.
-template <bool WARP, bool COMPACT>
-__device__ __forceinline__ void scatter_event(const ScatterHot& hs, const ScatterGeo& sg, unsigned long long* s_tile,
-                                              uint16_t* s_list, uint32_t* s_cnt,
-                                              const BinScatterArgs& a, float2* p, uint32_t i, uint32_t v, int32_t ti,
-                                              double pr_x, double pr_y, uint32_t& n_ovf) {
+// The warp of one event and its splat centre (accel_lib.h:154-158); false: the event falls outside the window.
+template <bool WARP>
+__device__ __forceinline__ bool event_target(const ScatterHot& hs, float2* p, uint32_t i, uint32_t v, int32_t ti,
+                                             double pr_x, double pr_y, int& X, int& Y) {
     const uint32_t fx = v & 0xffffu, fy = v >> 16;
     if (WARP) {
         float2 q;
@@ -319,33 +315,98 @@ __device__ __forceinline__ void scatter_event(const ScatterHot& hs, const Scatte
         pr_y = pr_from_p(fy, q.y);
     }
     const int s = hs.scale, hsc = hs.scale / 2;
-    const int X = trunc_scatter(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
-    const int Y = trunc_scatter(pr_y * (double)s + (double)hs.y_sh);
-    if (!((X >= hs.wsx + hsc) || (X < hsc) || (Y >= hs.wsy + hsc) || (Y < hsc))) {
-        const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
-        const int lx = X - sg.X0, ly = Y - sg.Y0;
-        if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
-            const int idx = __mul24(lx, sg.L) + ly;
-            if (COMPACT) {
-                const unsigned long long old = atomicAdd(&s_tile[idx], (1ull << hs.bin_tbits) + dt);
-                if (old == 0ull) {
-                    const unsigned long long m = __ballot(1);   // the lanes that are first at their pixel
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    uint32_t base = 0;
-                    if (rank == 0) base = atomicAdd(s_cnt, (uint32_t)__popcll(m));
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // (the first active lane is the one of rank 0)
-                    s_list[base + rank] = (uint16_t)idx;
-                    atomicAdd(&s_cnt[1 + lx], 1u);   // entries per tile row (the flush sorts the list by row)
-                }
-            } else {
-                atomicAdd(&s_tile[idx], (1ull << hs.bin_tbits) + dt);
-            }
-        } else {   // drifted out of this bin's tile: exact, slow path
-            const size_t kk = (size_t)X * (size_t)hs.C + (size_t)Y;
-            atomicAdd(&a.ovf_plane[kk], dt);
-            atomicAdd(&a.ovf_cplane[kk], 1u);
-            ++n_ovf;
+    X = trunc_scatter(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
+    Y = trunc_scatter(pr_y * (double)s + (double)hs.y_sh);
+    return !((X >= hs.wsx + hsc) || (X < hsc) || (Y >= hs.wsy + hsc) || (Y < hsc));
+}
+// the exact slow path: straight into the overflow planes
+__device__ __forceinline__ void overflow_add(const ScatterHot& hs, const BinScatterArgs& a, int X, int Y, unsigned long long dt) {
+    const size_t kk = (size_t)X * (size_t)hs.C + (size_t)Y;
+    atomicAdd(&a.ovf_plane[kk], dt);
+    atomicAdd(&a.ovf_cplane[kk], 1u);
+}
+
+// Dense slabs: accumulate in the bin's LDS tile.
+template <bool WARP>
+__device__ __forceinline__ void scatter_event(const ScatterHot& hs, const ScatterGeo& sg, unsigned long long* s_tile,
+                                              const BinScatterArgs& a, float2* p, uint32_t i, uint32_t v, int32_t ti,
+                                              double pr_x, double pr_y, uint32_t& n_ovf) {
+    int X, Y;
+    if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return;
+    const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
+    const int lx = X - sg.X0, ly = Y - sg.Y0;
+    if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
+        atomicAdd(&s_tile[__mul24(lx, sg.L) + ly], (1ull << hs.bin_tbits) + dt);
+    } else {   // drifted out of this bin's tile: exact, slow path
+        overflow_add(hs, a, X, Y, dt);
+        ++n_ovf;
+    }
+}
+
+// ---- event lists (the compact form) ----------------------------------------------------------------------------------
+// Sparse slices (fewer than one event per four pixels: a 1280x720 sensor at scale 3 has 8.3M pixels for 1M events): the
+// bin's LDS tile would be ~100 KB -- one work-group per CU, four rounds of a latency chain per launch -- to merge events
+// that almost never meet at a pixel.  Instead every event becomes one ENTRY (tile-local pixel index, packed accumulator
+// of one event) of the bin's list, SORTED BY TILE ROW (counting sort: per-row counts in LDS, an exclusive scan, cursors),
+// with the first entry of every row in `crow` (LR + 1 words per bin): the stencil kernel reads exactly the rows it needs
+// and splats entries with LDS atomics, so duplicates simply add.  No LDS tile: occupancy is set by registers, all bins of
+// a 1280x720 slice are resident at once.  The order inside a row is whatever the atomics make it (integers).  A list
+// holds LL entries (the slab's size); a bin with more events sends the surplus down the overflow path.
+constexpr uint32_t kNoEntry = 0xffffffffu;
+// pixel of one event -> entry code (row << 16 | index inside the tile fits: LL <= 65536), or kNoEntry (outside the window,
+// or outside the bin's tile: overflow path, taken here unless `count_only`)
+template <bool WARP>
+__device__ __forceinline__ uint32_t list_event(const ScatterHot& hs, const ScatterGeo& sg, const BinScatterArgs& a, float2* p,
+                                               uint32_t i, uint32_t v, int32_t ti, double pr_x, double pr_y, bool take_overflow,
+                                               int& row, uint32_t& n_ovf) {
+    int X, Y;
+    row = 0;
+    if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return kNoEntry;
+    const int lx = X - sg.X0, ly = Y - sg.Y0;
+    if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
+        row = lx;
+        return (uint32_t)(__mul24(lx, sg.L) + ly);
+    }
+    if (take_overflow) {
+        overflow_add(hs, a, X, Y, (unsigned long long)((long long)ti - hs.tmin));
+        ++n_ovf;
+    }
+    return kNoEntry;
+}
+// exclusive scan of the row counts s_row[1 .. LR] (one wave, 64 rows per step): cursors in LDS, row starts in `crow`
+__device__ __forceinline__ void list_row_scan(uint32_t* s_row, int LR, uint32_t* crow, int lane) {
+    uint32_t carry = 0;
+    for (int r0 = 0; r0 < LR; r0 += 64) {
+        const int r = r0 + lane;
+        const uint32_t v = r < LR ? s_row[1 + r] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
         }
+        if (r < LR) {
+            s_row[1 + r] = carry + incl - v;
+            crow[r] = carry + incl - v;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) crow[LR] = carry;
+}
+// one entry to its slot (the row's cursor); a full list -> overflow path
+__device__ __forceinline__ void list_put(const ScatterHot& hs, const ScatterGeo& sg, const BinScatterArgs& a, uint32_t* s_row,
+                                         uint32_t code, int row, int32_t ti, uint32_t LL, unsigned long long* vals,
+                                         uint16_t* cidx, uint32_t& n_ovf) {
+    const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
+    const uint32_t slot = atomicAdd(&s_row[1 + row], 1u);
+    if (slot < LL) {
+        // (plain stores: the slots of a wave are scattered over the list, a write-through store would send each 8-byte
+        // entry to memory on its own -- measured 17.7 against 16.5 us per launch at 1280x720)
+        vals[slot] = (1ull << hs.bin_tbits) + dt;
+        cidx[slot] = (uint16_t)code;
+    } else {
+        overflow_add(hs, a, sg.X0 + row, sg.Y0 + (int)code - __mul24(row, sg.L), dt);
+        ++n_ovf;
     }
 }
 
@@ -361,45 +422,6 @@ __device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, uns
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slab + 2 * i), "v"(v) : "memory");
     }
 }
-// Compact form: (tile-local index, packed accumulator) of the touched pixels only, and their number.  The traffic is
-// proportional to the EVENTS of the bin, not to its area (a 1280x720 slice at scale 3: 8.1M pixels, 62 500 scene points).
-// The list goes out SORTED BY TILE ROW (counting sort on the per-row counts the scatter kept; the order inside a row is
-// whatever the LDS atomics make it -- the consumers add integers), with the first entry of every row in `crow`
-// (LR + 1 words per bin): a stencil tile then reads exactly the rows it needs.  s_cnt: [0] entries, [1 .. LR] per-row
-// counts, turned into running cursors here.  Called after a work-group barrier.
-template <int THREADS>
-__device__ __forceinline__ void flush_list(const unsigned long long* s_tile, const uint16_t* s_list, uint32_t* s_cnt,
-                                           int LR, uint32_t mul_l, unsigned long long* vals, uint16_t* cidx, uint32_t* crow,
-                                           int tid) {
-    const uint32_t n = s_cnt[0];
-    if (tid < 64) {   // exclusive scan of the row counts, 64 rows per step
-        uint32_t carry = 0;
-        for (int r0 = 0; r0 < LR; r0 += 64) {
-            const int r = r0 + tid;
-            const uint32_t v = r < LR ? s_cnt[1 + r] : 0u;
-            uint32_t incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += u;
-            }
-            if (r < LR) {
-                s_cnt[1 + r] = carry + incl - v;
-                crow[r] = carry + incl - v;
-            }
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        if (tid == 0) crow[LR] = n;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += THREADS) {
-        const uint32_t idx = s_list[i];
-        const uint32_t slot = atomicAdd(&s_cnt[1 + __umulhi(idx, mul_l)], 1u);
-        __hip_atomic_store(&vals[slot], s_tile[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cidx[slot] = (uint16_t)idx;
-    }
-}
-
 // K1 (binned): [pending update] + warp + LDS scatter + slab flush, one work-group per bin.
 //
 // The model / loop update of the tile-binned loop runs HERE.  The stencil kernel of iteration j - 1 only adds its
@@ -415,10 +437,11 @@ __device__ __forceinline__ void flush_list(const unsigned long long* s_tile, con
 // model-independent third of the per-event arithmetic); the first wave catches up after the barrier.
 template <bool WARP, int THREADS, int U, bool COMPACT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
-    extern __shared__ unsigned long long s_tile[];
+    extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
     __shared__ DevState s_state;
-    __shared__ uint32_t s_ncompact[COMPACT ? 1 + kMaxTileRows : 1];   // compact lists: entries, entries per tile row
-    if (COMPACT && threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
+    __shared__ uint32_t s_row[COMPACT ? 1 + kMaxTileRows : 1];   // event lists: entries per tile row, then the rows' cursors
+    if (COMPACT)
+        for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     };
     load_pass();
     asm volatile("" ::: "memory");   // (keep the requests above ahead of everything below)
-    {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
+    if (!COMPACT) {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
         ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
         for (int i = tid; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
     }
@@ -518,14 +541,64 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     }
     if (pending && tid < 64) previous_positions();
     const ScatterGeo sg = {X0, Y0, L, LR};
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);   // (dynamic LDS: the tile, then one index slot per pixel)
     uint32_t n_ovf = 0;
+    if constexpr (COMPACT) {
+        // Event lists.  Pass A: warp, store the products, count the entries per tile row (a bin of the usual size is one
+        // pass and keeps its entries in registers).  Scan.  Pass B: every entry to its row's cursor -- from the registers,
+        // or, for a bin of several passes, recomputed from the products just stored (the cheap half of the arithmetic).
+        const bool single = end - beg <= (uint32_t)(THREADS * U);
+        uint32_t code[U];
+        int row[U];
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint32_t i = base + k * THREADS + tid;
+                code[k] = kNoEntry;
+                if (i >= end) continue;
+                code[k] = list_event<WARP>(hs, sg, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], true, row[k], n_ovf);
+                if (code[k] != kNoEntry) atomicAdd(&s_row[1 + row[k]], 1u);
+            }
+            base += THREADS * U;
+            if (base >= end) break;
+            load_pass();
+            previous_positions();
+        }
+        tl_stamp(a.tl, a.j, 2);
+        __syncthreads();
+        tl_stamp(a.tl, a.j, 3);
+        store_state();
+        if (tid < 64) list_row_scan(s_row, LR, a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+        __syncthreads();
+        unsigned long long* vals = a.slabs + (size_t)b * (size_t)LL;
+        uint16_t* cidx = a.cidx + (size_t)b * (size_t)LL;
+        if (single) {
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (code[k] != kNoEntry) list_put(hs, sg, a, s_row, code[k], row[k], vt[k], (uint32_t)LL, vals, cidx, n_ovf);
+        } else {
+            for (base = beg; base < end; base += THREADS * U) {
+                load_pass();   // (p: the products this thread stored in pass A)
+                previous_positions();
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t i = base + k * THREADS + tid;
+                    if (i >= end) continue;
+                    int r;
+                    const uint32_t cd = list_event<false>(hs, sg, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], false, r, n_ovf);
+                    if (cd != kNoEntry) list_put(hs, sg, a, s_row, cd, r, vt[k], (uint32_t)LL, vals, cidx, n_ovf);
+                }
+            }
+        }
+        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        tl_stamp(a.tl, a.j, 4);
+        return;
+    }
     for (;;) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            scatter_event<WARP, COMPACT>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
         }
         base += THREADS * U;
         if (base >= end) break;
@@ -537,9 +610,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     __syncthreads();
     tl_stamp(a.tl, a.j, 3);
     store_state();
-    if (COMPACT) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
-                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
-    else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     tl_stamp(a.tl, a.j, 4);
 }
 
@@ -549,9 +620,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
 // still carries the state to the other buffer and to the host snapshot.
 template <bool WARP, int THREADS, int U, bool COMPACT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
-    extern __shared__ unsigned long long s_tile[];
-    __shared__ uint32_t s_ncompact[COMPACT ? 1 + kMaxTileRows : 1];   // compact lists: entries, entries per tile row
-    if (COMPACT && threadIdx.x <= kMaxTileRows) s_ncompact[threadIdx.x] = 0;
+    extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
+    __shared__ uint32_t s_row[COMPACT ? 1 + kMaxTileRows : 1];   // event lists: entries per tile row, then the rows' cursors
+    if (COMPACT)
+        for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -560,7 +632,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
     unsigned long long state_word = 0;
     if (b == 0 && tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
     const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
-    {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
+    if (!COMPACT) {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
         ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
         for (int i = tid; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
     }
@@ -584,13 +656,12 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
     const int32_t* __restrict__ t = ev.t;
     float2* __restrict__ p = ev.p;
     const ScatterGeo sg = {X0, Y0, L, LR};
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
     uint32_t n_ovf = 0;
     __syncthreads();
-    for (uint32_t base = beg; base < end; base += THREADS * U) {
-        uint32_t vxy[U];
-        int32_t vt[U];
-        float2 vp[U];
+    uint32_t vxy[U];
+    int32_t vt[U];
+    float2 vp[U];
+    auto load_pass = [&](uint32_t base) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             uint32_t i = base + k * THREADS + tid;
@@ -599,19 +670,65 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
             vt[k] = t[i];
             vp[k] = p[i];
         }
+    };
+    if constexpr (COMPACT) {   // event lists: see k_bin_warp_scatter
+        const bool single = end - beg <= (uint32_t)(THREADS * U);
+        uint32_t code[U];
+        int row[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) code[k] = kNoEntry;   // (an empty bin does not enter the loop)
+        for (uint32_t base = beg; base < end; base += THREADS * U) {
+            load_pass(base);
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint32_t i = base + k * THREADS + tid;
+                code[k] = kNoEntry;
+                if (i >= end) continue;
+                code[k] = list_event<WARP>(hs, sg, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                           pr_from_p(vxy[k] >> 16, vp[k].y), true, row[k], n_ovf);
+                if (code[k] != kNoEntry) atomicAdd(&s_row[1 + row[k]], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) list_row_scan(s_row, LR, a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+        __syncthreads();
+        unsigned long long* vals = a.slabs + (size_t)b * (size_t)LL;
+        uint16_t* cidx = a.cidx + (size_t)b * (size_t)LL;
+        if (single) {
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (code[k] != kNoEntry) list_put(hs, sg, a, s_row, code[k], row[k], vt[k], (uint32_t)LL, vals, cidx, n_ovf);
+        } else {
+            for (uint32_t base = beg; base < end; base += THREADS * U) {
+                load_pass(base);   // (p: the products this thread stored in the first pass)
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t i = base + k * THREADS + tid;
+                    if (i >= end) continue;
+                    int r;
+                    const uint32_t cd = list_event<false>(hs, sg, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                                          pr_from_p(vxy[k] >> 16, vp[k].y), false, r, n_ovf);
+                    if (cd != kNoEntry) list_put(hs, sg, a, s_row, cd, r, vt[k], (uint32_t)LL, vals, cidx, n_ovf);
+                }
+            }
+        }
+        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        hand_state_on();
+        return;
+    }
+    for (uint32_t base = beg; base < end; base += THREADS * U) {
+        load_pass(base);
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            scatter_event<WARP, COMPACT>(hs, sg, s_tile, s_list, s_ncompact, a, p, i, vxy[k], vt[k],
-                                         pr_from_p(vxy[k] & 0xffffu, vp[k].x), pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
         }
     }
     if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     __syncthreads();
-    if (COMPACT) flush_list<THREADS>(s_tile, s_list, s_ncompact, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
-                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
-    else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     hand_state_on();
 }
 
@@ -697,8 +814,9 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
                 const int top = (br_lo + r) * g.TSR - g.D;   // image row of tile row 0
                 const int lo = min(max(r0 - 1 - HS - top, 0), g.LR), hi = min(max(r0 + TR + HS + 1 - top, 0), g.LR);
                 const uint32_t* crow = a.chdr + (size_t)bin * (size_t)(g.LR + 1);
-                first = crow[lo];
-                n = crow[hi] - first;
+                // (a list holds LL entries: the surplus of a fuller bin went down the overflow path)
+                first = min(crow[lo], (uint32_t)LLi);
+                n = min(crow[hi], (uint32_t)LLi) - first;
             }
             uint32_t incl = n;
 #pragma unroll
@@ -887,7 +1005,7 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 
 template <int THREADS, int U, bool COMPACT>
 static void launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    const size_t lds = (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (COMPACT ? sizeof(uint16_t) : 0)) + 16;   // tile (+ index list)
+    const size_t lds = COMPACT ? 0 : (size_t)a.g.LR * a.g.L * sizeof(unsigned long long) + 16;   // the bin's tile (event lists: none)
     static bool raised = false;   // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);

@@ -889,6 +889,31 @@ def test_context_reuse_fuzz():
     assert r.returncode == 0 and "0 mismatches" in out.splitlines()[-1], out[-3000:]
 
 
+def test_event_lists_full_bins_and_second_pass(accel_mod):
+    """The event-list form of the tile-binned scatter at its edges: a bin with more events than its list holds sends the
+    surplus down the exact overflow path; a bin with more events than one pass of the work-group covers recomputes its
+    entries from the stored products; empty bins write empty lists.  Every case must give the bits of the global-atomic
+    scatter."""
+    for (n, H, W, scale, opts, want_overflow) in (
+            (60000, 60, 80, 1, dict(bin_tile=32, bin_tile_rows=32, bin_threads=256, bin_ev=1), True),    # lists of 48 x 48 entries, ~10 000 events per bin
+            (60000, 120, 160, 3, dict(bin_tile=64, bin_tile_rows=64, bin_threads=256, bin_ev=1), False),  # ~40 passes per bin
+            (1500, 180, 240, 5, dict(), False)):                                                        # mostly empty bins
+        sl = synth.make_slice(n, H, W, 0.05, seed=23)
+        ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=0)
+        got = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=2, bin_compact=2, **opts)
+        tail = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=2, bin_compact=2, co_schedule=1, **opts)
+        for r in (got, tail):
+            assert r[0] == ref[0] and r[2].iterations == ref[2].iterations and r[2].rebins >= 1, (n, H, W)
+            assert r[1].as_dict() == ref[1].as_dict(), (n, H, W)
+            for a, b in zip(r[3], ref[3]):
+                assert a.model.as_dict() == b.model.as_dict(), (n, H, W)
+            for a, b in zip(r[4], ref[4]):
+                assert np.array_equal(a, b), (n, H, W)
+            assert np.array_equal(r[5], ref[5]) and np.array_equal(r[6], ref[6]), (n, H, W)
+        if want_overflow:
+            assert got[2].overflow_events > 0, "the lists must have overflowed"
+
+
 def test_moment_accumulators_are_clean_for_the_next_user(accel_mod):
     """The head-update loop consumes, but does not clear, the moment sums of its last iteration.  Whoever uses the
     accumulators next through the stencil kernel's last-work-group form -- a sparse slice on the global-atomic path,

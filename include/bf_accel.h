@@ -168,10 +168,11 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "bin_threads"  work-group size of the binned warp+scatter kernel: 0 (default: 1024 where a bin holds thousands
  *                  of events, 512 where it holds a few hundred), 256, 512, 1024.
  *   "bin_ev"       events a scatter thread keeps in flight: 0 (default: from the events per bin), 1, 2, 4, 8.
- *   "bin_compact"  what the scatter kernel hands to the stencil kernel: 0 dense tiles (one accumulator per tile pixel),
- *                  2 compact lists (index + accumulator of the touched pixels only, sorted by tile row: traffic and
- *                  work proportional to the events instead of the image area), 1 (default) lists when the slice has
- *                  fewer than one event per four pixels.  Bit-identical results either way. */
+ *   "bin_compact"  what the scatter kernel hands to the stencil kernel: 0 dense tiles (the bin's events merged in an LDS
+ *                  tile, one accumulator per tile pixel written), 2 event lists (one entry per event: tile-local pixel
+ *                  index + packed accumulator, sorted by tile row; no LDS tile, traffic and work proportional to the
+ *                  events instead of the image area), 1 (default) lists when the slice has fewer than one event per
+ *                  four pixels.  Bit-identical results either way. */
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 
 /* ---- slice set-up -------------------------------------------------------------- */
@@ -245,12 +246,26 @@ int bf_compute_uv(bf_ctx *ctx, double *u, double *v);
 int bf_set_model(bf_ctx *ctx, const bf_model *model);
 
 /* OptimizerRolling::run (optimizer_rolling.h:48-125) with iteration_step (:305-347)
- * executed entirely on the device: per iteration a warp+scatter kernel, a
- * stencil+moments kernel and a scalar update kernel, no host round trip except a
+ * executed entirely on the device: per iteration a warp+scatter kernel and a
+ * stencil+moments kernel (the scalar model / loop update rides in one of them), no host round trip except a
  * poll of the `done` word every opts->poll_interval iterations.  The starting model is
  * the zero ObjectModel of a fresh optimizer (after bf_set_cloud) or what bf_set_model
  * was given; model_out receives get_model() (:285-287).  opts == NULL: defaults.
- * Returns info->rc. */
+ * Returns info->rc.
+ *
+ * Tolerance contract.  The fused loop is NOT bit-identical to the reference's CPU path, and cannot be: (i) the time
+ * image is the exact integer-nanosecond sum of a pixel's events rounded to f32 once, where the reference adds f32 seconds
+ * event by event in container order (accel_lib.h:162) -- its own result moves by ~1e-7 relative with the event order;
+ * (ii) the moments are centred sums reduced in a fixed tree, where object_model.cpp:22-30 adds per pixel in row-major
+ * order; (iii) sin / cos of the rotation angle are evaluated on the device (Taylor polynomials for |x| <= 0.25, <= 1 ulp
+ * from libm), where event.h:102-103 calls std::cos / std::sin -- bf_project_4param_reinit, the one-to-one operator,
+ * evaluates them on the host with libm like the reference, so the two entry points can differ by that ulp.
+ * What holds: the event-count image is bit-exact at fixed warp parameters; the time image agrees to 1e-6 relative, the
+ * moments to 1e-9; a trajectory agrees with the CPU restatement to rounding until the first event crosses a pixel
+ * boundary differently and within the restatement's own event-order spread afterwards; converged per-event flow
+ * agrees to 1e-4 relative or 0.02 px/s, iteration counts to +-1 (tests/test_gpu_parity.py, tests/test_gpu_geometries.py
+ * bound all of these at full size).  Every scatter / loop mode of this library gives the same bits as every other, and
+ * every run is bit-reproducible (integer accumulators). */
 int bf_run(bf_ctx *ctx, const bf_run_opts *opts, bf_model *model_out, bf_run_info *info);
 
 /* A grid of independent optimizers over the staged slice (BASELINE config 4; the reference's

@@ -65,8 +65,8 @@ struct bf_ctx {
     uint16_t* d_cidx = nullptr;      // compact lists: pixel index per entry (same slot count as d_slabs)
     uint32_t* d_chdr = nullptr;      // compact lists: entries per bin
     int stencil_threads = 256;       // work-group size of the stencil kernels for this slice (bf_set_cloud)
-    int opt_stencil_threads = 0;     // 0: by the number of tiles
-    bool use_compact = false;        // this slice's scatter writes compact lists (decided in bf_set_cloud)
+    int opt_stencil_threads = 0;     // 0: 256
+    int fmt = 0;                     // what this slice's scatter hands to the stencil: 0 dense slabs, 1 merged lists, 2 event lists (bf_set_cloud)
     int opt_bin_ev = 0;              // events per scatter thread in flight (0: from the events per bin)
     int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
     int bins_alloc = 0;
@@ -285,7 +285,7 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.zero_cplane = (c->packed && !c->use_binned) ? nullptr : c->d_cplane[buf ^ 1];
     a.slabs = c->d_slabs;
     a.cidx = c->d_cidx; a.chdr = c->d_chdr;
-    a.compact = c->use_compact ? 1 : 0;
+    a.compact = c->fmt;
     a.threads = c->stencil_threads;
     a.g = c->grid;
     a.ovf_cur = a.ovf_prev = c->d_ovf;   // (the tile-binned loop sets the three counters per launch)
@@ -645,7 +645,7 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         return BF_OK;
     }
     if (!strcmp(key, "bin_compact")) {
-        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "bin_compact must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(c, BF_ERR_ARG, "bin_compact must be 0, 1, 2 or 3");
         c->opt_bin_compact = (int)value;
         return BF_OK;
     }
@@ -917,10 +917,12 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     h.x_shift = w.x_shift; h.y_shift = w.y_shift;
     h.hot.tmin = tmin;
     h.nblocks = gx * gy;
-    // Stencil work-group size.  A small image gives fewer tiles than the chip has room for: 512 threads per tile then halve
-    // the pixels per thread and shorten every work-group's dependent chain (what one slice alone waits for); a large image
-    // is throughput-bound and keeps 256 (fewer per-wave fixed costs).
-    c->stencil_threads = c->opt_stencil_threads > 0 ? c->opt_stencil_threads : (gx * gy <= 1024 ? 512 : 256);
+    // Stencil work-group size: 256 threads per 16 x 64 tile.  "stencil_threads" = 512 halves the pixels per thread and
+    // shortens a work-group's dependent chain: one context alone on a small image gains 1.5 % (20.65 -> 20.35 us per
+    // iteration at 346x260), four contexts sharing the GPU lose 12 % (164 -> 144 Mev/s: twice the waves for the same
+    // work), and the f64 partial sums are formed in another order, so its bits differ from the 256-thread build's.
+    // Hence an option, not a default.
+    c->stencil_threads = c->opt_stencil_threads > 0 ? c->opt_stencil_threads : 256;
     memset(&h.model, 0, sizeof(h.model));   // a fresh OptimizerRolling has a zero ObjectModel
     h.hot.wp = identity_warp();
     h.hot.it = 0; h.hot.done = 0; h.rc = 0;
@@ -992,17 +994,26 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         h.n_events = (uint32_t)c->n;
         h.hot.bin_tbits = tbits > 62 ? 62 : tbits; h.hot.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
         h.hot.flip = 0;
-        // Event lists or dense slabs.  A dense slice (one event per pixel or more) merges its events in the bin's LDS tile
-        // and writes the tile; a sparse one writes one list entry per event (no LDS tile: the tile of a 1280x720 bin would
-        // fill the CU's LDS and leave one work-group per CU).  "auto" goes by the density, once per slice: the kernels are
-        // compiled per format.
+        // Dense slabs, merged lists or event lists.  A dense slice (one event per four pixels or more) merges its events in
+        // the bin's LDS tile and writes the tile.  A sparse one writes lists, work and traffic following the events: one
+        // entry per EVENT and no LDS tile where events rarely meet at a pixel (at most two events per sensor pixel of the
+        // window: a 1280x720 sensor with 1M events -- the tile of such a bin would fill the CU's LDS and leave one
+        // work-group per CU), one entry per touched PIXEL, merged in the LDS tile, where they do (a small sensor at a large
+        // scale: a third of the entries, and the stencil kernel splats every entry into s x s pixels).  "auto" decides once
+        // per slice: the kernels are compiled per format.  Measured per iteration (dense / merged / events): 1280x720
+        // scale 3: 90 / 81 / 68 us; 346x260 scale 7: 96 / 61 / 103; 640x480 scale 3: 44 / 53 / 52.
         {
             const double P = (double)w.scale_img_x * (double)w.scale_img_y;
-            // (16-bit tile-local pixel indices in the lists)
+            const double sensor_px = P / ((double)scale * (double)scale);
             const size_t LLg = (size_t)g.LR * (size_t)g.L;
-            const int mode = (c->use_binned && LLg <= 65536) ? c->opt_bin_compact : 0;
-            c->use_compact = mode == 2 || (mode == 1 && 4.0 * (double)c->n < P);
-            h.hot.fmt = c->use_compact ? 1 : 0;
+            const bool lists_ok = c->use_binned && LLg <= 65536;                         // 16-bit tile-local pixel indices
+            const bool merged_ok = lists_ok && LLg * 10 + 16 <= (size_t)kBinTileLdsMax;   // tile + index list in LDS
+            const int mode = lists_ok ? c->opt_bin_compact : 0;
+            c->fmt = 0;
+            if (mode == 2) c->fmt = 2;
+            else if (mode == 3) c->fmt = merged_ok ? 1 : 2;
+            else if (mode == 1 && 4.0 * (double)c->n < P) c->fmt = ((double)c->n <= 2.0 * sensor_px || !merged_ok) ? 2 : 1;
+            h.hot.fmt = c->fmt;
         }
         h.t_span = (c->n > 0) ? (long long)s.tmax - (long long)s.tmin : 0;
         h.t_abs_max = (c->n > 0) ? std::fmax(std::fabs((double)s.tmin), std::fabs((double)s.tmax)) : 0.0;
@@ -1356,7 +1367,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     else if (binned) {
         // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a
         // CU, and a bin above the pass size takes a second pass; measured at 1280x720: 512 x 2 69.8 us, 512 x 4 73.5)
-        const double per_bin = (c->use_compact ? 1.0 : 1.5) * ev_per_bin / (double)bin_threads;
+        const double per_bin = (c->fmt == 2 ? 1.0 : 1.5) * ev_per_bin / (double)bin_threads;
         ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2 ? 2 : (per_bin <= 4 ? 4 : 8));
     }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
@@ -1403,7 +1414,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.bin_start = c->d_bin_start;
                 ba.slabs = c->d_slabs;
                 ba.cidx = c->d_cidx; ba.chdr = c->d_chdr;
-                ba.compact = c->use_compact ? 1 : 0;
+                ba.compact = c->fmt;
                 ba.ovf_plane = c->d_plane[buf]; ba.ovf_cplane = c->d_cplane[buf];
                 ba.st_in = state_of(j); ba.st_out = state_of(j + 1);
                 ba.acc = head_update ? acc_of(j - 1) : nullptr;

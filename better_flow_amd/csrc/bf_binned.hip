@@ -410,6 +410,55 @@ __device__ __forceinline__ void list_put(const ScatterHot& hs, const ScatterGeo&
     }
 }
 
+// ---- merged lists (the other compact form) ---------------------------------------------------------------------------
+// A sparse image whose events still meet at pixels (a small sensor at a large scale: 1M events from 90 000 sensor pixels
+// on a 1729 x 2352 image): the bin's events are merged in its LDS tile as in the dense form, but only the TOUCHED pixels
+// go out -- the accumulate returns the previous value, the lane that finds 0 there touched the pixel first and appends
+// its index to the tile's LDS list (one counter add per wave: ballot + rank) and counts its tile row; the flush
+// counting-sorts the list by tile row.  Same list format as the event lists, a third of the entries in that example
+// (the stencil kernel splats every entry into (2 HS + 1)^2 pixels: 49 at scale 7).
+template <bool WARP>
+__device__ __forceinline__ void scatter_event_merged(const ScatterHot& hs, const ScatterGeo& sg, unsigned long long* s_tile,
+                                                     uint16_t* s_list, uint32_t* s_cnt, const BinScatterArgs& a, float2* p,
+                                                     uint32_t i, uint32_t v, int32_t ti, double pr_x, double pr_y,
+                                                     uint32_t& n_ovf) {
+    int X, Y;
+    if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return;
+    const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
+    const int lx = X - sg.X0, ly = Y - sg.Y0;
+    if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
+        const int idx = __mul24(lx, sg.L) + ly;
+        const unsigned long long old = atomicAdd(&s_tile[idx], (1ull << hs.bin_tbits) + dt);
+        if (old == 0ull) {
+            const unsigned long long m = __ballot(1);   // the lanes that are first at their pixel
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint32_t base = 0;
+            if (rank == 0) base = atomicAdd(s_cnt, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // (the first active lane is the one of rank 0)
+            s_list[base + rank] = (uint16_t)idx;
+            atomicAdd(&s_cnt[1 + lx], 1u);   // entries per tile row (the flush sorts the list by row)
+        }
+    } else {
+        overflow_add(hs, a, X, Y, dt);
+        ++n_ovf;
+    }
+}
+// s_cnt: [0] entries, [1 .. LR] per-row counts, turned into running cursors here.  Called after a work-group barrier.
+template <int THREADS>
+__device__ __forceinline__ void flush_list(const unsigned long long* s_tile, const uint16_t* s_list, uint32_t* s_cnt,
+                                           int LR, uint32_t mul_l, unsigned long long* vals, uint16_t* cidx, uint32_t* crow,
+                                           int tid) {
+    const uint32_t n = s_cnt[0];
+    if (tid < 64) list_row_scan(s_cnt, LR, crow, tid);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += THREADS) {
+        const uint32_t idx = s_list[i];
+        const uint32_t slot = atomicAdd(&s_cnt[1 + __umulhi(idx, mul_l)], 1u);
+        __hip_atomic_store(&vals[slot], s_tile[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cidx[slot] = (uint16_t)idx;
+    }
+}
+
 // The whole tile goes to the bin's slab (nothing to zero, no atomics).  WRITE-THROUGH stores (agent-scope relaxed =
 // global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat dirty in the L2s until the end of the
 // kernel, and their write-back stretched the kernel boundary to ~5.6 us (measured; "B / 6 TB/s" in the MI355X notes).
@@ -435,12 +484,13 @@ __device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, uns
 // accumulators are the first thing requested, the events of the first pass the second, and while the first wave forms
 // the total and updates, the other fifteen turn their events' stored f32 products into the previous positions (the
 // model-independent third of the per-event arithmetic); the first wave catches up after the barrier.
-template <bool WARP, int THREADS, int U, bool COMPACT>
+template <bool WARP, int THREADS, int U, int FMT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
+    constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
     __shared__ DevState s_state;
-    __shared__ uint32_t s_row[COMPACT ? 1 + kMaxTileRows : 1];   // event lists: entries per tile row, then the rows' cursors
-    if (COMPACT)
+    __shared__ uint32_t s_row[FMT ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
+    if (FMT)
         for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
@@ -593,12 +643,14 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
         tl_stamp(a.tl, a.j, 4);
         return;
     }
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);   // (merged lists: the tile, then one index slot per pixel)
     for (;;) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            if (MERGED) scatter_event_merged<WARP>(hs, sg, s_tile, s_list, s_row, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            else scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
         }
         base += THREADS * U;
         if (base >= end) break;
@@ -610,7 +662,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     __syncthreads();
     tl_stamp(a.tl, a.j, 3);
     store_state();
-    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
+                                    a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+    else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     tl_stamp(a.tl, a.j, 4);
 }
 
@@ -618,11 +672,12 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
 // updated it: "co_schedule", the throughput mode with several slice contexts per GPU).  No barrier between the loads
 // and the scatter, so the waves of a work-group drift apart and overlap each other's memory latency.  Work-group 0
 // still carries the state to the other buffer and to the host snapshot.
-template <bool WARP, int THREADS, int U, bool COMPACT>
+template <bool WARP, int THREADS, int U, int FMT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
+    constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
-    __shared__ uint32_t s_row[COMPACT ? 1 + kMaxTileRows : 1];   // event lists: entries per tile row, then the rows' cursors
-    if (COMPACT)
+    __shared__ uint32_t s_row[FMT ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
+    if (FMT)
         for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
@@ -716,19 +771,24 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
         hand_state_on();
         return;
     }
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
     for (uint32_t base = beg; base < end; base += THREADS * U) {
         load_pass(base);
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
-                                pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            if (MERGED) scatter_event_merged<WARP>(hs, sg, s_tile, s_list, s_row, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                                   pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            else scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                     pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
         }
     }
     if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     __syncthreads();
-    flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
+    if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
+                                    a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+    else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     hand_state_on();
 }
 
@@ -1003,29 +1063,31 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
                        has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);
 }
 
-template <int THREADS, int U, bool COMPACT>
+template <int THREADS, int U, int FMT>
 static void launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    const size_t lds = COMPACT ? 0 : (size_t)a.g.LR * a.g.L * sizeof(unsigned long long) + 16;   // the bin's tile (event lists: none)
+    // dynamic LDS: the bin's tile (dense slabs, merged lists: + one 16-bit index slot per pixel); event lists: none
+    const size_t lds = FMT == 2 ? 0 : (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (FMT == 1 ? sizeof(uint16_t) : 0)) + 16;
     static bool raised = false;   // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
         raised = true;
     }
     if (!a.acc) {   // nothing to update at the head
-        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
         return;
     }
-    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-    else launch_timed(k_bin_warp_scatter<false, THREADS, U, COMPACT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    else launch_timed(k_bin_warp_scatter<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
 }
 template <int THREADS, int U>
 static void launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    if (a.compact) launch_bws2<THREADS, U, true>(a, warp, s);
-    else launch_bws2<THREADS, U, false>(a, warp, s);
+    if (a.compact >= 2) launch_bws2<THREADS, U, 2>(a, warp, s);
+    else if (a.compact == 1) launch_bws2<THREADS, U, 1>(a, warp, s);
+    else launch_bws2<THREADS, U, 0>(a, warp, s);
 }
 
 // `per_thread`: events a thread keeps in flight (1, 2, 4 or 8 at 1024 threads; the smaller work-group sizes keep 8192

@@ -75,7 +75,7 @@ for ci in range(cases):
     modes = [("default", {}), ("atomics", {"binned": 0}), ("binned", {"binned": 2}),
              ("tile32", {"binned": 2, "bin_tile": 32, "bin_margin": int(rng.choice([4, 8, 12]))}),
              ("nopredict", {"binned": 2, "bin_predict": 0, "bin_margin": 2}),
-             ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}),
+             ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}), ("merged", {"binned": 2, "bin_compact": 3}), ("merged_co", {"binned": 2, "bin_compact": 3, "co_schedule": 1}),
              ("dense_co", {"binned": 2, "bin_compact": 0, "co_schedule": 1}), ("compact_co", {"binned": 2, "bin_compact": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
              ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))})]
     for name, kv in modes:

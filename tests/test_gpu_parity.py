@@ -617,7 +617,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
     runs = {}
     for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2)),
                        ("tail_update", dict(binned=2, co_schedule=1)), ("compact", dict(binned=2, bin_compact=2)),
-                       ("dense", dict(binned=2, bin_compact=0))):
+                       ("dense", dict(binned=2, bin_compact=0)), ("merged", dict(binned=2, bin_compact=3))):
         a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         for k, v in opts.items():
             a2.set_option(k, v)
@@ -628,7 +628,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
         rc, m, info = a2.run(o)
         runs[name] = (rc, info.iterations, m.as_dict(), [t_.model.as_dict() for t_ in a2.get_trace(K + 1)], a2.compute_uv())
         a2.close()
-    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4] == runs["compact"][:4] == runs["dense"][:4]
+    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4] == runs["compact"][:4] == runs["dense"][:4] == runs["merged"][:4]
     assert np.array_equal(runs["binned"][4][0], runs["atomics"][4][0])
     assert runs["binned"][1] == oloop.itercount == K + 1
     for k in range(K + 1):

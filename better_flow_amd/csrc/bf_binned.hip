@@ -821,8 +821,9 @@ __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* a
 template <int HS, bool COMPACT, int NT>
 __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     tl_stamp(a.tl, a.tl_launch, 0);
-    const HotState hs = sload(&a.st->hot);   // one burst of scalar loads, then the branch
-    if (a.check_done && hs.done) return;
+    // one burst of scalar loads; the state is not CONSUMED (not even for the early exit of a finished loop) before the
+    // first vector loads below are out: their latencies overlap instead of adding up
+    const HotState hs = sload(&a.st->hot);
     tl_stamp(a.tl, a.tl_launch, 1);
     constexpr int TR = kTileR, TC = kTileC;
     constexpr int H = HS + 1;
@@ -892,6 +893,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
             }
             if (tid == 0) s_eoff[0] = 0;
         }
+        if (a.check_done && hs.done) return;   // (uniform; before the first barrier)
         __syncthreads();   // (the box plane is zero, the bin table is in place)
         const uint32_t E = s_eoff[nbin_];
         for (uint32_t e = tid; e < E; e += NT) {
@@ -953,6 +955,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
             w[c][q] = use ? a.slabs[(uint32_t)(((q & 2) ? rowpart_h : rowpart_l) + ((q & 1) ? colpart_h : colpart_l))] : 0ull;
         }
     }
+    if (a.check_done && hs.done) return;   // (uniform; before the first barrier -- the loads above are already out)
     // The slab accumulators stay PACKED (count << tbits | time sum) through the merge and the box sum: k_bin_scan sized
     // the fields for any sum over the events of up to four bins, which covers the <= 2 x 2 slabs at a pixel and the
     // s x s box around it.  One 64-bit add per contribution, one unpack per pixel.  Events that took the overflow path

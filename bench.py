@@ -428,7 +428,7 @@ def main():
                 "algorithmic_bytes_per_launch": 24.0 * img_px,
                 "achieved": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9,
                 "frac": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS,
-                "note": "instruction-issue bound, not bandwidth bound: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
+                "note": "bound by dependent latency and instruction issue (its waves wait ~55 % of their cycles), not by bandwidth: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
             },
             "per_kernel_us": {
                 "warp_scatter": 1e3 * p.warp_scatter_ms / max(1, live),

@@ -337,11 +337,11 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
         for (void* o : old) if (o) HIP_TRY(c, hipFree(o));
         c->d_hist_cnt = nullptr; c->d_bin_start = nullptr; c->d_cursor = nullptr; c->d_chdr = nullptr;
         const size_t nb = (size_t)g.nbins + 1;
-        HIP_TRY(c, hipMalloc(&c->d_hist_cnt, nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_hist_cnt, kHistCopies * nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_bin_start, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_cursor, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_chdr, nb * 200 * sizeof(uint32_t)));   // compact lists: LR + 1 <= 193 row offsets per bin
-        HIP_TRY(c, hipMemsetAsync(c->d_hist_cnt, 0, nb * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_hist_cnt, 0, kHistCopies * nb * sizeof(uint32_t), c->stream));
         c->bins_alloc = g.nbins;
     }
     const size_t need = (size_t)g.nbins * (size_t)g.LR * (size_t)g.L;
@@ -1333,7 +1333,6 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     h.hot.cs = c->cs; h.hot.flip = 0;
     if (!first_warp) h.hot.wp = identity_warp();
     h.ref_wp = h.hot.wp;
-    launch_set_state(c->d_state, h, c->stream);
     const bool perm_at_start = c->has_perm;
 
     const int b0 = c->cur;
@@ -1349,7 +1348,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     auto state_of = [&](int j) { return c->d_state + (j & 1); };
     auto acc_of = [&](int j) { return c->d_acc + (size_t)(j & 1) * kAccGroups; };
     auto ovf_of = [&](int j) { return c->d_ovf + ((j % 3) + 3) % 3; };
-    if (binned || c->acc_dirty) launch_loop_init(c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, c->stream);
+    // (one launch: the state, and the loop's counters / accumulators)
+    launch_run_init(c->d_state, h, c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, binned || c->acc_dirty, c->stream);
     c->acc_dirty = false;
     // Where the model / loop update runs.  One slice context alone: at the head of the next warp+scatter launch (every
     // work-group for itself; shortest iteration).  Several contexts sharing the GPU ("co_schedule"): in the last
@@ -1475,7 +1475,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             fa.pick_set = binned ? 1 : 0;
             fa.sorted_out = 1;
             if (o.want_uv) fa.uv = c->d_uv;
-            launch_warp_scatter(fa, true, false, true, c->stream);
+            launch_final_warp(fa, c->stream);
             inf.launches++;
         }
         HIP_TRY(c, hipGetLastError());
@@ -1567,7 +1567,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         fa.pick_set = binned ? 1 : 0;                    // the device knows which set holds the (tile-sorted) events
         fa.sorted_out = 1;
         if (o.want_uv) fa.uv = c->d_uv;   // Event::compute_uv (event.h:135-142) in the same pass
-        launch_warp_scatter(fa, true, false, true, c->stream);
+        launch_final_warp(fa, c->stream);
         inf.launches++;
     }
     if (snap_polled) {   // the final state, consistently: behind everything that is queued

@@ -52,12 +52,22 @@ __device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs,
 // of OptimizerRolling::set_model (optimizer_rolling.h:294-298) is applied on the way (the events must be
 // sorted by where that warp puts them), saving a pass over the events.  A launch that has nothing to do
 // also disarms the scatter kernel (see k_bin_scatter).
+// Work-groups of 1024 threads x 4 events (the same kBsEvents consecutive events per work-group as in k_bin_scatter), every
+// load of a thread's events issued before the first is used; the local histogram is flushed with atomics into ONE OF
+// kHistCopies copies of the global histogram (work-group b -> copy b % kHistCopies; the scan kernel adds the copies up):
+// a slice in upload order has events of every bin in every work-group, and with one copy ~500 atomics queued on each
+// address at ~30 ns apiece -- 15.6 us for this kernel; now 7-10.  (A (work-groups x bins) histogram matrix with column
+// prefixes in the scan kernel, i.e. no atomics at all, was tried: the one-work-group column scan cost what the atomics
+// had, 10-14 us against 5.)
+constexpr int kBsThreads = 1024;
+constexpr int kBsPerThread = 4;
+constexpr int kBsEvents = kBsThreads * kBsPerThread;   // 4096 events per work-group, here and in k_bin_scatter
 template <bool PREWARP>
-__global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n,
-                                                        const DevState* __restrict__ st, BinGrid g,
-                                                        uint16_t* __restrict__ binid,
-                                                        uint32_t* __restrict__ hist_cnt,
-                                                        uint32_t* __restrict__ armed, WarpParams prewarp) {
+__global__ __launch_bounds__(kBsThreads) void k_bin_count(EvSets sets, long long n,
+                                                          const DevState* __restrict__ st, BinGrid g,
+                                                          uint16_t* __restrict__ binid,
+                                                          uint32_t* __restrict__ hist_cnt,
+                                                          uint32_t* __restrict__ armed, WarpParams prewarp) {
     const HotState hs = st->hot;
     if (!hs.need_rebin || hs.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *armed = 0;
@@ -65,72 +75,106 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(EvSets sets, long long n
     }
     const EvSetPtrs e = sets.s[hs.cs ^ hs.flip];
     extern __shared__ uint32_t s_cnt[];
-    for (int i = threadIdx.x; i < g.nbins; i += kThreads) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < g.nbins; i += kBsThreads) s_cnt[i] = 0;
     __syncthreads();
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
-         i += (long long)gridDim.x * kThreads) {
-        const uint32_t v = e.xy[i];
-        const int32_t ti = e.t[i];
-        float2 q = e.p[i];
+    // every load of a thread's events is issued before the first is used
+    const long long base = (long long)blockIdx.x * kBsEvents;
+    uint32_t v[kBsPerThread];
+    int32_t ti[kBsPerThread];
+    float2 q[kBsPerThread];
+#pragma unroll
+    for (int k = 0; k < kBsPerThread; ++k) {
+        long long i = base + k * kBsThreads + threadIdx.x;
+        i = i < n ? i : base;
+        v[k] = e.xy[i];
+        if (PREWARP) ti[k] = e.t[i];
+        q[k] = e.p[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kBsPerThread; ++k) {
+        const long long i = base + k * kBsThreads + threadIdx.x;
+        if (i >= n) continue;
         if (PREWARP) {
             double nx, ny;
-            warp_products(prewarp, pr_from_p(v & 0xffffu, q.x), pr_from_p(v >> 16, q.y), ti, q, nx, ny);
-            e.p[i] = q;
+            warp_products(prewarp, pr_from_p(v[k] & 0xffffu, q[k].x), pr_from_p(v[k] >> 16, q[k].y), ti[k], q[k], nx, ny);
+            e.p[i] = q[k];
         }
-        const int b = bin_of(v, q, hs, g);
+        const int b = bin_of(v[k], q[k], hs, g);
         binid[i] = (uint16_t)b;
         atomicAdd(&s_cnt[b], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < g.nbins; i += kThreads) {
-        if (s_cnt[i]) atomicAdd(&hist_cnt[i], s_cnt[i]);
-    }
+    uint32_t* copy = hist_cnt + (size_t)(blockIdx.x % kHistCopies) * (size_t)g.nbins;
+    for (int i = threadIdx.x; i < g.nbins; i += kBsThreads)
+        if (s_cnt[i]) atomicAdd(&copy[i], s_cnt[i]);
 }
 
-// R2: exclusive scan of the counts -> bin_start.
+// R2: the copies of the histogram added up, exclusive scan of the counts -> bin_start.
+constexpr int kMaxGridBins = 8192;   // (bf_set_cloud keeps the bin grid below this)
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_cnt, int nbins,
                                                    uint32_t* __restrict__ bin_start,
                                                    uint32_t* __restrict__ cursor, DevState* st,
                                                    uint32_t* __restrict__ armed, int pack_limit) {
     if (!st->hot.need_rebin || st->hot.done) return;
-    __shared__ uint32_t s_sum[1024];
-    __shared__ uint32_t s_maxc[1024];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t s_tot[kMaxGridBins];
+    __shared__ uint32_t s_wsum[16], s_wmax[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = tid; b < nbins; b += 1024) {   // (consecutive threads -> consecutive bins: coalesced)
+        uint32_t c[kHistCopies];
+#pragma unroll
+        for (int q = 0; q < kHistCopies; ++q) c[q] = hist_cnt[(size_t)q * (size_t)nbins + (size_t)b];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int q = 0; q < kHistCopies; ++q) {
+            tot += c[q];
+            if (c[q]) hist_cnt[(size_t)q * (size_t)nbins + (size_t)b] = 0;   // ready for the next re-bin
+        }
+        s_tot[b] = tot;
+        cursor[b] = 0;
+    }
+    __syncthreads();
     const int per = (nbins + 1023) / 1024;
     uint32_t local = 0, maxc = 0;
     for (int k = 0; k < per; ++k) {
         const int b = tid * per + k;
-        if (b < nbins) { local += hist_cnt[b]; maxc = max(maxc, hist_cnt[b]); }
+        if (b < nbins) { local += s_tot[b]; maxc = max(maxc, s_tot[b]); }
     }
-    s_sum[tid] = local; s_maxc[tid] = maxc;
+    // inclusive scan of `local` / maximum over the work-group: wave scan by shuffles, then the 16 wave totals
+    uint32_t incl = local, wmax = maxc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+        wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off, 64));
+    }
+    if (lane == 63) { s_wsum[wave] = incl; s_wmax[wave] = wmax; }
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan (sum) / running maximum
-        uint32_t v = (tid >= off) ? s_sum[tid - off] : 0u;
-        uint32_t mc = (tid >= off) ? s_maxc[tid - off] : 0u;
-        __syncthreads();
-        s_sum[tid] += v;
-        s_maxc[tid] = max(s_maxc[tid], mc);
-        __syncthreads();
+    uint32_t wbase = 0, total = 0, allmax = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t v = s_wsum[w];
+        if (w < wave) wbase += v;
+        total += v;
+        allmax = max(allmax, s_wmax[w]);
     }
-    uint32_t run = s_sum[tid] - local;   // exclusive prefix of this thread's first bin
+    incl += wbase;
+    uint32_t run = incl - local;   // exclusive prefix of this thread's first bin
     for (int k = 0; k < per; ++k) {
         const int b = tid * per + k;
         if (b < nbins) {
             bin_start[b] = run;
-            run += hist_cnt[b];
-            cursor[b] = 0;
-            hist_cnt[b] = 0;   // ready for the next re-bin
+            run += s_tot[b];
         }
     }
     if (tid == 1023) {
-        bin_start[nbins] = s_sum[1023];
+        bin_start[nbins] = total;
         // Packing of the per-bin tiles (count << tbits | time sum).  Whatever is summed in packed form downstream -- a
         // tile pixel, the <= 2 x 2 slabs merged at a pixel, the s x s box around it -- is a sum over events of at most
         // four bins, each adding 1 and at most t_span: the fields need bits(4 maxc) and bits(4 maxc t_span), with maxc
         // the fullest bin.  (A slice-wide bound -- bits(N) + bits(sum of all times) -- stops fitting 64 bits just above
         // 1M events x 30 ms.)  If even this does not fit (nearly all events in one bin), bin_ok = 0 sends every event
         // down the exact overflow path (unpacked u64 + u32 planes).
-        const unsigned long long m4 = 4ull * (unsigned long long)s_maxc[1023];
+        const unsigned long long m4 = 4ull * (unsigned long long)allmax;
         int cb = 0, tb = 0;
         for (unsigned long long v = m4; v; v >>= 1) ++cb;
         const unsigned long long span = (unsigned long long)(st->t_span > 0 ? st->t_span : 1);
@@ -158,9 +202,9 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ hist_c
 // order, so that consecutive lanes write consecutive addresses of a bin's range.  Writing each event
 // straight to its slot (one 4 / 8-byte store per lane to ~64 different cache lines per instruction)
 // took 47 us per 1M events; this form is bound by the 40 B/event it moves.
-constexpr int kBsPerThread = 16;
-constexpr int kBsEvents = kThreads * kBsPerThread;   // 4096 events, 80 KB of LDS staging
-__global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_perm,
+// (1024 threads x 4 events: with 256 x 16 a CU ran four waves, every phase -- ranks, staging, write-out -- at its full
+// latency: 19.8 us per 1M events)
+__global__ __launch_bounds__(kBsThreads) void k_bin_scatter(EvSets sets, int has_perm,
                                                           const uint16_t* __restrict__ binid, long long n,
                                                           const uint32_t* __restrict__ bin_start,
                                                           uint32_t* __restrict__ cursor, int nbins,
@@ -178,9 +222,9 @@ __global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_p
     uint32_t* s_perm = reinterpret_cast<uint32_t*>(s_t + kBsEvents);
     uint16_t* s_bin = reinterpret_cast<uint16_t*>(s_perm + kBsEvents);
     float2* s_p = reinterpret_cast<float2*>(s_bin + kBsEvents);   // (8-byte aligned: all counts above are even)
-    __shared__ uint32_t s_wsum[kThreads / 64];
+    __shared__ uint32_t s_wsum[kBsThreads / 64];
     const int tid = threadIdx.x;
-    for (int i = tid; i < nbins; i += kThreads) s_cnt[i] = 0;
+    for (int i = tid; i < nbins; i += kBsThreads) s_cnt[i] = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * kBsEvents;
     const int live = (int)((n - base) < kBsEvents ? (n - base) : kBsEvents);
@@ -188,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_p
     int bin[kBsPerThread];
 #pragma unroll
     for (int k = 0; k < kBsPerThread; ++k) {
-        const int j = k * kThreads + tid;
+        const int j = k * kBsThreads + tid;
         bin[k] = -1;
         if (j < live) {
             bin[k] = binid[base + j];
@@ -198,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_p
     __syncthreads();
     // reserve the global ranges, then turn the histogram into exclusive local offsets (block scan)
     {
-        const int per = (nbins + kThreads - 1) / kThreads;
+        const int per = (nbins + kBsThreads - 1) / kBsThreads;
         uint32_t local = 0;
         for (int k = 0; k < per; ++k) {
             const int b = tid * per + k;
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_p
     // stage: event -> LDS slot (local offset of its bin + its rank)
 #pragma unroll
     for (int k = 0; k < kBsPerThread; ++k) {
-        const int j = k * kThreads + tid;
+        const int j = k * kBsThreads + tid;
         if (bin[k] >= 0) {
             const long long i = base + j;
             const uint32_t o = s_cnt[bin[k]] + rank[k];
@@ -246,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_scatter(EvSets sets, int has_p
     }
     __syncthreads();
     // write out in sorted order: slot j of bin b goes to s_base[b] + (j - local offset of b)
-    for (int j = tid; j < live; j += kThreads) {
+    for (int j = tid; j < live; j += kBsThreads) {
         const int b = s_bin[j];
         const uint32_t o = s_base[b] + ((uint32_t)j - s_cnt[b]);
         dst.xy[o] = s_xy[j];
@@ -1051,18 +1095,16 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
                   uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
                   uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s) {
     if (n <= 0) return;
-    long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
-    if (blocks > 1024) blocks = 1024;
+    const unsigned blocks = (unsigned)((n + kBsEvents - 1) / kBsEvents);
     if (prewarp)
-        hipLaunchKernelGGL(k_bin_count<true>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 4, s, sets, n,
+        hipLaunchKernelGGL(k_bin_count<true>, dim3(blocks), dim3(kBsThreads), (size_t)g.nbins * 4, s, sets, n,
                            st, g, binid, hist_cnt, armed, *prewarp);
     else
-        hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)blocks), dim3(kThreads), (size_t)g.nbins * 4, s, sets, n,
+        hipLaunchKernelGGL(k_bin_count<false>, dim3(blocks), dim3(kBsThreads), (size_t)g.nbins * 4, s, sets, n,
                            st, g, binid, hist_cnt, armed, WarpParams{});
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, hist_cnt, g.nbins, bin_start, cursor,
-                       st, armed, pack_limit);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, hist_cnt, g.nbins, bin_start, cursor, st, armed, pack_limit);
     const size_t lds = ((size_t)g.nbins * 2 + (g.nbins & 1)) * 4 + (size_t)kBsEvents * (4 + 4 + 4 + 2 + 8);
-    hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + kBsEvents - 1) / kBsEvents)), dim3(kThreads), lds, s, sets,
+    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks), dim3(kBsThreads), lds, s, sets,
                        has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);
 }
 
@@ -1107,15 +1149,19 @@ void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, in
 #undef BF_K1
 }
 
-// Start of a tile-binned run: overflow counters (slot j % 3 <- iteration j; slot 2 = "iteration -1") and both
+// Start of a run, one launch: the host's state to the device (the struct travels as a kernel argument), and -- tile-binned
+// run, or accumulators left dirty -- the overflow counters (slot j % 3 <- iteration j; slot 2 = "iteration -1") and both
 // accumulator parities.
-__global__ __launch_bounds__(kThreads) void k_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc) {
+__global__ __launch_bounds__(kThreads) void k_run_init(DevState* st, DevState v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc,
+                                                       int init_loop) {
     const int tid = threadIdx.x;
+    if (tid < kStateWords) reinterpret_cast<unsigned long long*>(st)[tid] = reinterpret_cast<const unsigned long long*>(&v)[tid];
+    if (!init_loop) return;
     if (tid < 3) ovf[tid] = (tid == 2) ? prev_dirty : 0u;
     for (int i = tid; i < 2 * kAccGroups * 16; i += kThreads) (&acc[0].f[0])[i] = 0ull;
 }
-void launch_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, hipStream_t s) {
-    hipLaunchKernelGGL(k_loop_init, dim3(1), dim3(kThreads), 0, s, ovf, prev_dirty, acc);
+void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, bool init_loop, hipStream_t s) {
+    hipLaunchKernelGGL(k_run_init, dim3(1), dim3(kThreads), 0, s, st, v, ovf, prev_dirty, acc, init_loop ? 1 : 0);
 }
 
 void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,

@@ -8,6 +8,7 @@
 
 namespace bf {
 
+constexpr int kHistCopies = 8;   // copies of the re-bin's global histogram (work-group b adds to copy b % 8: contention)
 constexpr int kBinTileLdsMax = 156 * 1024;   // dynamic LDS of a scatter work-group (160 KiB per CU minus its static part)
 constexpr int kPrepBlocks = 1024;   // work-groups of k_prepare == SliceStats records it writes
 
@@ -82,6 +83,8 @@ struct LaunchTimer {
 LaunchTimer& launch_timer();   // thread local
 
 void launch_set_state(DevState* st, const DevState& v, hipStream_t s);
+// the run's final warp with compute_uv fused (outputs in slot order): one event per thread
+void launch_final_warp(const WarpScatterArgs& a, hipStream_t s);
 void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool write_n,
                          hipStream_t s);
 void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_in, uint32_t* xy,
@@ -145,7 +148,7 @@ struct BinScatterArgs {
     unsigned long long* tl;
 };
 void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
-void launch_loop_init(uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, hipStream_t s);
+void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, bool init_loop, hipStream_t s);
 
 // bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)
 struct LocalGeom {

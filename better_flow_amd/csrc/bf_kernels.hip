@@ -123,6 +123,38 @@ __global__ __launch_bounds__(kThreads) void k_warp_scatter(
     }
 }
 
+// The last project_4param_reinit of a run (optimizer_rolling.h:340-344) with Event::compute_uv (event.h:135-142) fused:
+// n, (u, v) and the new products for every event, outputs in slot order.  ONE event per thread: the general kernel above
+// takes four consecutive events per thread (16-byte loads), which leaves 3900 waves for 1M events -- four per SIMD, each
+// running ~1000 dependent f64 instructions (hypot and three IEEE divisions per event); this form has four times the waves
+// to interleave.  Same arithmetic per event, same bits.
+__global__ __launch_bounds__(kThreads) void k_final_warp(WarpScatterArgs a) {
+    const HotState hs = sload(&a.st->hot);
+    if (a.check_done == 1 && hs.done) return;
+    if (a.check_done == 2 && !hs.done) return;
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t* xy = a.xy;
+    const int32_t* t = a.t;
+    float2* p = a.p;
+    if (a.pick_set) {   // tile-binned loop: the device knows which set holds the (sorted) events
+        const EvSetPtrs e = (hs.cs ^ hs.flip) ? a.sets.s[1] : a.sets.s[0];
+        xy = e.xy; t = e.t; p = e.p;
+    }
+    const uint32_t v = xy[i];
+    const int32_t ti = t[i];
+    float2 q = p[i];
+    double nx, ny;
+    warp_products(hs.wp, pr_from_p(v & 0xffffu, q.x), pr_from_p(v >> 16, q.y), ti, q, nx, ny);
+    p[i] = q;
+    a.nxny[i] = make_double2(nx, ny);
+    if (a.uv) a.uv[i] = uv_from_n(make_double2(nx, ny));
+}
+void launch_final_warp(const WarpScatterArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(k_final_warp, dim3((unsigned)((a.n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
+}
+
 // ---------------------------------------------------------------------------------------
 // Slice staging: pack fr_x / fr_y, copy t, reset p, and reduce min / max / sum statistics.
 // ---------------------------------------------------------------------------------------

@@ -326,8 +326,12 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
         HIP_TRY(c, hipMalloc(&c->d_binid, (size_t)c->cap_events * sizeof(uint16_t)));
         HIP_TRY(c, hipMalloc(&c->d_armed, 64));
         HIP_TRY(c, hipMemsetAsync(c->d_armed, 0, 64, c->stream));
-        for (int i = 0; i < 2; ++i)
-            HIP_TRY(c, hipMalloc(&c->set[i].perm, (size_t)c->cap_events * sizeof(uint32_t)));
+    }
+    // (the second event set and the permutations are shared with bf_run_tiles, which may have allocated them -- and may have
+    // left the slice's events IN the second set: replacing the buffers here lost them)
+    for (int i = 0; i < 2; ++i)
+        if (!c->set[i].perm) HIP_TRY(c, hipMalloc(&c->set[i].perm, (size_t)c->cap_events * sizeof(uint32_t)));
+    if (!c->set[1].xy) {
         HIP_TRY(c, hipMalloc(&c->set[1].xy, (size_t)c->cap_events * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->set[1].t, (size_t)c->cap_events * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->set[1].p, (size_t)c->cap_events * sizeof(float2)));
@@ -411,9 +415,7 @@ int wait_event_sleeping(bf_ctx* c, hipEvent_t ev) {
 // device-to-host copy per slice, cached).
 int fold_stats(bf_ctx* c) {
     if (c->stats_valid) return BF_OK;
-    HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->d_stats, kPrepBlocks * sizeof(SliceStats), hipMemcpyDeviceToHost,
-                              c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (the records are in pinned host memory once k_prepare has completed)
     SliceStats s = c->h_stats[0];
     for (int k = 1; k < kPrepBlocks; ++k) {
         const SliceStats& q = c->h_stats[k];
@@ -533,10 +535,11 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMalloc(&c->d_state, 2 * sizeof(DevState)));
         HIP_TRY(c, hipMalloc(&c->d_ticket, 16 * 64 * sizeof(unsigned int)));   // 1 + 32 counters, 64 B apart
         HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, 16 * 64 * sizeof(unsigned int), c->stream));
-        HIP_TRY(c, hipMalloc(&c->d_stats, kPrepBlocks * sizeof(SliceStats)));
+
         HIP_TRY(c, hipHostMalloc(&c->h_state, 2 * sizeof(DevState), hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
         HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
+        c->d_stats = c->h_stats;   // k_prepare writes its per-work-group records straight into pinned host memory: no copy command
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, 2 * sizeof(DevState), c->stream));
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
@@ -584,8 +587,8 @@ void bf_destroy(bf_ctx* c) {
                     c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
-                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_ticket, c->d_state, c->d_stats,
-                    c->d_trace};
+                    c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_ticket, c->d_state,
+                    c->d_trace};   // (d_stats is h_stats: freed below)
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -1466,7 +1469,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
             if (head_update) {   // `done` of the batch's last iteration: apply its update now (normally the next launch would)
                 launch_finish_update(state_of(launched_iters), acc_of(launched_iters - 1), ovf_of(launched_iters - 1),
-                                     launched_iters, buf ^ 1, trace, c->stream);
+                                     launched_iters, buf ^ 1, trace, &c->h_state[batch & 1], c->stream);
                 inf.launches++;
             }
             ProfScope ps(c, 3);
@@ -1514,8 +1517,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;
         }
-        HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], state_of(binned ? launched_iters : 0), sizeof(DevState),
-                                  hipMemcpyDeviceToHost, c->stream));
+        if (!(warm_start && head_update))   // (there k_finish_update has written the state to the pinned copy itself)
+            HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], state_of(binned ? launched_iters : 0), sizeof(DevState),
+                                      hipMemcpyDeviceToHost, c->stream));
         // A cold run is polled one batch behind the launches, so its wait can sleep (the wake-up latency hides
         // behind the batch already queued) instead of burning a host core per slice context; a warm start waits
         // for the batch it has just launched and spins.

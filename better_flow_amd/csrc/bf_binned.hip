@@ -839,23 +839,27 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
 // The pending update outside a warp+scatter launch (a warm start's gated final warp needs `done` of the batch's last
 // iteration; nothing else does): one work-group, state updated in place.
 __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j,
-                                                            int cur_prev, bf_trace_rec* trace) {
+                                                            int cur_prev, bf_trace_rec* trace, DevState* snap) {
     __shared__ DevState s_state;
     const int tid = threadIdx.x;
     const int done = st->hot.done, it = st->hot.it;
-    if (done || it >= j) return;
     if (tid < kStateWords)
         reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(st)[tid];
-    const uint32_t ovf = *ovf_prev;
-    unsigned long long accv[kAccPerLane];
-    acc_load_wave<false, false>(acc, tid, accv);
-    const unsigned long long word = acc_reduce_wave(accv);
-    __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order: the state copy is in place)
-    model_update_wave(&s_state, word, tid, 1);
-    if (tid == 0) model_update_rest(&s_state, trace, cur_prev, ovf);
-    __builtin_amdgcn_wave_barrier();
-    if (tid < kStateWords)
-        reinterpret_cast<unsigned long long*>(st)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
+    if (!(done || it >= j)) {
+        const uint32_t ovf = *ovf_prev;
+        unsigned long long accv[kAccPerLane];
+        acc_load_wave<false, false>(acc, tid, accv);
+        const unsigned long long word = acc_reduce_wave(accv);
+        __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order: the state copy is in place)
+        model_update_wave(&s_state, word, tid, 1);
+        if (tid == 0) model_update_rest(&s_state, trace, cur_prev, ovf);
+        __builtin_amdgcn_wave_barrier();
+        if (tid < kStateWords)
+            reinterpret_cast<unsigned long long*>(st)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
+    }
+    // the state after this batch, straight to the host's pinned copy (no copy command behind the batch)
+    if (snap && tid < kStateWords)
+        reinterpret_cast<unsigned long long*>(snap)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
 }
 
 // K3 (binned): merge the slabs covering each pixel, box-sum, normalise, then the shared tail.
@@ -1165,8 +1169,8 @@ void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t pr
 }
 
 void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(k_finish_update, dim3(1), dim3(64), 0, s, st, acc, ovf_prev, j, cur_prev, trace);
+                          DevState* snap, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish_update, dim3(1), dim3(64), 0, s, st, acc, ovf_prev, j, cur_prev, trace, snap);
 }
 
 int bin_kernel_setup() {

@@ -95,7 +95,7 @@ void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
 // applies a pending update (sums in `acc`) to `st` in place: the tile-binned loop's update outside a warp+scatter launch
 void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
-                          hipStream_t s);
+                          DevState* snap, hipStream_t s);
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s);
 void launch_unpermute(const double2* src, const uint32_t* perm, double2* dst, long long n, hipStream_t s);
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,

@@ -254,10 +254,30 @@ for step in range(steps):
                             opts0, changed = trial_o, True
                             break
                 print("    reduced: options at the start", opts0)
+                try:      # the slices of the reduced case, for a stand-alone reproduction
+                    od = os.path.join(ROOT, "gpurun_out"); os.makedirs(od, exist_ok=True)
+                    np.savez(os.path.join(od, "fuzz_reuse_case_%d.npz" % step), ops=repr([h_[1] for h_ in hist]), opts=repr(opts0),
+                             **{"s%d_%s" % (q_, k_): np.asarray(v_) for q_, h_ in enumerate(hist) for k_, v_ in h_[0].items()})
+                except Exception as e_:
+                    print("    (could not save the case:", e_, ")")
                 for (sl_h, ops_h) in hist:
                     print("        slice %dx%d n=%d:" % (sl_h["H"], sl_h["W"], len(sl_h["t"])), [tuple(o_[:1]) + tuple(x for x in o_[1:4] if not isinstance(x, np.ndarray)) for o_ in ops_h])
                 break
         mimic_long = False
+        # ... and the other way round: which operations of the script does the FRESH context need to arrive at its result?
+        try:
+            keep = list(script)
+            changed = True
+            while changed:
+                changed = False
+                for q in range(1, len(keep) - 1):
+                    trial = keep[:q] + keep[q + 1:]
+                    if replay({}, [(sl, trial)]) == want:
+                        keep, changed = trial, True
+                        break
+            print("    the fresh context's result needs:", [tuple(o_[:1]) + tuple(x for x in o_[1:4] if not isinstance(x, np.ndarray)) for o_ in keep])
+        except Exception as e_:
+            print("    (second reduction failed:", e_, ")")
         print("    fresh replays equal to each other:", reps[0] == reps[1], "| equal to first fresh:", reps[0] == want, "| equal to long-lived:", reps[0] == got)
         if bad >= 3:
             break

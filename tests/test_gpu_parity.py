@@ -914,6 +914,32 @@ def test_event_lists_full_bins_and_second_pass(accel_mod):
             assert got[2].overflow_events > 0, "the lists must have overflowed"
 
 
+def test_tile_grid_first_then_a_run_on_a_fresh_context(accel_mod):
+    """bf_run_tiles as the FIRST operation after an upload on a fresh context leaves the slice's events in the second
+    event set; the window / run that follow must find them there (scripts/fuzz_reuse.py seed 99: the tile-binned set-up
+    allocated that set a second time and the run saw 2833 events at pixel (0, 0))."""
+    H, W = 180, 240
+    sl = small_slice()
+
+    def go(tiles):
+        a = accel_mod.Accel(max_events=32768, max_rows=3 * H + 3, max_cols=3 * W + 3)
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        if tiles:
+            a.run_tiles(8, 8, 3, (H, W), (H // 8, W // 8), 64, max_iter=5)
+        a.set_cloud(1, H, W)
+        tim, cnt = a.get_time_img()
+        o = a.default_opts()
+        o.res_x, o.res_y, o.max_iter, o.min_events = H, W, 3, 50
+        rc, m, info = a.run(o)
+        out = (rc, info.iterations, m.as_dict(), tim.tobytes(), cnt.tobytes())
+        a.close()
+        return out
+
+    clean, after_tiles = go(False), go(True)
+    assert clean[0] == 0 and clean[1] == 4
+    assert clean == after_tiles
+
+
 def test_moment_accumulators_are_clean_for_the_next_user(accel_mod):
     """The head-update loop consumes, but does not clear, the moment sums of its last iteration.  Whoever uses the
     accumulators next through the stencil kernel's last-work-group form -- a sparse slice on the global-atomic path,

@@ -230,15 +230,24 @@ __global__ __launch_bounds__(kBsThreads) void k_bin_scatter(EvSets sets, int has
     const int live = (int)((n - base) < kBsEvents ? (n - base) : kBsEvents);
     uint32_t rank[kBsPerThread];
     int bin[kBsPerThread];
+    // the thread's events are requested together with their bin ids (they are only staged after two barriers and the
+    // range reservation: loading them there put a second memory round trip on the work-group's chain)
+    uint32_t exy[kBsPerThread], eperm[kBsPerThread];
+    int32_t et[kBsPerThread];
+    float2 ep[kBsPerThread];
 #pragma unroll
     for (int k = 0; k < kBsPerThread; ++k) {
         const int j = k * kBsThreads + tid;
-        bin[k] = -1;
-        if (j < live) {
-            bin[k] = binid[base + j];
-            rank[k] = atomicAdd(&s_cnt[bin[k]], 1u);
-        }
+        const long long i = base + (j < live ? j : 0);
+        bin[k] = j < live ? (int)binid[i] : -1;
+        exy[k] = src.xy[i];
+        et[k] = src.t[i];
+        ep[k] = src.p[i];
+        eperm[k] = perm_in ? src.perm[i] : (uint32_t)i;
     }
+#pragma unroll
+    for (int k = 0; k < kBsPerThread; ++k)
+        if (bin[k] >= 0) rank[k] = atomicAdd(&s_cnt[bin[k]], 1u);
     __syncthreads();
     // reserve the global ranges, then turn the histogram into exclusive local offsets (block scan)
     {
@@ -277,14 +286,12 @@ __global__ __launch_bounds__(kBsThreads) void k_bin_scatter(EvSets sets, int has
     // stage: event -> LDS slot (local offset of its bin + its rank)
 #pragma unroll
     for (int k = 0; k < kBsPerThread; ++k) {
-        const int j = k * kBsThreads + tid;
         if (bin[k] >= 0) {
-            const long long i = base + j;
             const uint32_t o = s_cnt[bin[k]] + rank[k];
-            s_xy[o] = src.xy[i];
-            s_t[o] = src.t[i];
-            s_p[o] = src.p[i];
-            s_perm[o] = perm_in ? src.perm[i] : (uint32_t)i;
+            s_xy[o] = exy[k];
+            s_t[o] = et[k];
+            s_p[o] = ep[k];
+            s_perm[o] = eperm[k];
             s_bin[o] = (uint16_t)bin[k];
         }
     }

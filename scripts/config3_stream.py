@@ -6,11 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from better_flow_amd import accel, synth
-NS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+NS = int(sys.argv[1]) if len(sys.argv) > 1 and '=' not in sys.argv[1] else 10
+OPTS = [a.split('=') for a in sys.argv[1:] if '=' in a]   # key=value: bf_set_option
 N, H, W, s = 1000000, 480, 640, 3
 slices = [synth.make_slice(N, H, W, 0.030, seed=100 + i) for i in range(NS)]
 nmax = max(len(sl["t"]) for sl in slices)
 acc = accel.Accel(max_events=nmax, max_rows=s * H + s, max_cols=s * W + s)
+for k_, v_ in OPTS:
+    acc.set_option(k_, int(v_))
 opts = acc.default_opts(); opts.res_x, opts.res_y, opts.want_uv = H, W, 1
 
 def optimise(prev):

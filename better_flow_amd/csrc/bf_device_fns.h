@@ -219,9 +219,11 @@ __device__ __forceinline__ unsigned int wave_total_dpp(unsigned int v) {
 // for 1024 terms -- through the wave reduction (one instruction per step and word, against five for a 64-bit
 // integer) and as one 64-bit word through the LDS hop.  Exact: sci = sum + n base_i.
 constexpr int kSumFields = 9;
+// Two halves: every wave publishes its totals (wave reduction, one LDS hop, work-group barrier); then whoever needs the
+// work-group's total adds the partials up -- in the stencil kernels that is the first wave only, the others are done.
 template <int THREADS, bool PACK_INTS = false>
-__device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_part /* 9 * THREADS / 64 */,
-                                                  const int tid, const int base_i = 0, const int base_j = 0) {
+__device__ __forceinline__ void block_reduce_publish(const Sums& sm, unsigned long long* s_part /* 9 * THREADS / 64 */,
+                                                     const int tid, const int base_i = 0, const int base_j = 0) {
     constexpr int W = THREADS / 64;
     Sums r;
     if constexpr (PACK_INTS) {
@@ -242,21 +244,7 @@ __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long 
             s_part[8 * W + w] = (unsigned long long)__double_as_longlong(r.sjgy);
         }
         __syncthreads();
-        Sums t;
-        unsigned long long pt = 0;
-        double d_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            pt += s_part[0 * W + w];
-#pragma unroll
-            for (int f = 3; f < kSumFields; ++f) d_[f - 3] += __longlong_as_double((long long)s_part[f * W + w]);
-        }
-        const unsigned int ta = (unsigned int)(pt >> 32), tb = (unsigned int)pt;
-        t.n = (long long)(ta >> 16);
-        t.sci = (long long)tb + t.n * (long long)base_i;
-        t.scj = (long long)(ta & 0xffffu) + t.n * (long long)base_j;
-        t.sgx = d_[0]; t.sgy = d_[1]; t.sigx = d_[2]; t.sigy = d_[3]; t.sjgx = d_[4]; t.sjgy = d_[5];
-        return t;
+        return;
     }
     r.n = wave_total_dpp(sm.n); r.sci = wave_total_dpp(sm.sci); r.scj = wave_total_dpp(sm.scj);
     r.sgx = wave_total_dpp(sm.sgx); r.sgy = wave_total_dpp(sm.sgy);
@@ -275,7 +263,27 @@ __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long 
         s_part[8 * W + w] = (unsigned long long)__double_as_longlong(r.sjgy);
     }
     __syncthreads();
+}
+template <int THREADS, bool PACK_INTS = false>
+__device__ __forceinline__ Sums block_reduce_total(const unsigned long long* s_part, const int base_i = 0, const int base_j = 0) {
+    constexpr int W = THREADS / 64;
     Sums t;
+    if constexpr (PACK_INTS) {
+        unsigned long long pt = 0;
+        double d_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            pt += s_part[0 * W + w];
+#pragma unroll
+            for (int f = 3; f < kSumFields; ++f) d_[f - 3] += __longlong_as_double((long long)s_part[f * W + w]);
+        }
+        const unsigned int ta = (unsigned int)(pt >> 32), tb = (unsigned int)pt;
+        t.n = (long long)(ta >> 16);
+        t.sci = (long long)tb + t.n * (long long)base_i;
+        t.scj = (long long)(ta & 0xffffu) + t.n * (long long)base_j;
+        t.sgx = d_[0]; t.sgy = d_[1]; t.sigx = d_[2]; t.sigy = d_[3]; t.sjgx = d_[4]; t.sjgy = d_[5];
+        return t;
+    }
     long long in_[3] = {0, 0, 0};
     double d_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -288,6 +296,12 @@ __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long 
     t.n = in_[0]; t.sci = in_[1]; t.scj = in_[2];
     t.sgx = d_[0]; t.sgy = d_[1]; t.sigx = d_[2]; t.sigy = d_[3]; t.sjgx = d_[4]; t.sjgy = d_[5];
     return t;
+}
+template <int THREADS, bool PACK_INTS = false>
+__device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long long* s_part /* 9 * THREADS / 64 */,
+                                                  const int tid, const int base_i = 0, const int base_j = 0) {
+    block_reduce_publish<THREADS, PACK_INTS>(sm, s_part, tid, base_i, base_j);
+    return block_reduce_total<THREADS, PACK_INTS>(s_part, base_i, base_j);
 }
 
 // Mean time of one pixel from its exact integer sums (accel_lib.h:162,172): the f32 sum of
@@ -685,7 +699,13 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         if (a.ticket && tid < (int)(sizeof(DevState) / 8))
             reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st_rw)[tid];
         __shared__ unsigned long long s_rpart[kSumFields * (NT / 64)];
-        const Sums blk = block_reduce_sums<NT, (TR * TC <= 1024 && TR <= 64 && TC <= 64)>(sm, s_rpart, tid, r0 - hR, c0 - hC);
+        constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
+        block_reduce_publish<NT, kPack>(sm, s_rpart, tid, r0 - hR, c0 - hC);
+        // Everything below is the FIRST WAVE's: the work-group's total, the accumulator adds, the ticket and -- in the
+        // last work-group -- the update.  The other waves are done (a quarter of a tile's instructions used to be every
+        // wave adding up the same partials).  No work-group barrier from here on: one wave, in order.
+        if (tid >= 64) return;
+        const Sums blk = block_reduce_total<NT, kPack>(s_rpart, r0 - hR, c0 - hC);
         tl_stamp(a.tl, a.tl_launch, 6);
         const int nblk = gridDim.x * gridDim.y;
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
@@ -698,7 +718,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             // and the overflow counter of the next iteration are cleared here for their next use.
             if (me == 0) {
                 if (a.acc_zero)
-                    for (int i = tid; i < kAccGroups * 16; i += NT) (&a.acc_zero[0].f[0])[i] = 0ull;
+                    for (int i = tid; i < kAccGroups * 16; i += 64) (&a.acc_zero[0].f[0])[i] = 0ull;
                 if (a.ovf_next && tid == 0) *a.ovf_next = 0u;
             }
             return;
@@ -706,43 +726,37 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         // Fused reduction + update: the LAST work-group to arrive reads the accumulators and runs the model / loop
         // update -- no separate kernel.  Hand-off (cdna_hip_programming.md, Guideline 16): the atomics are drained
         // with s_waitcnt vmcnt(0), then a relaxed agent-scope ticket; the reader uses agent-scope (L1-bypassing) loads.
-        __shared__ int s_last;
-        if (tid < 64) {   // (the first wave issued the atomics)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) {
-                // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
-                // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
-                // lines and only the last arriver of each group takes the top-level ticket.
-                const int grp = me % kTicketGroups;
-                const int grp_size = nblk / kTicketGroups + (grp < nblk % kTicketGroups ? 1 : 0);
-                const int n_groups = nblk < kTicketGroups ? nblk : kTicketGroups;
-                int last = 0;
-                const unsigned int t1 = __hip_atomic_fetch_add(&a.ticket[16 * (1 + grp)], 1u, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                if (t1 == (unsigned int)(grp_size - 1)) {
-                    a.ticket[16 * (1 + grp)] = 0;   // re-armed for the next launch
-                    const unsigned int t0 =
-                        __hip_atomic_fetch_add(&a.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    last = (t0 == (unsigned int)(n_groups - 1)) ? 1 : 0;
-                }
-                s_last = last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        if (tid == 0) {
+            // Two-level ticket: one word serialises at ~11 ns per atomic (833 work-groups would
+            // cost ~9 us), so arrivals are spread over kTicketGroups words on different cache
+            // lines and only the last arriver of each group takes the top-level ticket.
+            const int grp = me % kTicketGroups;
+            const int grp_size = nblk / kTicketGroups + (grp < nblk % kTicketGroups ? 1 : 0);
+            const int n_groups = nblk < kTicketGroups ? nblk : kTicketGroups;
+            const unsigned int t1 = __hip_atomic_fetch_add(&a.ticket[16 * (1 + grp)], 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            if (t1 == (unsigned int)(grp_size - 1)) {
+                a.ticket[16 * (1 + grp)] = 0;   // re-armed for the next launch
+                const unsigned int t0 =
+                    __hip_atomic_fetch_add(&a.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (t0 == (unsigned int)(n_groups - 1)) ? 1 : 0;
             }
         }
-        __syncthreads();
+        last = __builtin_amdgcn_readfirstlane(last);   // (lane 0's verdict, for the whole wave)
         tl_stamp(a.tl, a.tl_launch, 7);
-        if (!s_last) return;
-        if (tid < 64) {   // one wave forms the total and updates (no further barrier)
-            unsigned long long accv[kAccPerLane];
-            acc_load_wave<true, true>(a.acc, tid, accv);
-            const unsigned long long word = acc_reduce_wave(accv);
-            model_update_wave(&s_state, word, tid, a.update_mode);
-            if (tid == 0) {
-                a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
-                if (a.update_mode != 0) model_update_rest(&s_state, a.trace, a.cur, a.ovf_cur ? *a.ovf_cur : 0u);
-                if (a.ovf_next) *a.ovf_next = 0u;   // (tile-binned loop: the next iteration's overflow counter)
-            }
+        if (!last) return;
+        unsigned long long accv[kAccPerLane];
+        acc_load_wave<true, true>(a.acc, tid, accv);
+        const unsigned long long word = acc_reduce_wave(accv);
+        model_update_wave(&s_state, word, tid, a.update_mode);
+        if (tid == 0) {
+            a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
+            if (a.update_mode != 0) model_update_rest(&s_state, a.trace, a.cur, a.ovf_cur ? *a.ovf_cur : 0u);
+            if (a.ovf_next) *a.ovf_next = 0u;   // (tile-binned loop: the next iteration's overflow counter)
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order)
         if (tid < (int)(sizeof(DevState) / 8))
             reinterpret_cast<unsigned long long*>(a.st_rw)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
     }

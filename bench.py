@@ -108,7 +108,7 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         merged = farm.run_farm(specs, rank=rank, world=world, device=device, concurrent=max(1, args.concurrent), scale=s,
-                               dist=dist)
+                               dist=dist, options={k_: int(v_) for k_, v_ in (o_.split("=") for o_ in args.opt)})
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0

@@ -1,6 +1,10 @@
-// datastructures.h -- containers feeding the motion-compensation path (mirror of the
-// reference's better_flow/datastructures.h:6-259; the per-pixel EventCloudTemplate, :263-393,
-// is unreferenced there and not provided).
+// datastructures.h -- the containers that hand events to the motion-compensation path.
+//
+// Same class names, template parameters and member functions as the reference's
+// better_flow/datastructures.h (CircularArray :6-115, LinearEventCloudTemplate :119-168,
+// LinearEventPtrsTemplate :172-259), because DVS_flow, the optimizers and user code are written
+// against them; the implementation is this build's.  The per-pixel EventCloudTemplate (:263-393)
+// has no caller in the reference and is not provided.
 #ifndef BF_HOST_DATASTRUCTURES_H
 #define BF_HOST_DATASTRUCTURES_H
 
@@ -9,111 +13,146 @@
 #include <cstddef>
 #include <vector>
 
-// Ring of at most SZ elements spanning at most SPAN (ns) of time, iterated newest -> oldest
-// (datastructures.h:6-115).  Faithful quirk: once the ring is full, end() stops one element
-// short, so iteration visits SZ - 1 elements (:71-76).
+// A time-windowed ring: holds the most recent events, at most SZ of them and none older than SPAN
+// (in the units of `DType - DType`, ns) behind the newest.  Walks newest -> oldest.
+//
+// Behaviour callers depend on, all taken from the reference and pinned by tests/cpp/test_ring.cpp:
+//   * the first element lands in slot 1, not 0 (the cursor is advanced before the store);
+//   * trimming by SPAN is lazy: push_back only marks the ring stale, the next size() / begin() /
+//     end() drops what is too old;
+//   * a FULL ring reports size() == SZ but begin()..end() visits SZ - 1 elements: end() then names
+//     the oldest slot itself instead of the slot behind it (datastructures.h:71-76).
 template <class DType, size_t SZ, long long SPAN> class CircularArray final {
+    typedef long long slot_t;
+    static slot_t wrap(slot_t s) { s %= slot_t(SZ); return s < 0 ? s + slot_t(SZ) : s; }
+
 protected:
-    std::vector<DType> data;
-    size_t current_size, head_id;
-    bool span_checked;
-    size_t latest_id;
+    std::vector<DType> store;
+    size_t held;      // elements currently in the window
+    size_t cursor;    // slot of the newest element
+    bool stale;       // a push happened since the window was last trimmed
+
+    // slot `back` places behind the newest
+    size_t slot_behind(slot_t back) const { return size_t(wrap(slot_t(cursor) - back)); }
+
+    void trim() {
+        if (!stale) return;
+        stale = false;
+        size_t oldest = slot_behind(slot_t(held) - 1);
+        size_t dropped = 0;
+        // the newest element is 0 away from itself, so this stops at the latest there
+        while ((long long)(store[cursor] - store[oldest]) > SPAN) {
+            oldest = (oldest + 1 == SZ) ? 0 : oldest + 1;
+            ++dropped;
+        }
+        held -= dropped;
+    }
 
 public:
     typedef DType value_type;
 
-    CircularArray() : data(SZ), current_size(0), head_id(0), span_checked(true), latest_id(0) {}
+    CircularArray() : store(SZ), held(0), cursor(0), stale(false) {}
 
-    inline size_t size() {
-        this->fix_span();
-        return this->current_size;
+    void push_back(DType &d) {
+        cursor = (cursor + 1 == SZ) ? 0 : cursor + 1;
+        store[cursor] = d;
+        if (held < SZ) ++held;
+        stale = true;
     }
 
-    inline void push_back(DType &d) {   // :31-44
-        this->span_checked = false;
-        this->current_size += (this->current_size >= SZ) ? 0 : 1;
-        this->head_id++;
-        if (this->head_id >= SZ) this->head_id = 0;
-        this->data[this->head_id] = d;
-        this->latest_id = this->head_id;
+    void fix_span() { trim(); }
+
+    size_t size() {
+        trim();
+        return held;
     }
 
-    inline void fix_span() {   // :46-59
-        if (this->span_checked) return;
-        this->span_checked = true;
-        size_t tail_id = ((1 - int(this->current_size - this->head_id)) + SZ) % SZ;
-        size_t removed_cnt = 0;
-        while ((long long)(this->data[this->latest_id] - this->data[tail_id]) > SPAN) {
-            removed_cnt++;
-            tail_id++;
-            if (tail_id >= SZ) tail_id = 0;
-        }
-        this->current_size -= removed_cnt;
-    }
-
-    inline DType &operator[](size_t idx) {   // :61-64, idx 0 = newest
-        assert(idx < this->current_size);
-        return this->data[((int(this->head_id) - int(idx)) + SZ) % SZ];
+    // idx 0 is the newest element, size() - 1 the oldest
+    DType &operator[](size_t idx) {
+        assert(idx < held);
+        return store[slot_behind(slot_t(idx))];
     }
 
     class iterator {
         friend class CircularArray;
-        CircularArray *ca;
-        size_t id;
-        iterator(CircularArray *c, size_t i) : ca(c), id(i) {}
+        CircularArray *ring;
+        size_t at;
+        iterator(CircularArray *r, size_t slot) : ring(r), at(slot) {}
 
     public:
-        DType &operator*() { return ca->data[id]; }
-        DType *operator->() { return &ca->data[id]; }
-        iterator &operator++() {   // newest -> oldest, :86-96
-            id = (id == 0) ? SZ - 1 : id - 1;
+        DType &operator*() { return ring->store[at]; }
+        DType *operator->() { return &ring->store[at]; }
+        iterator &operator++() {   // one step into the past
+            at = at ? at - 1 : SZ - 1;
             return *this;
         }
-        bool operator!=(const iterator &o) const { return id != o.id; }
-        bool operator==(const iterator &o) const { return id == o.id; }
+        bool operator==(const iterator &o) const { return at == o.at; }
+        bool operator!=(const iterator &o) const { return at != o.at; }
     };
 
-    inline iterator begin() {   // :66-69
-        this->fix_span();
-        return iterator(this, this->head_id);
+    iterator begin() {
+        trim();
+        return iterator(this, cursor);
     }
 
-    inline iterator end() {   // :71-76
-        this->fix_span();
-        int shift = (this->current_size >= SZ) ? 1 : 0;
-        size_t tail_id = ((shift - int(this->current_size - this->head_id)) + SZ) % SZ;
-        return iterator(this, tail_id);
+    iterator end() {
+        trim();
+        // one slot past the oldest -- except for a full ring, where that slot is the newest again
+        // and the reference stops ON the oldest instead (the oldest element is never visited)
+        const slot_t back = (held >= SZ) ? slot_t(held) - 1 : slot_t(held);
+        return iterator(this, slot_behind(back));
     }
 };
 
-// A simple linear event cloud with a bounding box (datastructures.h:119-168).
+namespace bf_detail {
+// Bounding box of the sensor addresses pushed so far; x = row, y = column.
+struct AddressBox {
+    int &x_min, &y_min, &x_max, &y_max;
+    void take(int x, int y) {
+        x_min = x < x_min ? x : x_min;
+        x_max = x > x_max ? x : x_max;
+        y_min = y < y_min ? y : y_min;
+        y_max = y > y_max ? y : y_max;
+    }
+};
+}  // namespace bf_detail
+
+// Events by value, in insertion order, with the bounding box of their addresses kept up to date.
 template <class DType> class LinearEventCloudTemplate {
 protected:
     std::vector<DType> data;
 
 public:
-    int x_min, y_min, x_max, y_max;
+    int x_min, y_min, x_max, y_max;   // empty cloud: min = INT_MAX, max = INT_MIN
 
     LinearEventCloudTemplate() : x_min(INT_MAX), y_min(INT_MAX), x_max(INT_MIN), y_max(INT_MIN) {}
 
-    inline void push_back(DType d) {
-        if ((int)d.get_x() > this->x_max) this->x_max = d.get_x();
-        if ((int)d.get_y() > this->y_max) this->y_max = d.get_y();
-        if ((int)d.get_x() < this->x_min) this->x_min = d.get_x();
-        if ((int)d.get_y() < this->y_min) this->y_min = d.get_y();
-        this->data.push_back(d);
+    explicit LinearEventCloudTemplate(std::vector<DType> &src) : LinearEventCloudTemplate() {
+        data.reserve(src.size());
+        for (auto &d : src) push_back(d);
     }
-    inline DType &operator[](size_t idx) {
-        assert(idx < this->size());
-        return this->data[idx];
+
+    explicit LinearEventCloudTemplate(std::vector<LinearEventCloudTemplate<DType>> &parts)
+        : LinearEventCloudTemplate() {
+        for (auto &part : parts)
+            for (auto &d : part) push_back(d);
     }
-    inline size_t size() { return this->data.size(); }
-    inline auto begin() { return this->data.begin(); }
-    inline auto end() { return this->data.end(); }
-    inline void reserve(size_t n) { this->data.reserve(n); }
+
+    void push_back(DType d) {
+        bf_detail::AddressBox{x_min, y_min, x_max, y_max}.take(int(d.get_x()), int(d.get_y()));
+        data.push_back(d);
+    }
+    DType &operator[](size_t idx) {
+        assert(idx < data.size());
+        return data[idx];
+    }
+    size_t size() { return data.size(); }
+    void reserve(size_t n) { data.reserve(n); }
+    typename std::vector<DType>::iterator begin() { return data.begin(); }
+    typename std::vector<DType>::iterator end() { return data.end(); }
 };
 
-// Same interface, storing pointers (datastructures.h:172-259).
+// The same interface over events owned elsewhere (the slice views DVS_flow builds over its ring).
 template <class DType> class LinearEventPtrsTemplate {
 protected:
     std::vector<DType *> data;
@@ -123,37 +162,53 @@ public:
 
     LinearEventPtrsTemplate() : x_min(INT_MAX), y_min(INT_MAX), x_max(INT_MIN), y_max(INT_MIN) {}
 
-    inline void push_back(DType *d) {
-        if ((int)d->get_x() > this->x_max) this->x_max = d->get_x();
-        if ((int)d->get_y() > this->y_max) this->y_max = d->get_y();
-        if ((int)d->get_x() < this->x_min) this->x_min = d->get_x();
-        if ((int)d->get_y() < this->y_min) this->y_min = d->get_y();
-        this->data.push_back(d);
+    explicit LinearEventPtrsTemplate(std::vector<DType> &src) : LinearEventPtrsTemplate() {
+        data.reserve(src.size());
+        for (auto &d : src) push_back(&d);
     }
-    inline void push_back(DType &d) { this->push_back(&d); }
-    inline DType &operator[](size_t idx) {
-        assert(idx < this->size());
-        return *(this->data[idx]);
-    }
-    inline size_t size() { return this->data.size(); }
-    inline void reserve(size_t n) { this->data.reserve(n); }
 
+    explicit LinearEventPtrsTemplate(std::vector<LinearEventCloudTemplate<DType>> &parts)
+        : LinearEventPtrsTemplate() {
+        for (auto &part : parts)
+            for (auto &d : part) push_back(&d);
+    }
+
+    explicit LinearEventPtrsTemplate(std::vector<LinearEventPtrsTemplate<DType>> &parts)
+        : LinearEventPtrsTemplate() {
+        for (auto &part : parts)
+            for (auto &d : part) push_back(&d);
+    }
+
+    void push_back(DType *d) {
+        bf_detail::AddressBox{x_min, y_min, x_max, y_max}.take(int(d->get_x()), int(d->get_y()));
+        data.push_back(d);
+    }
+    void push_back(DType &d) { push_back(&d); }
+
+    DType &operator[](size_t idx) {
+        assert(idx < data.size());
+        return *data[idx];
+    }
+    size_t size() { return data.size(); }
+    void reserve(size_t n) { data.reserve(n); }
+
+    // dereferences twice, so range-for yields DType& as with the by-value cloud
     class iterator {
-        typename std::vector<DType *>::iterator it;
+        typename std::vector<DType *>::iterator pos;
 
     public:
-        explicit iterator(typename std::vector<DType *>::iterator i) : it(i) {}
-        DType &operator*() { return **it; }
-        DType *operator->() { return *it; }
+        explicit iterator(typename std::vector<DType *>::iterator p) : pos(p) {}
+        DType &operator*() { return **pos; }
+        DType *operator->() { return *pos; }
         iterator &operator++() {
-            ++it;
+            ++pos;
             return *this;
         }
-        bool operator!=(const iterator &o) const { return it != o.it; }
-        bool operator==(const iterator &o) const { return it == o.it; }
+        bool operator==(const iterator &o) const { return pos == o.pos; }
+        bool operator!=(const iterator &o) const { return pos != o.pos; }
     };
-    inline iterator begin() { return iterator(this->data.begin()); }
-    inline iterator end() { return iterator(this->data.end()); }
+    iterator begin() { return iterator(data.begin()); }
+    iterator end() { return iterator(data.end()); }
 };
 
 #endif  // BF_HOST_DATASTRUCTURES_H

@@ -112,7 +112,8 @@ EXPORTS = [
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
     "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
-    "bf_upload_ring_async", "bf_wait_uploads", "bf_projection_img", "bf_color_time_img",
+    "bf_upload_ring_async", "bf_upload_ring16_async", "bf_compute_uv_ring", "bf_wait_uploads", "bf_projection_img",
+    "bf_color_time_img",
 ]
 
 _lib = None
@@ -151,8 +152,10 @@ def load():
         L.bf_local_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(LocalState)]
         L.bf_projection_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.bf_color_time_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
-        L.bf_upload_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                                           C.c_uint64]
+        L.bf_upload_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                           C.c_int64, C.c_uint64]
+        L.bf_upload_ring16_async.argtypes = L.bf_upload_ring_async.argtypes
+        L.bf_compute_uv_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         L.bf_wait_uploads.argtypes = [C.c_void_p]
         L.bf_project_4param_reinit.argtypes = [C.c_void_p] + [C.c_double] * 6
         L.bf_get_time_img.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -379,13 +382,22 @@ class Accel:
         self._chk(self.L.bf_upload_events_async(self.h, _ptr(fr_x), _ptr(fr_y), _ptr(t_ns), int(n)))
         self._pending_n = getattr(self, "_pending_n", []) + [int(n)]
 
-    def upload_ring_async(self, ring_x, ring_y, ring_ts, first, n, t0):
-        """Slice = n events from ring index `first` (wrapping) of int32 / int32 / uint64 ring arrays (pinned for a
-        true DMA; pageable arrays work too); times become ts - t0 on the device (bf_upload_ring_async)."""
-        assert ring_x.dtype == np.int32 and ring_y.dtype == np.int32 and ring_ts.dtype == np.uint64
-        self._chk(self.L.bf_upload_ring_async(self.h, _ptr(ring_x), _ptr(ring_y), _ptr(ring_ts), int(len(ring_ts)),
-                                              int(first), int(n), int(t0)))
+    def upload_ring_async(self, ring_x, ring_y, ring_ts, first, n, t0, ring_noise=None):
+        """Slice = n events from ring index `first` (wrapping) of row / column / uint64 timestamp ring arrays (pinned for
+        a true DMA; pageable arrays work too); times become ts - t0 on the device.  int32 addresses go through
+        bf_upload_ring_async, uint16 addresses through bf_upload_ring16_async; ring_noise: optional uint8 Event::noise ring."""
+        assert ring_x.dtype == ring_y.dtype and ring_x.dtype in (np.int32, np.uint16) and ring_ts.dtype == np.uint64
+        assert ring_noise is None or ring_noise.dtype == np.uint8
+        fn = self.L.bf_upload_ring_async if ring_x.dtype == np.int32 else self.L.bf_upload_ring16_async
+        self._chk(fn(self.h, _ptr(ring_x), _ptr(ring_y), _ptr(ring_ts), None if ring_noise is None else _ptr(ring_noise),
+                     int(len(ring_ts)), int(first), int(n), int(t0)))
         self._pending_n = getattr(self, "_pending_n", []) + [int(n)]
+
+    def compute_uv_ring(self, uv_ring, first):
+        """Per-event (u, v) of the current slice as interleaved pairs into uv_ring (float64, 2 * cap), event i at ring
+        index (first + i) % cap (bf_compute_uv_ring)."""
+        assert uv_ring.dtype == np.float64 and uv_ring.size % 2 == 0
+        self._chk(self.L.bf_compute_uv_ring(self.h, _ptr(uv_ring), int(uv_ring.size // 2), int(first)))
 
     def commit_upload(self):
         self._chk(self.L.bf_commit_upload(self.h))

@@ -85,6 +85,10 @@ struct bf_ctx {
     bool staged_valid[2] = {false, false};
     long long pending_n[2] = {0, 0};
     bool pending_ts64[2] = {false, false};       // slot holds absolute 64-bit timestamps (ring hand-off)
+    bool pending_addr16[2] = {false, false};     // ... and 16-bit addresses in d_in16 (bf_upload_ring16_async)
+    bool pending_noise[2] = {false, false};      // ... and Event::noise flags in d_in_noise
+    uint16_t* d_in16[2] = {nullptr, nullptr};    // row[cap_events] then col[cap_events]
+    uint8_t* d_in_noise[2] = {nullptr, nullptr};
     unsigned long long pending_t0[2] = {0, 0};
     unsigned long long* d_in_ts[2] = {nullptr, nullptr};
     int pend_head = 0, pend_count = 0;   // FIFO of pending async uploads (slot = index & 1)
@@ -122,6 +126,7 @@ struct bf_ctx {
     DevState* h_state = nullptr;     // pinned, D2H target only: 2 slots (pipelined polling)
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     bool opt_blocking_poll = true;
+    double opt_watchdog_s = 40.0;    // a cold run whose device iteration counter stands still this long is declared hung
     SliceStats* h_stats = nullptr;   // pinned, D2H target only
 
     DevState hst;                    // authoritative host mirror outside bf_run
@@ -449,6 +454,54 @@ int after_upload(bf_ctx* c, long long n) {
 
 }  // namespace
 
+// The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays ring in pinned
+// memory: up to two contiguous pieces per array, no repacking on the host.  ADDR is int32_t (bf_upload_ring_async) or
+// uint16_t (bf_upload_ring16_async: the addresses travel as 16-bit values and are widened by the staging kernel).
+template <class ADDR>
+static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const uint64_t* ring_ts, const uint8_t* ring_noise,
+                       int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    if (!c) return BF_ERR_ARG;
+    if (n <= 0 || cap <= 0 || first < 0 || first >= cap || n > cap || !ring_x || !ring_y || !ring_ts)
+        return fail(c, BF_ERR_ARG, "bad ring slice (cap %lld, first %lld, n %lld)", (long long)cap, (long long)first, (long long)n);
+    if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
+    if (c->pend_count >= 2) return fail(c, BF_ERR_STATE, "two uploads are already pending");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    }
+    const int slot = (c->pend_head + c->pend_count) & 1;
+    if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
+    if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
+    const bool narrow = sizeof(ADDR) == 2;
+    if (narrow && !c->d_in16[slot]) HIP_TRY(c, hipMalloc(&c->d_in16[slot], (size_t)c->cap_events * 2 * sizeof(uint16_t)));
+    if (ring_noise && !c->d_in_noise[slot]) HIP_TRY(c, hipMalloc(&c->d_in_noise[slot], (size_t)c->cap_events));
+    // destinations of the two address columns: the slot's int32 staging arrays, or (16-bit form) two halves of d_in16
+    ADDR* dx = narrow ? reinterpret_cast<ADDR*>(c->d_in16[slot]) : reinterpret_cast<ADDR*>(slot ? c->d_in2[0] : c->d_in_x);
+    ADDR* dy = narrow ? reinterpret_cast<ADDR*>(c->d_in16[slot] + c->cap_events) : reinterpret_cast<ADDR*>(slot ? c->d_in2[1] : c->d_in_y);
+    const int64_t n0 = (first + n <= cap) ? n : cap - first, n1 = n - n0;   // [first, first + n0) then [0, n1)
+    HIP_TRY(c, hipMemcpyAsync(dx, ring_x + first, (size_t)n0 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(dy, ring_y + first, (size_t)n0 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot], ring_ts + first, (size_t)n0 * 8, hipMemcpyHostToDevice, c->copy_stream));
+    if (ring_noise) HIP_TRY(c, hipMemcpyAsync(c->d_in_noise[slot], ring_noise + first, (size_t)n0, hipMemcpyHostToDevice, c->copy_stream));
+    if (n1 > 0) {
+        HIP_TRY(c, hipMemcpyAsync(dx + n0, ring_x, (size_t)n1 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(dy + n0, ring_y, (size_t)n1 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot] + n0, ring_ts, (size_t)n1 * 8, hipMemcpyHostToDevice, c->copy_stream));
+        if (ring_noise) HIP_TRY(c, hipMemcpyAsync(c->d_in_noise[slot] + n0, ring_noise, (size_t)n1, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
+    c->pending_n[slot] = n;
+    c->pending_ts64[slot] = true;
+    c->pending_addr16[slot] = narrow;
+    c->pending_noise[slot] = ring_noise != nullptr;
+    c->pending_t0[slot] = t0;
+    c->pend_count++;
+    return BF_OK;
+}
+
 extern "C" {
 
 const char* bf_version(void) { return "bf_accel gfx950 r1"; }
@@ -582,6 +635,8 @@ void bf_destroy(bf_ctx* c) {
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
+    for (int i = 0; i < 2; ++i) if (c->d_in16[i]) (void)hipFree(c->d_in16[i]);
+    for (int i = 0; i < 2; ++i) if (c->d_in_noise[i]) (void)hipFree(c->d_in_noise[i]);
     void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
@@ -628,6 +683,11 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     }
     if (!strcmp(key, "blocking_poll")) {
         c->opt_blocking_poll = value != 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "watchdog_ms")) {
+        if (value < 1) return fail(c, BF_ERR_ARG, "watchdog_ms must be >= 1");
+        c->opt_watchdog_s = (double)value * 1e-3;
         return BF_OK;
     }
     if (!strcmp(key, "bin_tile_rows")) {
@@ -764,42 +824,14 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
     return BF_OK;
 }
 
-// The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays ring in pinned
-// memory: up to two contiguous pieces per array, no repacking on the host.
-int bf_upload_ring_async(bf_ctx* c, const int32_t* ring_x, const int32_t* ring_y, const uint64_t* ring_ts, int64_t cap,
-                         int64_t first, int64_t n, uint64_t t0) {
-    if (!c) return BF_ERR_ARG;
-    if (n <= 0 || cap <= 0 || first < 0 || first >= cap || n > cap || !ring_x || !ring_y || !ring_ts)
-        return fail(c, BF_ERR_ARG, "bad ring slice (cap %lld, first %lld, n %lld)", (long long)cap, (long long)first, (long long)n);
-    if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
-    if (c->pend_count >= 2) return fail(c, BF_ERR_STATE, "two uploads are already pending");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->copy_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
-        for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
-    }
-    const int slot = (c->pend_head + c->pend_count) & 1;
-    if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
-    if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
-    int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
-    int32_t* dy = slot ? c->d_in2[1] : c->d_in_y;
-    const int64_t n0 = (first + n <= cap) ? n : cap - first, n1 = n - n0;   // [first, first + n0) then [0, n1)
-    HIP_TRY(c, hipMemcpyAsync(dx, ring_x + first, (size_t)n0 * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(dy, ring_y + first, (size_t)n0 * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot], ring_ts + first, (size_t)n0 * 8, hipMemcpyHostToDevice, c->copy_stream));
-    if (n1 > 0) {
-        HIP_TRY(c, hipMemcpyAsync(dx + n0, ring_x, (size_t)n1 * 4, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(c, hipMemcpyAsync(dy + n0, ring_y, (size_t)n1 * 4, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot] + n0, ring_ts, (size_t)n1 * 8, hipMemcpyHostToDevice, c->copy_stream));
-    }
-    HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
-    c->pending_n[slot] = n;
-    c->pending_ts64[slot] = true;
-    c->pending_t0[slot] = t0;
-    c->pend_count++;
-    return BF_OK;
+int bf_upload_ring_async(bf_ctx* c, const int32_t* ring_x, const int32_t* ring_y, const uint64_t* ring_ts, const uint8_t* ring_noise,
+                         int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    return upload_ring<int32_t>(c, ring_x, ring_y, ring_ts, ring_noise, cap, first, n, t0);
+}
+
+int bf_upload_ring16_async(bf_ctx* c, const uint16_t* ring_row, const uint16_t* ring_col, const uint64_t* ring_ts,
+                           const uint8_t* ring_noise, int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    return upload_ring<uint16_t>(c, ring_row, ring_col, ring_ts, ring_noise, cap, first, n, t0);
 }
 
 int bf_wait_uploads(bf_ctx* c) {
@@ -817,8 +849,21 @@ int bf_commit_upload(bf_ctx* c) {
     // the staging kernel (compute stream) waits for the copy; nothing blocks on the host
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[slot], 0));
     c->has_noise = false;
-    if (c->pending_ts64[slot])   // absolute timestamps -> slice-local 32-bit times (Event::set_local_time)
-        launch_local_time(c->d_in_ts[slot], c->pending_t0[slot], slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot], c->stream);
+    if (c->pending_ts64[slot]) {   // absolute timestamps -> slice-local 32-bit times (Event::set_local_time)
+        if (c->pending_addr16[slot])   // ... and 16-bit addresses -> the staging kernel's int32 columns, same pass
+            launch_local_time16(c->d_in_ts[slot], c->d_in16[slot], c->d_in16[slot] + c->cap_events, c->pending_t0[slot],
+                                slot ? c->d_in2[0] : c->d_in_x, slot ? c->d_in2[1] : c->d_in_y, slot ? c->d_in2[2] : c->d_in_t,
+                                c->pending_n[slot], c->stream);
+        else
+            launch_local_time(c->d_in_ts[slot], c->pending_t0[slot], slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot], c->stream);
+        if (c->pending_noise[slot]) {   // Event::noise of the slice (padding: not noise, like the blocking upload's)
+            const long long gran = (long long)kThreads * kEvPerThread;
+            const long long n_pad = (c->pending_n[slot] + gran - 1) / gran * gran;
+            HIP_TRY(c, hipMemsetAsync(c->d_noise, 0, (size_t)n_pad, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_noise, c->d_in_noise[slot], (size_t)c->pending_n[slot], hipMemcpyDeviceToDevice, c->stream));
+            c->has_noise = true;
+        }
+    }
     int rc = stage_common(c, slot ? c->d_in2[0] : c->d_in_x, slot ? c->d_in2[1] : c->d_in_y,
                           slot ? c->d_in2[2] : c->d_in_t, c->pending_n[slot]);
     // the slot may be refilled once the staging kernels above have read it
@@ -1258,6 +1303,36 @@ int bf_compute_uv(bf_ctx* c, double* u, double* v) {
     return copy_pairs(c, c->d_uv, u, v);
 }
 
+int bf_compute_uv_ring(bf_ctx* c, double* uv_ring, int64_t cap, int64_t first) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_compute_uv_ring before bf_set_cloud");
+    if (c->degenerate) return fail(c, BF_ERR_STATE, "bf_compute_uv_ring on a degenerate (empty) window");
+    if (!uv_ring || cap <= 0 || first < 0 || first >= cap || c->n > cap)
+        return fail(c, BF_ERR_ARG, "bad flow ring (cap %lld, first %lld, n %lld)", (long long)cap, (long long)first, c->n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != BF_OK) return rc;
+    if (c->n == 0) return BF_OK;
+    const int64_t n0 = (first + c->n <= cap) ? c->n : cap - first, n1 = c->n - n0;
+    if (!c->n_valid) {   // Event::reset state: no flow yet
+        memset(uv_ring + 2 * first, 0, (size_t)n0 * 16);
+        memset(uv_ring, 0, (size_t)n1 * 16);
+        return BF_OK;
+    }
+    rc = materialize_outputs(c);
+    if (rc != BF_OK) return rc;
+    if (!c->uv_valid) {
+        ProfScope ps(c, 3);
+        launch_compute_uv(c->d_nxny, c->d_uv, c->n, c->stream);
+        c->uv_valid = true;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(uv_ring + 2 * first, c->d_uv, (size_t)n0 * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    if (n1 > 0) HIP_TRY(c, hipMemcpyAsync(uv_ring, c->d_uv + n0, (size_t)n1 * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
 // ---- fused optimizer ---------------------------------------------------------------------
 
 int bf_set_model(bf_ctx* c, const bf_model* model) {
@@ -1428,7 +1503,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.cur = buf; ba.j = j;
                 ba.tl = c->d_tl ? c->d_tl + 64 * 2 * 16 : nullptr;
                 ProfScope ps(c, 0, c->n);
-                launch_bin_warp_scatter(ba, warp, bin_threads, ev_per_thread, c->stream);
+                HIP_TRY(c, launch_bin_warp_scatter(ba, warp, bin_threads, ev_per_thread, c->stream));
             } else {
                 ProfScope ps(c, 0, c->n);
                 launch_warp_scatter(ws_args(c, buf, 1), warp, true, false, c->stream);
@@ -1493,7 +1568,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             bool done_seen = false;
             int gpu_it = 0;
             if (host_timing) { const double t = ht_now(); ht_launch += t - ht_mark; ht_mark = t; }
-            for (long spins = 0;; ++spins) {
+            // Invariant of this mode: the snapshot's `done` word is 0 while the loop runs and takes this run's tag --
+            // nothing else -- when it ends (a straggler launch of an earlier run can only leave an older tag, which is
+            // read as "not started yet": `it` 0).  The watchdog is a wall-clock deadline since the last PROGRESS of
+            // the device's iteration counter, not a count of looks: a spinning poll (blocking_poll = 0) takes a few
+            // nanoseconds per look, and one batch can legitimately take long (large poll_interval, 1280x720
+            // iterations, several contexts sharing the GPU, a first launch loading code objects).
+            auto wd_clock = [] { return std::chrono::steady_clock::now(); };
+            auto wd_mark = wd_clock();
+            int wd_it = -1;
+            for (unsigned spins = 0;; ++spins) {
                 const unsigned long long w0 = *w0p;
                 const int32_t sdone = (int32_t)(uint32_t)(w0 & 0xffffffffull), sit = (int32_t)(uint32_t)(w0 >> 32);
                 if (sdone == h.run_tag) { done_seen = true; break; }
@@ -1503,7 +1587,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                     struct timespec ts = {0, 20000};
                     nanosleep(&ts, nullptr);
                 }
-                if (spins > 2000000) {   // > 40 s without progress
+                if (gpu_it != wd_it) { wd_it = gpu_it; wd_mark = wd_clock(); }
+                else if ((spins & 1023u) == 0 &&
+                         std::chrono::duration<double>(wd_clock() - wd_mark).count() > c->opt_watchdog_s) {
                     const hipError_t e = hipStreamQuery(c->stream);
                     if (e != hipSuccess && e != hipErrorNotReady) HIP_TRY(c, e);
                     return fail(c, BF_ERR_HIP, "device loop makes no progress");

@@ -19,6 +19,7 @@
 //
 // All accumulators are integers (count << tbits | sum(t - tmin)), so the result is exactly
 // the reference's s x s splat (accel_lib.h:147-166) whatever the event order.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <limits.h>
@@ -1120,40 +1121,51 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 }
 
 template <int THREADS, int U, int FMT>
-static void launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
+static hipError_t launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
     // dynamic LDS: the bin's tile (dense slabs, merged lists: + one 16-bit index slot per pixel); event lists: none
     const size_t lds = FMT == 2 ? 0 : (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (FMT == 1 ? sizeof(uint16_t) : 0)) + 16;
-    static bool raised = false;   // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950)
-    if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
-        raised = true;
+    // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950).  The attribute belongs to
+    // the (function, device) pair, so it is raised once per device the instantiation is launched on: a bit per device
+    // ordinal, set after the calls succeeded (two threads racing here both make the calls, which is harmless).
+    static std::atomic<unsigned long long> raised{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const unsigned long long dev_bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_acquire) & dev_bit)) {
+        const void* fns[4] = {reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, FMT>),
+                              reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, FMT>),
+                              reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, FMT>),
+                              reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, FMT>)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
+            if (e != hipSuccess) return e;
+        }
+        raised.fetch_or(dev_bit, std::memory_order_release);
     }
     if (!a.acc) {   // nothing to update at the head
         if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
         else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-        return;
+        return hipSuccess;
     }
     if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
     else launch_timed(k_bin_warp_scatter<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    return hipSuccess;
 }
 template <int THREADS, int U>
-static void launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    if (a.compact >= 2) launch_bws2<THREADS, U, 2>(a, warp, s);
-    else if (a.compact == 1) launch_bws2<THREADS, U, 1>(a, warp, s);
-    else launch_bws2<THREADS, U, 0>(a, warp, s);
+static hipError_t launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
+    if (a.compact >= 2) return launch_bws2<THREADS, U, 2>(a, warp, s);
+    if (a.compact == 1) return launch_bws2<THREADS, U, 1>(a, warp, s);
+    return launch_bws2<THREADS, U, 0>(a, warp, s);
 }
 
 // `per_thread`: events a thread keeps in flight (1, 2, 4 or 8 at 1024 threads; the smaller work-group sizes keep 8192
 // events per pass).
-void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s) {
-#define BF_K1(T_)                                                   \
-    if (per_thread <= 1) launch_bws<T_, 1>(a, warp, s);             \
-    else if (per_thread <= 2) launch_bws<T_, 2>(a, warp, s);        \
-    else if (per_thread <= 4) launch_bws<T_, 4>(a, warp, s);        \
-    else launch_bws<T_, 8>(a, warp, s)
+hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s) {
+#define BF_K1(T_)                                                          \
+    if (per_thread <= 1) return launch_bws<T_, 1>(a, warp, s);             \
+    else if (per_thread <= 2) return launch_bws<T_, 2>(a, warp, s);        \
+    else if (per_thread <= 4) return launch_bws<T_, 4>(a, warp, s);        \
+    else return launch_bws<T_, 8>(a, warp, s)
     if (threads >= 1024) { BF_K1(1024); }
     else if (threads >= 512) { BF_K1(512); }
     else { BF_K1(256); }

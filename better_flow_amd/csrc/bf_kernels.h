@@ -91,6 +91,8 @@ void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_i
                     int32_t* t_out, float2* p, long long n, long long n_pad, SliceStats* stats,
                     hipStream_t s);
 void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s);
+void launch_local_time16(const unsigned long long* ts, const uint16_t* row, const uint16_t* col, unsigned long long t0,
+                         int32_t* x_out, int32_t* y_out, int32_t* t_out, long long n, hipStream_t s);
 void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
 // applies a pending update (sums in `acc`) to `st` in place: the tile-binned loop's update outside a warp+scatter launch
@@ -147,7 +149,7 @@ struct BinScatterArgs {
     int cur, j;                      // plane buffer of this iteration; number of stencil launches completed before it
     unsigned long long* tl;
 };
-void launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
+hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
 void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, bool init_loop, hipStream_t s);
 
 // bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)

@@ -344,9 +344,30 @@ __global__ __launch_bounds__(kThreads) void k_local_time(const unsigned long lon
     t_out[i] = (t > (long long)INT_MAX || t <= (long long)INT_MIN) ? INT_MIN : (int32_t)t;
 }
 
+// The same for a ring with 16-bit addresses (bf_upload_ring16_async): one pass widens row / column for the staging kernel.
+__global__ __launch_bounds__(kThreads) void k_local_time16(const unsigned long long* __restrict__ ts,
+                                                           const uint16_t* __restrict__ row, const uint16_t* __restrict__ col,
+                                                           unsigned long long t0, int32_t* __restrict__ x_out,
+                                                           int32_t* __restrict__ y_out, int32_t* __restrict__ t_out, long long n) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = ts[i];
+    const long long t = v > t0 ? (long long)(v - t0) : -(long long)(t0 - v);
+    t_out[i] = (t > (long long)INT_MAX || t <= (long long)INT_MIN) ? INT_MIN : (int32_t)t;
+    x_out[i] = (int32_t)row[i];
+    y_out[i] = (int32_t)col[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+void launch_local_time16(const unsigned long long* ts, const uint16_t* row, const uint16_t* col, unsigned long long t0,
+                         int32_t* x_out, int32_t* y_out, int32_t* t_out, long long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_local_time16, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, ts, row, col, t0,
+                       x_out, y_out, t_out, n);
+}
+
 void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_local_time, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, ts, t0, t_out, n);

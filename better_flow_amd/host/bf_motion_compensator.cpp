@@ -6,13 +6,23 @@
 // flag: spelling, kind of argument, destination, help text), so adding a flag is one row.
 //
 // Flags the reference fixes at compile time (common.h:39-40, bf_motion_compensator.cpp:6-7) are run-time options here:
-// --res-x= --res-y= (sensor rows / columns), --scale=, --max-iter=, --device=; --to-bin= converts a text recording to
-// the binary structure-of-arrays format (better_flow/event_reader.h); --slice-log= writes one CSV record per slice.
+// --res-x= --res-y= (sensor rows / columns), --scale=, --max-iter=, --device=, --max-events= --span= (the event ring);
+// --to-bin= converts a text recording to the binary structure-of-arrays format (better_flow/event_reader.h);
+// --slice-log= writes one CSV record per slice.
+//
+// Two slice managers sit behind the same flags and give the same results (tests/test_host_cli.py holds one to the
+// other): bf::StreamEngine (better_flow/stream_flow.h) -- events enter a pinned structure-of-arrays ring in bulk, a
+// binary input is read straight into that ring, slices are solved on a worker thread while the next block is read,
+// --devices= spreads independent slices (--stm-disable) over several GPUs, per-event flow is fetched only for -o -- and
+// DVS_flow (better_flow/dvs_flow.h), the reference's array-of-Event ring, which --img / --video / -i need (the frame
+// renderer works on its optimizer object) and --engine=ring selects.
 #include <better_flow/common.h>
 #include <better_flow/dvs_flow.h>
+#include <better_flow/stream_flow.h>
 
 #include <chrono>
 #include <functional>
+#include <thread>
 
 namespace {
 
@@ -29,7 +39,38 @@ struct Options {
     int scale = 3, max_iter = -1;
     std::string input, output, to_bin, slice_log;
     bool have_input = false, have_output = false;
+    // the event ring (EVENT_WIDTH / TIME_WIDTH of the reference, bf_motion_compensator.cpp:6-7)
+    unsigned long long max_events = kMaxEvents;
+    double span_sec = kMaxSpanSec;
+    bool ring_flags = false;               // --max-events / --span given
+    std::string engine;                    // "", "stream" or "ring"
+    std::vector<int> devices;              // --devices
+    int contexts = 1;                      // slice contexts per device
+    bool sync = false, timing = false;
+    int threads = 0;                       // reader / writer threads (0: one per core, at most 8)
 };
+
+// "0-3", "0,2,5", "1": the HIP devices of --devices
+std::vector<int> parse_device_list(const char *v) {
+    std::vector<int> out;
+    const char *p = v;
+    while (*p) {
+        char *e = nullptr;
+        const long a = std::strtol(p, &e, 10);
+        if (e == p || a < 0) return {};
+        long b = a;
+        p = e;
+        if (*p == '-') {
+            b = std::strtol(p + 1, &e, 10);
+            if (e == p + 1 || b < a) return {};
+            p = e;
+        }
+        for (long d = a; d <= b; ++d) out.push_back((int)d);
+        if (*p == ',') ++p;
+        else if (*p) return {};
+    }
+    return out;
+}
 
 enum class Arg { None, Inline, Next };     // "--flag", "--flag=value", "--flag value"
 
@@ -71,6 +112,18 @@ const std::vector<Flag> &flag_table() {
          "convert the text input to the binary event format and exit"},
         {"--slice-log", Arg::Inline, [](Options &o, const char *v) { o.slice_log = v; }, "<file>",
          "one CSV record per slice: slice,events,new_events,rc,iterations,ms,mevents_per_s"},
+        {"--max-events", Arg::Inline, [](Options &o, const char *v) { o.max_events = (unsigned long long)atoll(v); o.ring_flags = true; }, "<n>",
+         "event ring capacity = most events in a slice (the reference compiles in 50000)"},
+        {"--span", Arg::Inline, [](Options &o, const char *v) { o.span_sec = atof(v); o.ring_flags = true; }, "<seconds>",
+         "time span of the event ring = longest slice (the reference compiles in 0.2)"},
+        {"--engine", Arg::Inline, [](Options &o, const char *v) { o.engine = v; }, "stream|ring",
+         "slice manager: structure-of-arrays stream engine (default) or the reference's array-of-Event ring"},
+        {"--devices", Arg::Inline, [](Options &o, const char *v) { o.devices = parse_device_list(v); if (o.devices.empty()) o.devices.push_back(-1); },
+         "<list>", "HIP devices for independent slices (needs --stm-disable), e.g. 0-7 or 0,2"},
+        {"--contexts", Arg::Inline, [](Options &o, const char *v) { o.contexts = atoi(v); }, "<n>", "slice contexts (worker threads) per device"},
+        {"--sync", Arg::None, [](Options &o, const char *) { o.sync = true; }, "", "solve every slice before reading on (no pipelining)"},
+        {"--threads", Arg::Inline, [](Options &o, const char *v) { o.threads = atoi(v); }, "<n>", "threads for reading the input and formatting -o"},
+        {"--timing", Arg::None, [](Options &o, const char *) { o.timing = true; }, "", "print a JSON line with the run's wall-clock phases to stderr"},
     };
     return t;
 }
@@ -137,6 +190,22 @@ int parse(int argc, char **argv, Options &o) {
     }
     if (!o.have_input) { std::fprintf(stderr, "no input file\n"); return 1; }
     if (o.scale < 1 || o.scale % 2 == 0) { std::fprintf(stderr, "--scale must be odd\n"); return 1; }
+    if (!o.engine.empty() && o.engine != "stream" && o.engine != "ring") { std::fprintf(stderr, "--engine must be stream or ring\n"); return 1; }
+    const bool needs_ring = o.frames || o.video || o.interactive;
+    if (o.engine.empty()) o.engine = needs_ring ? "ring" : "stream";
+    if (o.engine == "stream" && needs_ring) { std::fprintf(stderr, "--img / --video / -i work on the reference ring: drop --engine=stream\n"); return 1; }
+    if (o.engine == "ring" && (o.ring_flags || !o.devices.empty() || o.contexts != 1)) {
+        std::fprintf(stderr, "--max-events / --span / --devices / --contexts belong to the stream engine (the reference ring is compiled for %zu events, %g s, one device)\n",
+                     kMaxEvents, kMaxSpanSec);
+        return 1;
+    }
+    if (o.max_events < 1 || o.span_sec <= 0 || o.contexts < 1) { std::fprintf(stderr, "--max-events, --span and --contexts must be positive\n"); return 1; }
+    for (int d : o.devices) if (d < 0) { std::fprintf(stderr, "--devices: a list such as 0-7 or 0,2\n"); return 1; }
+    if ((o.devices.size() > 1 || o.contexts > 1) && !o.stm_disable) {
+        std::fprintf(stderr, "--devices / --contexts spread INDEPENDENT slices: they need --stm-disable (a warm-start chain is sequential)\n");
+        return 1;
+    }
+    if (o.threads <= 0) { const unsigned hc = std::thread::hardware_concurrency(); o.threads = hc == 0 ? 1 : (hc > 8 ? 8 : (int)hc); }
     return -1;
 }
 
@@ -160,7 +229,7 @@ int convert_to_binary(const Options &o) {   // text -> binary structure-of-array
     return 0;
 }
 
-int run(const Options &o) {
+int run_ring(const Options &o) {
     typedef DVS_flow<kMaxEvents, (sll)FROM_SEC(kMaxSpanSec)> Estimator;
     Estimator estimator(o.refresh_events, FROM_SEC(o.refresh_time));
     estimator.set_quiet(o.quiet);
@@ -217,6 +286,116 @@ int run(const Options &o) {
     bf::DeviceContext::release();
     return 0;
 }
+
+double seconds_since(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+}
+
+// The same job on the stream engine (better_flow/stream_flow.h).
+int run_stream(const Options &o) {
+    const auto t_start = std::chrono::steady_clock::now();
+    bf::StreamEngine engine((size_t)o.max_events, (sll)FROM_SEC(o.span_sec), o.refresh_events, FROM_SEC(o.refresh_time));
+    engine.set_scale(o.scale);
+    engine.set_max_iter(o.max_iter);
+    engine.set_stm_disable(o.stm_disable);
+    engine.set_want_flow(false);                       // per-event flow only travels back for -o
+    if (o.have_output) engine.set_accumulate();
+    engine.set_pipelined(!o.sync && !o.bufferize);
+    if (!o.devices.empty() || o.contexts > 1)
+        engine.set_devices(o.devices.empty() ? std::vector<int>{bf::DeviceContext::device()} : o.devices, o.contexts);
+    FILE *slice_log = nullptr;
+    if (!o.slice_log.empty()) {
+        slice_log = std::fopen(o.slice_log.c_str(), "w");
+        if (!slice_log) { std::fprintf(stderr, "cannot write '%s'\n", o.slice_log.c_str()); return 1; }
+        std::fprintf(slice_log, "slice,events,new_events,rc,iterations,ms,mevents_per_s\n");
+    }
+    struct Past { ObjectModel model; size_t size; ull first_ts, last_ts; };   // what dvs_flow.h:245-252 prints per past slice
+    std::vector<Past> memory;
+    unsigned long long total_events = 0;
+    engine.on_slice([&](const bf::SliceRecord &r) {   // in slice order, on the worker's thread
+        if (!o.quiet) {
+            memory.push_back(Past{r.model, (size_t)r.events, r.events ? r.trigger_time : 0, r.oldest_time});
+            std::cout << "\n\n------------------------\n";
+            for (const Past &p : memory) std::cout << p.model << "\n" << p.size << "\t" << p.first_ts << "\t" << p.last_ts << "\n";
+            if (o.bufferize)
+                std::cout << 100.0f * float(r.events_seen) / float(total_events ? total_events : 1) << " %\t" << r.events_seen << "\t"
+                          << r.ms * 1e-3 << " sec\t" << r.ring_size << " events\t" << double(r.time_diff) * 1e-9 << " slice_td\t"
+                          << double((sll)(r.trigger_time - r.start_time)) * 1e-9 << " buffer_td\n";
+        }
+        if (slice_log) {
+            std::fprintf(slice_log, "%llu,%llu,%llu,%d,%d,%.3f,%.3f\n", (unsigned long long)r.index, (unsigned long long)r.events,
+                         (unsigned long long)r.new_events, r.rc, (int)r.info.iterations, r.ms, r.ms > 0 ? r.events / r.ms * 1e-3 : 0.0);
+            std::fflush(slice_log);
+        }
+    });
+    engine.warm_up();                                  // device contexts, worker threads, pinned ring
+    const double s_init = seconds_since(t_start);
+
+    const auto t_read = std::chrono::steady_clock::now();
+    double s_flow = 0;
+    unsigned long long n_events = 0;
+    if (!o.quiet && !o.bufferize) std::cout << "Reading " << o.input << " ..." << std::endl;
+    if (bf::SoaFile::is_soa(o.input) && !o.bufferize) {
+        // binary structure-of-arrays input: column blocks are read straight into the engine's pinned ring
+        bf::SoaFile file(o.input);
+        bool fine = file.good();
+        if (fine) n_events = bf::feed_soa_file(file, engine, o.threads, &fine);
+        if (!fine) { std::fprintf(stderr, "cannot read '%s'\n", o.input.c_str()); return 1; }
+    } else {
+        // text "t x y p" (the reference's format), or --bufferize-file: the whole input first, then the flow
+        if (o.bufferize) std::cout << "Reading from file... (" << o.input << ")" << std::endl;
+        bf::EventReader reader(o.input.c_str());
+        if (!reader.good()) { std::fprintf(stderr, "cannot read '%s'\n", o.input.c_str()); return 1; }
+        std::vector<unsigned long long> t_ns;
+        std::vector<uint32_t> row, col;
+        if (reader.is_binary() || !reader.parse_text_parallel(o.threads, t_ns, row, col)) {
+            t_ns.clear(); row.clear(); col.clear();
+            reader.for_each_event([&](unsigned r, unsigned c, unsigned long long t) { row.push_back(r); col.push_back(c); t_ns.push_back(t); });
+        }
+        n_events = total_events = t_ns.size();
+        if (o.bufferize) std::cout << "Read " << n_events << " events, finished" << std::endl;
+        const auto t_flow = std::chrono::steady_clock::now();
+        engine.add_events(row.data(), col.data(), t_ns.data(), t_ns.size());
+        if (o.bufferize) {
+            engine.recompute();
+            engine.drain();
+            s_flow = seconds_since(t_flow);
+            std::cout << "Total flow elapsed: " << s_flow << " sec." << std::endl;
+        }
+    }
+    if (!o.bufferize) {
+        if (!o.quiet) std::cout << "Read and processed " << n_events << " events" << std::endl;
+        engine.recompute();   // the tail of the stream: every event must have been in a slice
+        engine.drain();
+    }
+    const double s_stream = seconds_since(t_read);
+
+    const auto t_out = std::chrono::steady_clock::now();
+    if (o.have_output) {
+        if (!o.quiet) std::cout << "Aggregating events into one cloud...\n";
+        bf::FlowTable all = engine.get_accumulated();
+        if (!o.quiet) std::cout << "Final buffer contains " << all.size() << " events." << std::endl;
+        std::cout << "Writing events and flow to file... (" << o.output << ")" << std::endl;
+        if (!bf::write_flow_text(o.output, all.timestamp, all.row, all.col, all.u, all.v, o.threads)) {
+            std::fprintf(stderr, "cannot write '%s'\n", o.output.c_str());
+            return 1;
+        }
+        std::cout << "Written " << all.size() << " events, finished" << std::endl;
+    }
+    const double s_output = seconds_since(t_out);
+    if (!o.quiet)
+        std::cout << "slices: " << engine.get_slices_done() << " (skipped " << engine.get_slices_skipped()
+                  << "), minimizer iterations: " << engine.get_iterations_total() << std::endl;
+    if (o.timing)
+        std::fprintf(stderr, "{\"engine\": \"stream\", \"events\": %llu, \"slices\": %llu, \"iterations\": %llu, \"init_s\": %.6f, "
+                             "\"stream_s\": %.6f, \"output_s\": %.6f, \"total_s\": %.6f, \"mevents_per_s\": %.3f}\n",
+                     n_events, (unsigned long long)engine.get_slices_done(), (unsigned long long)engine.get_iterations_total(), s_init,
+                     s_stream, s_output, seconds_since(t_start), s_stream > 0 ? n_events / s_stream * 1e-6 : 0.0);
+    if (slice_log) std::fclose(slice_log);
+    return 0;
+}
+
+int run(const Options &o) { return o.engine == "ring" ? run_ring(o) : run_stream(o); }
 
 }  // namespace
 

@@ -157,6 +157,8 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  spinning in hipEventSynchronize: 0.85 instead of 4.1 host cores for 4 slice contexts at the
  *                  same throughput.  0: spin.  Warm-started runs always spin (they wait for the batch just
  *                  launched; latency matters there).
+ *   "watchdog_ms"  a cold bf_run whose device iteration counter has not advanced for this long (wall clock, default
+ *                  40000) stops with BF_ERR_HIP "device loop makes no progress" instead of waiting for ever.
  *   "bin_tile_rows"  tile HEIGHT (0 = default: chosen per slice among 32 .. 128 so that the bins -- one
  *                  work-group each -- fill the CUs; else a multiple of 16 in [32, 128]).  "bin_tile" is the
  *                  tile width.
@@ -329,12 +331,27 @@ int bf_color_time_img(bf_ctx *ctx, int32_t scale, int32_t res_x, int32_t res_y, 
 /* The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays event ring kept
  * in pinned memory (bf_host_alloc) -- no AoS -> SoA repack (accel_lib.h:91-99) and no per-slice allocation on
  * the host.  The slice is the n events starting at ring index `first` (wrapping at `cap`), stored oldest ->
- * newest; Event::set_local_time(t0) (event.h:61-63) is applied on the device.  Asynchronous like
- * bf_upload_events_async (same two staging slots; bf_commit_upload makes the slice current).  The ring slots
- * may be overwritten once bf_wait_uploads has returned. */
+ * newest; Event::set_local_time(t0) (event.h:61-63) is applied on the device.  ring_noise (may be NULL: no event
+ * is noise) is the ring of Event::noise flags -- the reference sets them for every event of a slice that its
+ * small-window guard rejects (optimizer_rolling.h:49-55) and get_time_img leaves flagged events out of later,
+ * overlapping slices (accel_lib.h:152).  Asynchronous like bf_upload_events_async (same two staging slots;
+ * bf_commit_upload makes the slice current).  The ring slots may be overwritten once bf_wait_uploads has
+ * returned. */
 int bf_upload_ring_async(bf_ctx *ctx, const int32_t *ring_fr_x, const int32_t *ring_fr_y,
-                         const uint64_t *ring_timestamp_ns, int64_t cap, int64_t first, int64_t n,
-                         uint64_t t0_ns);
+                         const uint64_t *ring_timestamp_ns, const uint8_t *ring_noise, int64_t cap,
+                         int64_t first, int64_t n, uint64_t t0_ns);
+
+/* The same hand-off for a ring with 16-bit addresses: 12 bytes per event over the link instead of 16, and the
+ * column layout of the binary event file (better_flow/event_reader.h: u64 t_ns[], u16 x[] = column, u16 y[] = row),
+ * so that a file block read into the ring is uploaded as it lies.  ring_row = Event::fr_x, ring_col = Event::fr_y. */
+int bf_upload_ring16_async(bf_ctx *ctx, const uint16_t *ring_row, const uint16_t *ring_col,
+                           const uint64_t *ring_timestamp_ns, const uint8_t *ring_noise, int64_t cap,
+                           int64_t first, int64_t n, uint64_t t0_ns);
+
+/* Event::compute_uv (event.h:135-142) of the current slice written straight into a ring of interleaved (u, v)
+ * pairs: event i of the slice goes to uv_ring[2 * ((first + i) % cap)] and [... + 1].  No intermediate host copy:
+ * with a pinned ring this is one or two DMA transfers.  Blocks until the data has arrived. */
+int bf_compute_uv_ring(bf_ctx *ctx, double *uv_ring, int64_t cap, int64_t first);
 
 /* Block until the host-to-device copies of every pending asynchronous upload have finished. */
 int bf_wait_uploads(bf_ctx *ctx);

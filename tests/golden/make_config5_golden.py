@@ -1,0 +1,93 @@
+"""Generator of tests/golden/config5_720p_seed<S>.npz -- BASELINE config 5's slice run to the loop's OWN termination.
+
+    python tests/golden/make_config5_golden.py [seed ...]          (default: seed 1; ~25 min of CPU per seed)
+
+The oracle (oracle/bf_oracle.c, the CPU restatement of optimizer_rolling.h:48-125 -- "parity unpinned", see its header)
+is run twice on the 1M-event 1280x720 slice `synth.make_slice(1000000, 720, 1280, 0.030, seed)`: events in upload order
+and in reversed order.  The reference accumulates its time image in f32 in container order (accel_lib.h:162), so the two
+runs are both "the reference's answer"; their difference is the yardstick the GPU run is held to
+(tests/test_gpu_geometries.py::test_config5_to_termination_against_golden).  Thousands of iterations at 0.27 s each do not
+fit the GPU suite's budget, hence a committed fixture: per order the return code, iteration count, dividers, final model,
+the model every 25 iterations, per-event flow at 4096 evenly spaced events and its percentiles, plus the largest
+forward / reversed flow difference over ALL events, and a digest of the input arrays.
+Oracle-generated: a regression pin of the restatement, not a pin to the reference.
+"""
+import hashlib
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+H, W, S, N, T = 720, 1280, 3, 1000000, 0.030
+STRIDE = 25
+SAMPLES = 4096
+FIELDS = ("cx", "cy", "dx", "dy", "rot", "div", "cnt", "total_dx", "total_dy", "total_rot", "total_div")
+PCT = (0, 1, 5, 25, 50, 75, 95, 99, 100)
+
+
+def slice_digest(sl):
+    h = hashlib.sha256()
+    for k in ("fr_x", "fr_y", "t"):
+        h.update(np.ascontiguousarray(sl[k]).tobytes())
+    return h.hexdigest()
+
+
+def one_run(args):
+    seed, reverse = args
+    import oracle
+    from better_flow_amd import synth
+    sl = synth.make_slice(N, H, W, T, seed=seed)
+    n = len(sl["t"])
+    order = np.arange(n)[::-1].copy() if reverse else np.arange(n)
+    oc = oracle.Cloud(sl["fr_x"][order], sl["fr_y"][order], sl["t"][order])
+    ow = oc.set_cloud(S, H, W)
+    om = oracle.Model()
+    cap = 60000
+    rc, loop, trace = oc.run(ow, om, res_x=H, res_y=W, hard_cap=cap, trace_cap=cap)
+    u, v = oc.compute_uv()
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    u, v = u[inv], v[inv]
+    every = np.array([[getattr(trace[k].model, f) for f in FIELDS] for k in range(0, len(trace), STRIDE)], dtype=np.float64)
+    return dict(rc=rc, iterations=int(loop.itercount),
+                dividers=np.array([loop.x_divider, loop.y_divider, loop.rot_divider, loop.div_divider], np.float32),
+                model=np.array([getattr(om, f) for f in FIELDS], np.float64), every=every, u=u, v=v,
+                digest=slice_digest(sl), n=n)
+
+
+def main():
+    seeds = [int(a) for a in sys.argv[1:]] or [1]
+    jobs = [(s, r) for s in seeds for r in (False, True)]
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        res = pool.map(one_run, jobs)
+    for i, seed in enumerate(seeds):
+        f, r = res[2 * i], res[2 * i + 1]
+        assert f["digest"] == r["digest"]
+        idx = np.linspace(0, f["n"] - 1, SAMPLES).astype(np.int64)
+        out = dict(seed=seed, geometry=np.array([H, W, S]), n=f["n"], input_sha256=f["digest"], fields=np.array(FIELDS),
+                   trace_stride=STRIDE, sample_idx=idx, percentiles=np.array(PCT),
+                   spread_u=np.abs(f["u"] - r["u"]).max(), spread_v=np.abs(f["v"] - r["v"]).max())
+        for tag, d in (("fwd", f), ("rev", r)):
+            out[tag + "_rc"] = d["rc"]
+            out[tag + "_iterations"] = d["iterations"]
+            out[tag + "_dividers"] = d["dividers"]
+            out[tag + "_model"] = d["model"]
+            out[tag + "_every"] = d["every"]
+            out[tag + "_u"] = d["u"][idx]
+            out[tag + "_v"] = d["v"][idx]
+            out[tag + "_u_pct"] = np.percentile(d["u"], PCT)
+            out[tag + "_v_pct"] = np.percentile(d["v"], PCT)
+        path = os.path.join(HERE, "config5_720p_seed%d.npz" % seed)
+        np.savez_compressed(path, **out)
+        print("%s: forward %d iterations (rc %d), reversed %d (rc %d); flow spread %.3e / %.3e px/s" %
+              (path, f["iterations"], f["rc"], r["iterations"], r["rc"], out["spread_u"], out["spread_v"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <utility>
 #include <vector>
 
@@ -24,8 +25,13 @@ struct bf_ctx {
     bfo_model model;
     bool have_window = false;
     bool reversed = false;   // events of a ring slice are held newest -> oldest, the order the reference iterates in
-    std::vector<int32_t> pend_x, pend_y;
-    std::vector<int64_t> pend_t;
+    struct PendingUpload {   // bf_upload_*_async ... bf_commit_upload: a FIFO, like the two staging slots of the product
+        std::vector<int32_t> x, y;
+        std::vector<int64_t> t;
+        std::vector<uint8_t> noise;
+        bool linear = false;
+    };
+    std::deque<PendingUpload> pend;
     bfo_local_window lwin;
     std::vector<float> time_img;
     char err[128] = "";
@@ -57,6 +63,21 @@ static bool flip_order() {
 }
 template <class T> static void reverse_vec(std::vector<T> &v) {
     for (size_t i = 0, n = v.size(); i < n / 2; ++i) std::swap(v[i], v[n - 1 - i]);
+}
+
+template <class ADDR>
+static int ring_slice(bf_ctx *c, const ADDR *rx, const ADDR *ry, const uint64_t *rts, const uint8_t *rnoise, int64_t cap,
+                      int64_t first, int64_t n, uint64_t t0) {
+    c->pend.emplace_back();
+    bf_ctx::PendingUpload &u = c->pend.back();
+    u.x.resize(n); u.y.resize(n); u.t.resize(n); u.noise.assign(n, 0);
+    for (int64_t i = 0; i < n; ++i) {   // newest -> oldest, like `for (auto &e : ev_buffer)` (dvs_flow.h:195-197)
+        const int64_t k = (first + (n - 1 - i)) % cap;
+        u.x[i] = (int32_t)rx[k]; u.y[i] = (int32_t)ry[k];
+        u.t[i] = rts[k] > t0 ? (int64_t)(rts[k] - t0) : -(int64_t)(t0 - rts[k]);   // event.h:61-63
+        if (rnoise) u.noise[i] = rnoise[k];
+    }
+    return BF_OK;
 }
 
 extern "C" {
@@ -228,26 +249,51 @@ int bf_host_free(bf_ctx *, void *ptr) { std::free(ptr); return BF_OK; }
 int bf_synchronize(bf_ctx *) { return BF_OK; }
 int bf_wait_uploads(bf_ctx *) { return BF_OK; }
 
-int bf_upload_ring_async(bf_ctx *c, const int32_t *rx, const int32_t *ry, const uint64_t *rts, int64_t cap, int64_t first,
-                         int64_t n, uint64_t t0) {
-    c->pend_x.resize(n); c->pend_y.resize(n); c->pend_t.resize(n);
-    for (int64_t i = 0; i < n; ++i) {   // newest -> oldest, like `for (auto &e : ev_buffer)` (dvs_flow.h:195-197)
-        const int64_t k = (first + (n - 1 - i)) % cap;
-        c->pend_x[i] = rx[k]; c->pend_y[i] = ry[k];
-        c->pend_t[i] = rts[k] > t0 ? (int64_t)(rts[k] - t0) : -(int64_t)(t0 - rts[k]);   // event.h:61-63
+int bf_upload_ring_async(bf_ctx *c, const int32_t *rx, const int32_t *ry, const uint64_t *rts, const uint8_t *rnoise,
+                         int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    return ring_slice(c, rx, ry, rts, rnoise, cap, first, n, t0);
+}
+int bf_upload_ring16_async(bf_ctx *c, const uint16_t *rrow, const uint16_t *rcol, const uint64_t *rts, const uint8_t *rnoise,
+                           int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    return ring_slice(c, rrow, rcol, rts, rnoise, cap, first, n, t0);
+}
+
+// slice event i (oldest -> newest) -> uv_ring[2 * ((first + i) % cap)]
+int bf_compute_uv_ring(bf_ctx *c, double *uv_ring, int64_t cap, int64_t first) {
+    const size_t n = c->fx.size();
+    std::vector<double> u(n), v(n);
+    bf_compute_uv(c, u.data(), v.data());
+    for (size_t i = 0; i < n; ++i) {
+        const size_t k = (size_t)((first + (int64_t)i) % cap);
+        uv_ring[2 * k] = u[i]; uv_ring[2 * k + 1] = v[i];
     }
     return BF_OK;
 }
 
+int bf_set_option(bf_ctx *, const char *, int64_t) { return BF_OK; }   // device tuning knobs: nothing to tune here
+
+// linear int32 arrays with slice-local times (the slice farm's second input form); held in upload order
+int bf_upload_events_async(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns, int64_t n) {
+    c->pend.emplace_back();
+    bf_ctx::PendingUpload &u = c->pend.back();
+    u.x.assign(fr_x, fr_x + n); u.y.assign(fr_y, fr_y + n);
+    u.t.assign(t_ns, t_ns + n);
+    u.noise.assign(n, 0);
+    u.linear = true;
+    return BF_OK;
+}
+
 int bf_commit_upload(bf_ctx *c) {
-    const int64_t n = (int64_t)c->pend_x.size();
-    c->fx = c->pend_x; c->fy = c->pend_y; c->t = c->pend_t;
-    c->noise.assign(n, 0);
+    if (c->pend.empty()) return BF_ERR_STATE;
+    bf_ctx::PendingUpload u = std::move(c->pend.front());
+    c->pend.pop_front();
+    const int64_t n = (int64_t)u.x.size();
+    c->fx = std::move(u.x); c->fy = std::move(u.y); c->t = std::move(u.t); c->noise = std::move(u.noise);
     c->pr_x.assign(n, 0); c->pr_y.assign(n, 0); c->nx.assign(n, 0); c->ny.assign(n, 0);
-    c->reversed = true;
+    c->reversed = !u.linear;   // ring slices arrive newest -> oldest, linear arrays in upload order
     if (flip_order()) {
-        reverse_vec(c->fx); reverse_vec(c->fy); reverse_vec(c->t);
-        c->reversed = false;
+        reverse_vec(c->fx); reverse_vec(c->fy); reverse_vec(c->t); reverse_vec(c->noise);
+        c->reversed = !c->reversed;
     }
     c->bind();
     c->have_window = false;

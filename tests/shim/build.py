@@ -27,7 +27,7 @@ def build(sanitize=False):
     extra = SAN if sanitize else []
     obj = os.path.join(OUT, "bf_oracle_san.o" if sanitize else "bf_oracle.o")
     subprocess.check_call(["gcc", "-O1" if sanitize else "-O2", "-std=c11", "-ffp-contract=off"] + extra + ["-c", srcs[2], "-o", obj])
-    subprocess.check_call(["g++", "-O1" if sanitize else "-O2", "-std=c++14", "-ffp-contract=off"] + extra + [
+    subprocess.check_call(["g++", "-O1" if sanitize else "-O2", "-std=c++14", "-pthread", "-ffp-contract=off"] + extra + [
                            "-I" + os.path.join(ROOT, "better_flow_amd", "host"), "-I" + os.path.join(ROOT, "include"),
                            srcs[0], srcs[1], obj, "-lm", "-o", exe])
     return exe

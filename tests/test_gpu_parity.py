@@ -1073,3 +1073,91 @@ def test_run_to_convergence_with_rotation_and_divergence(oracle_lib, accel_mod):
         if div:
             assert abs(m.total_div - om.total_div) <= 1e-6 * abs(om.total_div) + 1e-9 and abs(m.total_div) > 1e-4
         acc.close()
+
+
+def test_ring16_hand_off_with_noise_and_flow_ring(oracle_lib, accel_mod):
+    """bf_upload_ring16_async (16-bit addresses, absolute 64-bit timestamps, an Event::noise ring, a slice that wraps
+    around the end of the ring) + bf_compute_uv_ring: event-count image bit-exact against the oracle with the same noise
+    mask (accel_lib.h:152), run and per-event flow identical to the blocking int32 upload of the same slice, and the
+    (u, v) pairs land at their ring positions."""
+    H, W, s = 180, 240, 3
+    sl = synth.make_slice(30000, H, W, 0.04, seed=123)
+    n = len(sl["t"])
+    cap, first, t0 = n + 5000, n + 5000 - 7000, 5_000_000_000      # the slice occupies [first, cap) and [0, n - 7000)
+    idx = (first + np.arange(n)) % cap
+    ring_row, ring_col = np.zeros(cap, np.uint16), np.zeros(cap, np.uint16)
+    ring_ts, ring_noise = np.zeros(cap, np.uint64), np.zeros(cap, np.uint8)
+    noise = (np.arange(n) % 7 == 0).astype(np.uint8)
+    ring_row[idx], ring_col[idx] = sl["fr_x"], sl["fr_y"]
+    ring_ts[idx] = sl["t"].astype(np.uint64) + np.uint64(t0)
+    ring_noise[idx] = noise
+    ring_noise[(first - 100) % cap] = 1                            # outside the slice: must not matter
+    oc = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    oc.noise[:] = noise
+    ow = oc.set_cloud(s, H, W)
+    _, ocnt = oc.get_time_img(ow)
+
+    def solve(acc):
+        acc.set_cloud(s, H, W)
+        _, cnt = acc.get_time_img(want_time=False)
+        o = acc.default_opts()
+        o.res_x, o.res_y, o.want_uv = H, W, 1
+        rc, m, info = acc.run(o)
+        return cnt, rc, m.as_dict(), info.iterations
+
+    acc = accel_mod.Accel(max_events=n, max_rows=s * H + s, max_cols=s * W + s)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"], noise)
+    want = solve(acc)
+    wu, wv = acc.compute_uv()
+    assert np.array_equal(want[0], ocnt.astype(np.uint32)) and want[1] == 0
+    for with_noise in (True, False):
+        acc.upload_ring_async(ring_row, ring_col, ring_ts, first, n, t0, ring_noise if with_noise else None)
+        acc.commit_upload()
+        got = solve(acc)
+        if with_noise:
+            assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+            uv = np.full(2 * cap, np.nan)
+            acc.compute_uv_ring(uv, first)
+            assert np.array_equal(uv[2 * idx], wu) and np.array_equal(uv[2 * idx + 1], wv)
+            rest = np.ones(cap, bool)
+            rest[idx] = False
+            assert np.isnan(uv[0::2][rest]).all()                  # nothing outside the slice's ring positions was written
+        else:
+            assert int(got[0].sum()) > int(want[0].sum())          # without the mask the flagged events count again
+    # the int32 ring form carries the same noise ring
+    acc.upload_ring_async(ring_row.astype(np.int32), ring_col.astype(np.int32), ring_ts, first, n, t0, ring_noise)
+    acc.commit_upload()
+    got = solve(acc)
+    assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    acc.close()
+
+
+def test_spinning_poll_with_long_batches(accel_mod):
+    """blocking_poll = 0 (the host spins on the pinned snapshot instead of sleeping) with a poll interval of 256
+    iterations: the watchdog of the progress poll is a wall-clock deadline since the device's last progress, so a healthy
+    run whose batches take milliseconds is not declared hung -- and gives the bits of the default run."""
+    H, W, s = 260, 346, 3
+    sl = synth.make_slice(400000, H, W, 0.030, seed=2)
+
+    def go(**opt):
+        acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+        poll = opt.pop("poll", None)
+        for k, v in opt.items():
+            acc.set_option(k, v)
+        acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        acc.set_cloud(s, H, W)
+        o = acc.default_opts()
+        o.res_x, o.res_y = H, W
+        if poll:
+            o.poll_interval = poll
+        try:
+            rc, m, info = acc.run(o)
+            return rc, m.as_dict(), info.iterations
+        finally:
+            acc.close()
+
+    want = go(binned=2)
+    assert want[0] == 0 and want[2] > 100
+    assert go(binned=2, blocking_poll=0, poll=256) == want
+    assert go(binned=2, blocking_poll=0, poll=256, co_schedule=1) == want
+    assert go(binned=2, blocking_poll=0, poll=256, watchdog_ms=2000) == want

@@ -149,13 +149,124 @@ def test_cli_gpu_matches_oracle_cli(oracle_cli, events_txt, tmp_path):
     assert "gfx950" in ver and "SHIM" not in ver
 
 
+# ---- the two slice managers behind the command line: stream engine (default) vs the reference's ring ----
+
+ENGINE_CASES = ([], ["--stm-disable"], ["--max-iter=10"], ["--sync"], ["--stm-disable", "--contexts=3"], ["--bufferize-file"])
+
+
+def _engine_outputs(exe, path, tmp_path, tag, extra):
+    out = str(tmp_path / ("eng_%s.txt" % tag))
+    so = run_cli(exe, extra + ["-o", out, path], str(tmp_path))
+    return parse_summary(so), open(out, "rb").read()
+
+
+def test_cli_stream_engine_equals_reference_ring_oracle(oracle_cli, events_txt, tmp_path):
+    """The stream engine (bulk input, pinned SoA ring, slice farm, SoA -o table) gives the output FILE of the reference's
+    array-of-Event ring byte for byte: default flags, cold slices, capped, unpipelined, three workers, --bufferize-file,
+    and from the binary event file (read straight into the ring)."""
+    path, _ = events_txt
+    want = _engine_outputs(oracle_cli, path, tmp_path, "ring", ["--engine=ring"])
+    assert want[0][0] == 4
+    for i, extra in enumerate(ENGINE_CASES):
+        ref = _engine_outputs(oracle_cli, path, tmp_path, "ring%d" % i, ["--engine=ring"] + [e for e in extra if e not in ("--sync", "--contexts=3")])
+        got = _engine_outputs(oracle_cli, path, tmp_path, "stream%d" % i, extra)
+        assert got == ref, extra
+    binary = str(tmp_path / "ev.bin")
+    run_cli(oracle_cli, ["--to-bin=" + binary, path], str(tmp_path))
+    assert _engine_outputs(oracle_cli, binary, tmp_path, "bin", []) == want
+    assert _engine_outputs(oracle_cli, binary, tmp_path, "bin1", ["--threads=1"]) == want
+    # flags that belong to one engine are refused on the other, with a message
+    r = subprocess.run([oracle_cli, "--engine=ring", "--max-events=1000", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"stream engine" in r.stderr
+    r = subprocess.run([oracle_cli, "--devices=0,0", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"--stm-disable" in r.stderr
+
+
+def _big_stream_file(tmp_path, slices=4, per_slice=250000):
+    """`slices` consecutive 30 ms slices of ~per_slice events at 346x260 as one binary event file."""
+    import struct
+    H, W = 260, 346
+    parts = [synth.make_slice(per_slice, H, W, 0.030, seed=900 + i) for i in range(slices)]
+    t = np.concatenate([p["t"].astype(np.uint64) + np.uint64(i * 30_000_000 + 1_000_000_000) for i, p in enumerate(parts)])
+    x = np.concatenate([p["fr_y"] for p in parts]).astype(np.uint16)   # file x = column
+    y = np.concatenate([p["fr_x"] for p in parts]).astype(np.uint16)   # file y = row
+    path = str(tmp_path / "big.bin")
+    with open(path, "wb") as f:
+        f.write(b"BFEVSOA1" + struct.pack("<Q", len(t)))
+        f.write(t.tobytes()); f.write(x.tobytes()); f.write(y.tobytes()); f.write(np.ones(len(t), np.uint8).tobytes())
+    return path, len(t)
+
+
+BIG_FLAGS = ["--res-x=260", "--res-y=346", "--max-events=400000", "--span=0.03", "--refresh-time=0.03",
+             "--refresh-event-count=100000000"]
+
+
+def test_cli_runtime_ring_large_slices_oracle(oracle_cli, tmp_path):
+    """--max-events / --span: rolling 30 ms slices of ~250k events at 346x260 from a binary file (config-3 style), on
+    the oracle shim: one slice per 30 ms plus the tail, every solved event in the -o table once."""
+    path, n = _big_stream_file(tmp_path, slices=3, per_slice=60000)
+    out = str(tmp_path / "big_o.txt")
+    so = run_cli(oracle_cli, BIG_FLAGS + ["-o", out, path], str(tmp_path))
+    slices, skipped, iters = parse_summary(so)
+    assert slices == 3 and skipped == 0, so[-500:]
+    a = np.loadtxt(out)
+    # (a handful of events at the head of a 30 ms block are older than trigger - span when the next block's first event
+    # closes the slice: the ring has dropped them before any slice saw them -- the reference's behaviour)
+    assert n - 20 <= a.shape[0] <= n and a.shape[1] == 6
+
+
+@pytest.mark.gpu
+def test_cli_stream_engine_large_slices_gpu_matches_oracle(oracle_cli, tmp_path):
+    """The stream engine on the HIP path against the SAME engine on the oracle shim, at slices of a quarter million events
+    from a binary file (read into the pinned ring, 16-bit ring upload, worker thread, -o table): same slices and skip
+    decisions, iteration counts within +-1 per slice, per-event flow within 1e-4 relative / 0.02 px/s."""
+    path, n = _big_stream_file(tmp_path)
+    gpu_cli = os.path.join(ROOT, "better_flow_amd", "host", "bf_motion_compensator")
+    outs = {}
+    for tag, exe, extra in (("oracle", oracle_cli, []), ("gpu", gpu_cli, []), ("gpu_sync", gpu_cli, ["--sync", "--threads=1"])):
+        out = str(tmp_path / ("big_%s.txt" % tag))
+        so = run_cli(exe, BIG_FLAGS + extra + ["-o", out, path], str(tmp_path))
+        outs[tag] = (parse_summary(so), np.loadtxt(out))
+    (so_, a), (sg_, b), (ss_, c) = outs["oracle"], outs["gpu"], outs["gpu_sync"]
+    assert so_[0] == 4 and so_[:2] == sg_[:2] == ss_[:2]
+    assert abs(so_[2] - sg_[2]) <= so_[0]
+    assert a.shape == b.shape and n - 20 <= a.shape[0] <= n and np.array_equal(a[:, :4], b[:, :4])
+    assert sg_ == ss_ and np.array_equal(b, c)          # pipelined == unpipelined, bit for bit
+    for col in (4, 5):
+        d = np.abs(a[:, col] - b[:, col])
+        assert np.all(d <= np.maximum(1e-4 * np.abs(a[:, col]), 0.02)), (col, d.max())
+
+
+@pytest.mark.gpu
+def test_cli_stream_engine_equals_reference_ring_gpu(events_txt, tmp_path):
+    """Both slice managers on the HIP path: byte-identical -o files (the device results are bit-reproducible and do not
+    depend on the event order inside a slice), including independent slices on three slice contexts of GPU 0."""
+    path, _ = events_txt
+    gpu_cli = os.path.join(ROOT, "better_flow_amd", "host", "bf_motion_compensator")
+    for i, extra in enumerate(ENGINE_CASES):
+        ref = _engine_outputs(gpu_cli, path, tmp_path, "gring%d" % i, ["--engine=ring"] + [e for e in extra if e not in ("--sync", "--contexts=3")])
+        got = _engine_outputs(gpu_cli, path, tmp_path, "gstream%d" % i, extra)
+        assert got == ref, extra
+    two = _engine_outputs(gpu_cli, path, tmp_path, "gdev", ["--stm-disable", "--devices=0,0", "--contexts=2"])
+    assert two == _engine_outputs(gpu_cli, path, tmp_path, "gdev1", ["--stm-disable"])
+
+
+def test_fixed9_formatter_matches_printf(tmp_path):
+    """bf::format_fixed9 (the -o writer's number formatter) == snprintf("%.9f") on three million values."""
+    exe = str(tmp_path / "test_format")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I" + os.path.join(ROOT, "better_flow_amd", "host"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_format.cpp"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert out.strip().endswith(" 0 mismatches"), out
+
+
 # ---- OptimizerLocal through the host class (better_flow/optimizer_sampler.h) ----
 
 def _build_test_local(out_dir, against_gpu):
     host = os.path.join(ROOT, "better_flow_amd", "host")
     src = os.path.join(ROOT, "tests", "cpp", "test_local.cpp")
     exe = os.path.join(out_dir, "test_local_gpu" if against_gpu else "test_local_oracle")
-    base = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-I" + host, "-I" + os.path.join(ROOT, "include"), src]
+    base = ["g++", "-O2", "-std=c++14", "-pthread", "-ffp-contract=off", "-I" + host, "-I" + os.path.join(ROOT, "include"), src]
     if against_gpu:
         subprocess.check_call(base + ["-L" + os.path.join(ROOT, "better_flow_amd"), "-lbf_accel",
                                       "-Wl,-rpath," + os.path.join(ROOT, "better_flow_amd"), "-Wl,-rpath,/opt/rocm/lib",
@@ -260,7 +371,7 @@ def _build_test_stream(out_dir, against_gpu):
     host = os.path.join(ROOT, "better_flow_amd", "host")
     src = os.path.join(ROOT, "tests", "cpp", "test_stream.cpp")
     exe = os.path.join(out_dir, "test_stream_gpu" if against_gpu else "test_stream_oracle")
-    base = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-I" + host, "-I" + os.path.join(ROOT, "include"), src]
+    base = ["g++", "-O2", "-std=c++14", "-pthread", "-ffp-contract=off", "-I" + host, "-I" + os.path.join(ROOT, "include"), src]
     if against_gpu:
         subprocess.check_call(base + ["-L" + os.path.join(ROOT, "better_flow_amd"), "-lbf_accel",
                                       "-Wl,-rpath," + os.path.join(ROOT, "better_flow_amd"), "-Wl,-rpath,/opt/rocm/lib",
@@ -275,17 +386,31 @@ def _build_test_stream(out_dir, against_gpu):
 
 
 def _check_stream_output(out):
-    verdicts = [ln for ln in out.splitlines() if ln.startswith(("OK", "FAIL"))]
-    assert len(verdicts) == 3 and all(v.startswith("OK") for v in verdicts), out[-3000:]
+    lines = out.splitlines()
+    verdicts = [ln for ln in lines if ln.startswith(("OK", "FAIL"))]
+    assert len(verdicts) == 6 and all(v.startswith("OK") for v in verdicts), out[-4000:]
     # the small ring really filled (full-ring quirk: one element fewer iterated) and the short span really trimmed
     assert "ring 3000 / 3000, iterated 2999" in out
-    assert any("ring 3000" not in ln and "(ring" not in ln and "/ " in ln and int(ln.split("ring ")[1].split(" /")[0]) < 3000
-               for ln in out.splitlines() if ln.startswith("slice") )
+    assert any(int(ln.split("ring ")[1].split(" /")[0]) < 3000 for ln in lines if ln.startswith("slice"))
+    # every run compared a non-trivial accumulated table, and the bulk / pipelined / multi-worker replays agreed
+    acc = [ln for ln in lines if ln.startswith("accumulated:")]
+    assert len(acc) == 6 and all(ln.endswith(" 0 differences") and int(ln.split()[1]) > 3000 for ln in acc), acc
+    bulk = [ln for ln in lines if ln.startswith("bulk, pipelined")]
+    assert len(bulk) == 6 and all("0 slice differences, 0 table differences" in ln for ln in bulk), bulk
+    assert sum("3 worker(s)" in ln or "2 worker(s)" in ln for ln in bulk) == 2
+    # the two runs on the oversized sensor went through the window guard (events flagged as noise) AND through real solves
+    noise = [v for v in verdicts if "noise-" in v]
+    assert len(noise) == 2
+    for v in noise:
+        stopped = int(v.split("slices + tail, ")[1].split(" stopped")[0])
+        total = int(v.split(": ")[1].split(" slices")[0])
+        assert 0 < stopped < total, v
 
 
 def test_stream_flow_equals_dvs_flow_oracle(events_txt, tmp_path):
-    """Same stream through DVS_flow (AoS ring, repack per slice) and StreamFlow (pinned SoA ring, ring hand-off): same
-    triggers, slices, models and per-event flow -- here on the oracle shim (which holds ring slices in the reference's
+    """Same streams through DVS_flow (AoS ring, repack per slice) and StreamFlow (pinned SoA ring, ring hand-off, slice
+    farm): same triggers, slices, models, per-event flow, noise flags and accumulated -o table; one event at a time, in bulk
+    blocks, pipelined, on several workers -- here on the oracle shim (which holds ring slices in the reference's
     newest -> oldest order, so even the f32 accumulation order is the same)."""
     path, _ = events_txt
     out = run_cli(_build_test_stream(str(tmp_path), False), [path], str(tmp_path))

@@ -454,6 +454,16 @@ int after_upload(bf_ctx* c, long long n) {
 
 }  // namespace
 
+// copy stream, its events and the second staging slot of the asynchronous uploads (created on first use)
+static int streaming_setup(bf_ctx* c) {
+    if (c->copy_stream) return BF_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    return BF_OK;
+}
+
 // The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays ring in pinned
 // memory: up to two contiguous pieces per array, no repacking on the host.  ADDR is int32_t (bf_upload_ring_async) or
 // uint16_t (bf_upload_ring16_async: the addresses travel as 16-bit values and are widened by the staging kernel).
@@ -466,11 +476,9 @@ static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const 
     if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
     if (c->pend_count >= 2) return fail(c, BF_ERR_STATE, "two uploads are already pending");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->copy_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
-        for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    {
+        const int rc = streaming_setup(c);
+        if (rc != BF_OK) return rc;
     }
     const int slot = (c->pend_head + c->pend_count) & 1;
     if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
@@ -685,6 +693,17 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_blocking_poll = value != 0;
         return BF_OK;
     }
+    if (!strcmp(key, "stream_prealloc")) {   // everything the 16-bit ring hand-off allocates on first use, now
+        if (!value) return BF_OK;
+        HIP_TRY(c, hipSetDevice(c->device));
+        const int rc = streaming_setup(c);
+        if (rc != BF_OK) return rc;
+        for (int slot = 0; slot < 2; ++slot) {
+            if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
+            if (!c->d_in16[slot]) HIP_TRY(c, hipMalloc(&c->d_in16[slot], (size_t)c->cap_events * 2 * sizeof(uint16_t)));
+        }
+        return BF_OK;
+    }
     if (!strcmp(key, "watchdog_ms")) {
         if (value < 1) return fail(c, BF_ERR_ARG, "watchdog_ms must be >= 1");
         c->opt_watchdog_s = (double)value * 1e-3;
@@ -801,11 +820,9 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
     if (n > c->cap_events) return fail(c, BF_ERR_CAPACITY, "n=%lld exceeds capacity %lld", (long long)n, c->cap_events);
     if (c->pend_count >= 2) return fail(c, BF_ERR_STATE, "two uploads are already pending");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->copy_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
-        for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    {
+        const int rc = streaming_setup(c);
+        if (rc != BF_OK) return rc;
     }
     const int slot = (c->pend_head + c->pend_count) & 1;
     // the slot's previous content may still be waiting for its staging kernel on the compute stream

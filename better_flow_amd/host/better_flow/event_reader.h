@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -288,7 +289,7 @@ public:
 // Feed a binary event file to a StreamEngine-like sink (reserve / commit / set_time_base) block by block, the blocks
 // read into the sink's own ring on `threads` threads.  Same event stream as EventReader::for_each_event: the first
 // record's time is the origin.  Returns the number of events fed; *ok = false on a read error.
-template <class Sink> uint64_t feed_soa_file(const SoaFile &file, Sink &sink, int threads, bool *ok) {
+template <class Sink> uint64_t feed_soa_file(const SoaFile &file, Sink &sink, int threads, bool *ok, double *read_seconds = nullptr) {
     *ok = file.good();
     if (!file.good() || file.events() == 0) return 0;
     uint64_t t0 = 0;
@@ -313,12 +314,14 @@ template <class Sink> uint64_t feed_soa_file(const SoaFile &file, Sink &sink, in
             }
             at += sp[p].n;
         }
+        const auto t_read = std::chrono::steady_clock::now();
         std::vector<char> fine(pieces.size(), 1);
         std::vector<std::thread> pool;
         for (size_t k = 1; k < pieces.size(); ++k)
             pool.emplace_back([&, k] { fine[k] = file.read(pieces[k].first, pieces[k].n, pieces[k].t, pieces[k].r, pieces[k].c) ? 1 : 0; });
         if (!pieces.empty()) fine[0] = file.read(pieces[0].first, pieces[0].n, pieces[0].t, pieces[0].r, pieces[0].c) ? 1 : 0;
         for (auto &th : pool) th.join();
+        if (read_seconds) *read_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read).count();
         for (char f : fine) if (!f) { *ok = false; return done; }
         sink.commit(got);
         done += got;

@@ -198,9 +198,17 @@ private:
             return r;
         };
         int rc;
+        static const bool phase_timing = std::getenv("BF_FARM_TIMING") != nullptr;   // debug: where a slice's time goes
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return 1e6 * std::chrono::duration<double>(b - a).count();
+        };
         if (t.n > 0) {
+            const auto t0 = now();
             if ((rc = bf_commit_upload(wk.ctx)) < 0) return fail(rc, "commit_upload");
+            const auto t1 = now();
             if ((rc = bf_set_cloud(wk.ctx, t.scale, t.res_x, t.res_y, &r.window)) < 0) return fail(rc, "set_cloud");
+            const auto t2 = now();
             if (t.warm == Warm::FromModel) rc = bf_set_model(wk.ctx, &t.start);
             else if (t.warm == Warm::FromPrevious && wk.have_last) rc = bf_set_model(wk.ctx, &wk.last_model);
             else if (t.warm == Warm::FromPrevious) { bf_model zero; std::memset(&zero, 0, sizeof(zero)); rc = bf_set_model(wk.ctx, &zero); }
@@ -211,7 +219,11 @@ private:
             rc = bf_run(wk.ctx, &o, &r.model, &r.info);
             if (rc < 0) return fail(rc, "run");
             r.rc = rc;
+            const auto t3 = now();
             if (t.uv_ring && (rc = bf_compute_uv_ring(wk.ctx, t.uv_ring, t.uv_cap, t.uv_first)) < 0) return fail(rc, "compute_uv_ring");
+            if (phase_timing)
+                std::fprintf(stderr, "farm worker %d slice %llu: since upload issue %.0f us | commit %.0f set_cloud %.0f run %.0f (%d it) uv %.0f us\n", wk.index,
+                             (unsigned long long)s.job.id, us(s.t_issue, t0), us(t0, t1), us(t1, t2), us(t2, t3), (int)r.info.iterations, us(t3, now()));
         } else {
             // the reference runs its optimizer on the empty cloud: x_min = RES_X, x_max = 0 (optimizer_rolling.h:252-260)
             // make a negative window, the guard of :49-55 skips it, and get_model() is the model set_model() stored

@@ -182,9 +182,11 @@ public:
         if (want > room) want = room;
         uint64_t prot = protected_from.load(std::memory_order_acquire);
         if (prot != UINT64_MAX && head + 1 > prot + cap) {   // not even one slot: wait for the oldest slice in flight
+            const auto t_wait = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> g(mu);
             cv.wait(g, [&] { prot = protected_from.load(std::memory_order_acquire); return failed || prot == UINT64_MAX || head + 1 <= prot + cap; });
             g.unlock();
+            blocked_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
             rethrow_failure();
         }
         if (prot != UINT64_MAX && head + want > prot + cap) want = (size_t)(prot + cap - head);
@@ -313,6 +315,7 @@ public:
     sll get_buf_size() { return (sll)size(); }
     sll get_time_diff() const { return time_diff; }
     ull events_seen() const { return head; }
+    double seconds_blocked() const { return blocked_s; }   // the producer waited this long in reserve() for slices in flight
 
     // DVS_flow::get_accumulated (dvs_flow.h:351-389): the events of all slices, each once, with the flow of the first
     // slice that solved it.  The marking rule is the reference's: walking the slices in order and, inside a slice, the
@@ -347,6 +350,7 @@ protected:
     uint8_t *noise;
     double *uv;
     uint64_t head;                // events committed so far
+    double blocked_s = 0;
     size_t ring_size;             // CircularArray::current_size
     bool stale;                   // !span_checked
     sll time_diff, event_diff;
@@ -414,6 +418,15 @@ protected:
         if (ring_size == 0) return;
         const ull newest = logical(head - 1);
         uint64_t oldest = head - ring_size;
+        if (assume_sorted) {   // the events too old form a prefix: find its end instead of walking it
+            uint64_t lo = oldest, hi = head - 1;   // (the newest event is never too old)
+            while (lo < hi) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                if ((sll)(newest - logical(mid)) > span) lo = mid + 1; else hi = mid;
+            }
+            ring_size -= (size_t)(lo - oldest);
+            return;
+        }
         while ((sll)(newest - logical(oldest)) > span) { ++oldest; --ring_size; }
     }
 
@@ -427,6 +440,7 @@ protected:
                                  [this](const SliceFarm::Result &r) { deliver(r); }, chained));
         size_t extra = lookahead ? lookahead : (max_sz > 65536 ? max_sz : 65536);
         cap = max_sz + extra;
+        for (size_t w = 0; w < farm->workers(); ++w) (void)bf_set_option(farm->context(w), "stream_prealloc", 1);   // staging slots, copy stream: now, not at the first slice
         bf_ctx *c = farm->context(0);
         void *p = nullptr;   // (pinned host memory is not tied to the ctx object)
         auto alloc = [&](size_t bytes) {

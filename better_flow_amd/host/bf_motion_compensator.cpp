@@ -312,7 +312,10 @@ int run_stream(const Options &o) {
     struct Past { ObjectModel model; size_t size; ull first_ts, last_ts; };   // what dvs_flow.h:245-252 prints per past slice
     std::vector<Past> memory;
     unsigned long long total_events = 0;
+    std::chrono::steady_clock::time_point t_first_slice;          // --timing: when the first (cold) slice was delivered
+    unsigned long long events_first_slice = 0;
     engine.on_slice([&](const bf::SliceRecord &r) {   // in slice order, on the worker's thread
+        if (r.index == 0) { t_first_slice = std::chrono::steady_clock::now(); events_first_slice = r.events_seen; }
         if (!o.quiet) {
             memory.push_back(Past{r.model, (size_t)r.events, r.events ? r.trigger_time : 0, r.oldest_time});
             std::cout << "\n\n------------------------\n";
@@ -332,14 +335,14 @@ int run_stream(const Options &o) {
     const double s_init = seconds_since(t_start);
 
     const auto t_read = std::chrono::steady_clock::now();
-    double s_flow = 0;
+    double s_flow = 0, s_read = 0;
     unsigned long long n_events = 0;
     if (!o.quiet && !o.bufferize) std::cout << "Reading " << o.input << " ..." << std::endl;
     if (bf::SoaFile::is_soa(o.input) && !o.bufferize) {
         // binary structure-of-arrays input: column blocks are read straight into the engine's pinned ring
         bf::SoaFile file(o.input);
         bool fine = file.good();
-        if (fine) n_events = bf::feed_soa_file(file, engine, o.threads, &fine);
+        if (fine) n_events = bf::feed_soa_file(file, engine, o.threads, &fine, &s_read);
         if (!fine) { std::fprintf(stderr, "cannot read '%s'\n", o.input.c_str()); return 1; }
     } else {
         // text "t x y p" (the reference's format), or --bufferize-file: the whole input first, then the flow
@@ -369,6 +372,8 @@ int run_stream(const Options &o) {
         engine.drain();
     }
     const double s_stream = seconds_since(t_read);
+    // the stream behind its first slice: a cold start (hundreds of iterations) followed by warm-started slices
+    const double s_steady = engine.get_slices_done() > 1 ? seconds_since(t_first_slice) : 0.0;
 
     const auto t_out = std::chrono::steady_clock::now();
     if (o.have_output) {
@@ -388,9 +393,11 @@ int run_stream(const Options &o) {
                   << "), minimizer iterations: " << engine.get_iterations_total() << std::endl;
     if (o.timing)
         std::fprintf(stderr, "{\"engine\": \"stream\", \"events\": %llu, \"slices\": %llu, \"iterations\": %llu, \"init_s\": %.6f, "
-                             "\"stream_s\": %.6f, \"output_s\": %.6f, \"total_s\": %.6f, \"mevents_per_s\": %.3f}\n",
+                             "\"stream_s\": %.6f, \"read_s\": %.6f, \"blocked_s\": %.6f, \"output_s\": %.6f, \"total_s\": %.6f, \"mevents_per_s\": %.3f, "
+                             "\"steady_s\": %.6f, \"steady_mevents_per_s\": %.3f}\n",
                      n_events, (unsigned long long)engine.get_slices_done(), (unsigned long long)engine.get_iterations_total(), s_init,
-                     s_stream, s_output, seconds_since(t_start), s_stream > 0 ? n_events / s_stream * 1e-6 : 0.0);
+                     s_stream, s_read, engine.seconds_blocked(), s_output, seconds_since(t_start), s_stream > 0 ? n_events / s_stream * 1e-6 : 0.0,
+                     s_steady, s_steady > 0 ? (n_events - events_first_slice) / s_steady * 1e-6 : 0.0);
     if (slice_log) std::fclose(slice_log);
     return 0;
 }

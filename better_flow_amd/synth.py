@@ -89,3 +89,24 @@ def write_bin(path, sl, time_offset_s=1.0):
         f.write(np.asarray(sl["fr_y"]).astype("<u2").tobytes())
         f.write(np.asarray(sl["fr_x"]).astype("<u2").tobytes())
         f.write(np.ones(len(t_ns), dtype=np.uint8).tobytes())
+
+
+def write_stream_bin(path, n_slices, events_per_slice, height, width, duration_s=0.030, seed=1, distinct=4):
+    """A rolling stream for the front-end measurements: n_slices consecutive `duration_s` blocks of ~events_per_slice
+    events, as one binary structure-of-arrays event file.  Only `distinct` different blocks are generated (seeds seed,
+    seed + 1, ...) and repeated round-robin with their times shifted, so a 20M-event file takes seconds to write.
+    Returns the number of events."""
+    blocks = [make_slice(events_per_slice, height, width, duration_s, seed=seed + k) for k in range(min(distinct, n_slices))]
+    step = np.uint64(int(round(duration_s * 1e9)))
+    with open(path, "wb") as f:
+        total = sum(len(blocks[i % len(blocks)]["t"]) for i in range(n_slices))
+        f.write(b"BFEVSOA1")
+        f.write(np.uint64(total).tobytes())
+        for i in range(n_slices):
+            f.write((blocks[i % len(blocks)]["t"].astype(np.uint64) + np.uint64(i) * step + np.uint64(1_000_000_000)).astype("<u8").tobytes())
+        for i in range(n_slices):
+            f.write(blocks[i % len(blocks)]["fr_y"].astype("<u2").tobytes())
+        for i in range(n_slices):
+            f.write(blocks[i % len(blocks)]["fr_x"].astype("<u2").tobytes())
+        f.write(np.ones(total, dtype=np.uint8).tobytes())
+    return total

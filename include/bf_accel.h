@@ -157,6 +157,9 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  spinning in hipEventSynchronize: 0.85 instead of 4.1 host cores for 4 slice contexts at the
  *                  same throughput.  0: spin.  Warm-started runs always spin (they wait for the batch just
  *                  launched; latency matters there).
+ *   "stream_prealloc"  1: create now what the asynchronous uploads (bf_upload_events_async / bf_upload_ring*_async) create
+ *                  on first use -- the copy stream, its events, both staging slots -- so that the first slice of a stream
+ *                  does not pay ~20 ms of allocations.
  *   "watchdog_ms"  a cold bf_run whose device iteration counter has not advanced for this long (wall clock, default
  *                  40000) stops with BF_ERR_HIP "device loop makes no progress" instead of waiting for ever.
  *   "bin_tile_rows"  tile HEIGHT (0 = default: chosen per slice among 32 .. 128 so that the bins -- one

@@ -177,6 +177,6 @@ void launch_color_time(const uint32_t* xy, const int32_t* t, const float2* p, co
                        const ColorGeom& g, uint32_t* cnt, unsigned long long* pc, unsigned long long* ps, uint8_t* bgr,
                        hipStream_t s);
 
-void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
+void launch_copy(const void* src, void* dst, long long bytes, int blocks, bool nontemporal, hipStream_t s);
 
 }  // namespace bf

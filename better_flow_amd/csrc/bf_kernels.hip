@@ -318,11 +318,29 @@ __global__ __launch_bounds__(kThreads) void k_expand_pr(const uint32_t* __restri
     pr[perm ? (long long)perm[i] : i] = make_double2(pr_from_p(v & 0xffffu, q.x), pr_from_p(v >> 16, q.y));
 }
 
+// Streaming-copy probe (bf_copy_bandwidth): every thread keeps four 16-byte loads in flight per round (consecutive
+// threads touch consecutive 16-byte words, the four loads of a thread are one work-group stride apart), then stores
+// them -- NT: with non-temporal stores, which do not allocate the destination lines in the L2.
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void k_copy_f4(const float4* __restrict__ src,
                                                       float4* __restrict__ dst, long long n4) {
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4;
-         i += (long long)gridDim.x * kThreads)
-        dst[i] = src[i];
+    const long long stride = (long long)gridDim.x * kThreads * 4;
+    for (long long base = (long long)blockIdx.x * kThreads * 4 + threadIdx.x; base < n4; base += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = base + (long long)k * kThreads;
+            if (i < n4) v[k] = NT ? __builtin_nontemporal_load(&src[i]) : src[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = base + (long long)k * kThreads;
+            if (i < n4) {
+                if (NT) __builtin_nontemporal_store(v[k], &dst[i]);
+                else dst[i] = v[k];
+            }
+        }
+    }
 }
 
 // Host -> device state hand-over.  The struct travels as a kernel argument (captured at
@@ -450,9 +468,11 @@ void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm,
                        s, xy, p, perm, pr, n);
 }
 
-void launch_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_copy_f4, dim3(2048), dim3(kThreads), 0, s, (const float4*)src, (float4*)dst,
-                       bytes / 16);
+void launch_copy(const void* src, void* dst, long long bytes, int blocks, bool nontemporal, hipStream_t s) {
+    if (nontemporal)
+        hipLaunchKernelGGL(k_copy_f4<true>, dim3(blocks), dim3(kThreads), 0, s, (const float4*)src, (float4*)dst, bytes / 16);
+    else
+        hipLaunchKernelGGL(k_copy_f4<false>, dim3(blocks), dim3(kThreads), 0, s, (const float4*)src, (float4*)dst, bytes / 16);
 }
 
 }  // namespace bf

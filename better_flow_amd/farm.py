@@ -44,10 +44,21 @@ class SliceSpec:
         self.arrays = arrays
 
     def load(self):
-        if self.arrays is not None:
-            return self.arrays
-        from . import synth
-        return synth.make_slice(self.events, self.height, self.width, self.duration_s, seed=self.seed)
+        if self.arrays is None:   # generated once, outside the farm's lanes (and outside any timed region: prepare())
+            from . import synth
+            self.arrays = synth.make_slice(self.events, self.height, self.width, self.duration_s, seed=self.seed)
+        return self.arrays
+
+    def count(self):
+        return len(self.arrays["t"]) if self.arrays is not None else self.events
+
+
+def prepare(specs, rank=0, world=1):
+    """Load (generate) the event arrays of this rank's slices up front -- the farm's lanes only move and solve them."""
+    for s in specs:
+        if s.index % world == rank:
+            s.load()
+    return specs
 
 
 def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-1, want_flow_digest=False, dist=None,
@@ -55,67 +66,101 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
     """The slice farm on the HIP path (dvs_flow.h:200-231's task queue, over ranks and slice contexts).
 
     Rank `rank` takes the slices i with i % world == rank and runs them with `concurrent` slice contexts (one host
-    thread + bf_ctx + HIP stream each: contexts pull the rank's slices from a shared queue, so a slow slice does not
-    hold the others up); every slice is a cold start (STM off: independent slices).  The per-slice records --
-    return code, iterations, the 88-byte model, events, milliseconds, optionally a digest of the per-event flow -- are
-    merged on every rank with all_gather_object when `dist` is an initialised torch.distributed (gloo: no data-path
-    collective exists on this path).  Returns {slice index: record}."""
+    thread + bf_ctx + HIP stream + copy stream each: contexts pull the rank's slices from a shared queue, so a slow slice
+    does not hold the others up); every slice is a cold start (STM off: independent slices).  A lane stages its next
+    slice in pinned memory and uploads it on its copy stream (bf_upload_events_async) while the current one is being
+    solved.  The per-slice records -- return code, iterations, the 88-byte model, events, milliseconds, optionally a digest
+    of the per-event flow, or the text of an error -- are merged on every rank with all_gather_object when `dist` is an
+    initialised torch.distributed (gloo: no data-path collective exists on this path).  An error in any lane of any rank
+    is raised on EVERY rank, after the gather (no rank is left waiting in a collective).  Returns {slice index: record}.
+    The native form of the same farm, for C++ callers and the command line, is better_flow/slice_farm.h."""
     import hashlib
     import queue
     import threading
     import time
+    import numpy as np
     from . import accel
     mine = [s for s in specs if s.index % world == rank]
     results = {}
     if mine:
-        loaded = {}
+        for s in mine:
+            s.load()
         hmax = max(s.height for s in mine)
         wmax = max(s.width for s in mine)
-        nmax = max(s.events for s in mine)
+        nmax = max(s.count() for s in mine)
         work = queue.Queue()
         for s in mine:
             work.put(s)
         lock = threading.Lock()
-        errors = []
 
         def lane():
+            a = None
+            cur = None
             try:
                 a = accel.Accel(device=device, max_events=nmax, max_rows=scale * hmax + scale, max_cols=scale * wmax + scale)
                 if concurrent > 1:
                     a.set_option("co_schedule", 1)
+                a.set_option("stream_prealloc", 1)
                 for k, v in (options or {}).items():
                     a.set_option(k, v)
                 o = a.default_opts()
-                while True:
+                pin = [[a.pinned_int32(nmax) for _ in range(3)] for _ in range(2)]   # two staging slots of pinned memory
+
+                def put(slot):
+                    """Take the next slice off the queue and start its upload; None when the queue is empty."""
                     try:
                         s = work.get_nowait()
                     except queue.Empty:
-                        break
+                        return None
                     sl = s.load()
-                    o.res_x, o.res_y, o.max_iter, o.want_uv = s.height, s.width, max_iter, 1 if want_flow_digest else 0
-                    t0 = time.perf_counter()
-                    a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
-                    a.set_cloud(scale, s.height, s.width)
+                    n = len(sl["t"])
+                    pin[slot][0][:n], pin[slot][1][:n], pin[slot][2][:n] = sl["fr_x"], sl["fr_y"], sl["t"]
+                    t_issue = time.perf_counter()
+                    if n > 0:
+                        a.upload_events_async(pin[slot][0], pin[slot][1], pin[slot][2], n)
+                    return s, n, t_issue
+
+                k = 0
+                nxt = put(0)
+                while nxt is not None:
+                    cur, n, t0 = nxt
+                    if n > 0:
+                        a.commit_upload()
+                    else:
+                        a.upload_events(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+                    k ^= 1
+                    nxt = put(k)          # the next slice's DMA overlaps this slice's solve
+                    o.res_x, o.res_y, o.max_iter, o.want_uv = cur.height, cur.width, max_iter, 1 if want_flow_digest else 0
+                    a.set_cloud(scale, cur.height, cur.width)
                     rc, m, info = a.run(o)
-                    rec = {"rc": int(rc), "iterations": int(info.iterations), "model": m.as_dict(), "events": len(sl["t"]),
-                           "rank": rank}
+                    rec = {"rc": int(rc), "iterations": int(info.iterations), "model": m.as_dict(), "events": n, "rank": rank}
                     if want_flow_digest:
                         u, v = a.compute_uv()
                         rec["flow_sha1"] = hashlib.sha1(u.tobytes() + v.tobytes()).hexdigest()
                     a.synchronize()
                     rec["ms"] = 1e3 * (time.perf_counter() - t0)
                     with lock:
-                        results[s.index] = rec
-                a.close()
-            except Exception as e:   # noqa: BLE001 -- reported to the caller below
-                errors.append(e)
+                        results[cur.index] = rec
+                    cur = None
+            except Exception as e:   # noqa: BLE001 -- travels with the records, raised after the gather
+                with lock:
+                    results[("error", rank, threading.get_ident())] = {"error": "%s: %s" % (type(e).__name__, e),
+                                                                       "slice": None if cur is None else cur.index, "rank": rank}
+            finally:
+                if a is not None:
+                    try:
+                        a.close()
+                    except Exception:   # noqa: BLE001
+                        pass
 
         threads = [threading.Thread(target=lane) for _ in range(max(1, min(concurrent, len(mine))))]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
-        if errors:
-            raise errors[0]
-        del loaded
-    return gather(results, dist)
+    merged = gather(results, dist)
+    errors = [v for k, v in merged.items() if isinstance(k, tuple)]
+    if errors:
+        raise RuntimeError("slice farm: %d lane(s) failed; first: rank %s, slice %s: %s" %
+                           (len(errors), errors[0]["rank"], errors[0]["slice"], errors[0]["error"]))
+    return merged

@@ -40,8 +40,16 @@ def _check(d, n_gpus, steps, warmup):
 
 @pytest.mark.gpu
 def test_bench_single_process():
-    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-iters", "8", "--cpu-cores", "2"])
+    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-iters", "8", "--cpu-cores", "2",
+               "--front-end-slices", "8"])
     _check(d, 1, 3, 1)
+    fe = d["front_end"]                  # the command-line front end: file -> last model
+    assert "error" not in fe, fe
+    assert fe["file_to_last_model"]["slices"] == 8 and fe["steady_state_warm"]["mevents_per_s"] > 100
+    assert fe["with_flow_output"]["output_s"] > 0
+    assert d["value_host_to_host"] == d["regimes"]["host_to_host"]["cold"]["mevents_per_s"]
+    assert d["targets"]["met_by"]["mevents_per_s"] > 1000          # north_star: >= 1 Gevents/s (warm STM, H2D included)
+    assert 0 < d["roofline"]["iteration_frac"] < 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -107,7 +107,7 @@ EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
     "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_upload_events", "bf_upload_events_device",
     "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
-    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_tiles", "bf_get_trace",
+    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_many", "bf_run_tiles", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
@@ -117,6 +117,21 @@ EXPORTS = [
 ]
 
 _lib = None
+
+
+def run_many(accels, opts=None):
+    """bf_run_many: the slices staged on `accels` (Accel objects, each after upload + set_cloud) solved together.
+    Returns [(rc, Model, RunInfo)]."""
+    n = len(accels)
+    L = load()
+    hs = (C.c_void_p * n)(*[a.h for a in accels])
+    models = (Model * n)()
+    infos = (RunInfo * n)()
+    rc = L.bf_run_many(hs, n, C.byref(opts) if opts is not None else None, models, infos)
+    if rc < 0:
+        bad = next((a for a, i in zip(accels, infos) if i.rc < 0), accels[0])
+        raise BfError(rc, L.bf_last_error(bad.h).decode())
+    return [(infos[i].rc, models[i], infos[i]) for i in range(n)]
 
 
 class BfError(RuntimeError):
@@ -166,6 +181,7 @@ def load():
         L.bf_set_model.argtypes = [C.c_void_p, C.POINTER(Model)]
         L.bf_run.argtypes = [C.c_void_p, C.POINTER(RunOpts), C.POINTER(Model), C.POINTER(RunInfo)]
         L.bf_run_tiles.argtypes = [C.c_void_p, C.POINTER(TileOpts), C.c_void_p, C.c_void_p]
+        L.bf_run_many.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RunOpts), C.c_void_p, C.c_void_p]
         L.bf_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.bf_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.bf_profile_reset.argtypes = [C.c_void_p]

@@ -15,6 +15,7 @@
 #include <ctime>
 #include <new>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "bf_device.h"
@@ -1720,6 +1721,30 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (info) *info = inf;
     if (d.rc < 0) return fail(c, d.rc, "iteration cap (%d) reached without convergence", o.hard_iter_cap);
     return d.rc;
+}
+
+int bf_run_many(bf_ctx* const* ctxs, int32_t n, const bf_run_opts* opts, bf_model* models_out, bf_run_info* infos_out) {
+    if (!ctxs || n < 0) return BF_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return BF_ERR_ARG;
+        for (int k = 0; k < i; ++k)
+            if (ctxs[k] == ctxs[i]) return fail(ctxs[i], BF_ERR_ARG, "bf_run_many: context %d is also context %d (a context holds one slice)", i, k);
+    }
+    std::vector<int> rc((size_t)n, BF_OK);
+    auto one = [&](int i) {
+        bf_model m;
+        bf_run_info inf;
+        rc[(size_t)i] = bf_run(ctxs[i], opts, &m, &inf);
+        if (models_out) models_out[i] = m;
+        if (infos_out) { infos_out[i] = inf; infos_out[i].rc = rc[(size_t)i]; }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back(one, i);
+    if (n > 0) one(0);
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i)
+        if (rc[(size_t)i] < 0) return rc[(size_t)i];
+    return BF_OK;
 }
 
 int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_info* infos_out) {

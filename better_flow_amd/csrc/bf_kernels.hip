@@ -321,12 +321,13 @@ __global__ __launch_bounds__(kThreads) void k_expand_pr(const uint32_t* __restri
 // Streaming-copy probe (bf_copy_bandwidth): every thread keeps four 16-byte loads in flight per round (consecutive
 // threads touch consecutive 16-byte words, the four loads of a thread are one work-group stride apart), then stores
 // them -- NT: with non-temporal stores, which do not allocate the destination lines in the L2.
+typedef float bf_v4f __attribute__((ext_vector_type(4)));
 template <bool NT>
-__global__ __launch_bounds__(kThreads) void k_copy_f4(const float4* __restrict__ src,
-                                                      float4* __restrict__ dst, long long n4) {
+__global__ __launch_bounds__(kThreads) void k_copy_f4(const bf_v4f* __restrict__ src,
+                                                      bf_v4f* __restrict__ dst, long long n4) {
     const long long stride = (long long)gridDim.x * kThreads * 4;
     for (long long base = (long long)blockIdx.x * kThreads * 4 + threadIdx.x; base < n4; base += stride) {
-        float4 v[4];
+        bf_v4f v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const long long i = base + (long long)k * kThreads;
@@ -470,9 +471,9 @@ void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm,
 
 void launch_copy(const void* src, void* dst, long long bytes, int blocks, bool nontemporal, hipStream_t s) {
     if (nontemporal)
-        hipLaunchKernelGGL(k_copy_f4<true>, dim3(blocks), dim3(kThreads), 0, s, (const float4*)src, (float4*)dst, bytes / 16);
+        hipLaunchKernelGGL(k_copy_f4<true>, dim3(blocks), dim3(kThreads), 0, s, (const bf_v4f*)src, (bf_v4f*)dst, bytes / 16);
     else
-        hipLaunchKernelGGL(k_copy_f4<false>, dim3(blocks), dim3(kThreads), 0, s, (const float4*)src, (float4*)dst, bytes / 16);
+        hipLaunchKernelGGL(k_copy_f4<false>, dim3(blocks), dim3(kThreads), 0, s, (const bf_v4f*)src, (bf_v4f*)dst, bytes / 16);
 }
 
 }  // namespace bf

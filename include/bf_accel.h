@@ -298,6 +298,15 @@ typedef struct bf_tile_opts {
 } bf_tile_opts;
 int bf_run_tiles(bf_ctx *ctx, const bf_tile_opts *opts, bf_model *models_out, bf_run_info *infos_out);
 
+/* A batch of independent slices -- the reference's queue of (events, model) tasks (dvs_flow.h:200-231, executed there
+ * one after the other) -- solved together: bf_run on each of the n contexts, all in flight at once (one host thread per
+ * context inside the library; the contexts' streams share the GPU, set "co_schedule" on them when n > 1).  Every
+ * context must hold its own slice (upload + bf_set_cloud [+ bf_set_model]).  models_out / infos_out: n entries (either
+ * may be NULL); infos_out[i].rc is that slice's return code.  Returns BF_OK when every slice returned 0 or 1, else the
+ * first error code (the text is on that context: bf_last_error).  For slices spread over several GPUs and for streams
+ * of slices, see better_flow/slice_farm.h, which drives the same entry points. */
+int bf_run_many(bf_ctx *const *ctxs, int32_t n, const bf_run_opts *opts, bf_model *models_out, bf_run_info *infos_out);
+
 /* Records of the last bf_run (opts->trace_cap > 0): model and dividers after every iteration_step -- what the
  * reference prints under VERBOSE (optimizer_rolling.h:116-118) or shows in manual() (:212).  Returns the number written. */
 int bf_get_trace(bf_ctx *ctx, bf_trace_rec *out, int32_t cap, int32_t *written);

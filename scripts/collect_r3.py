@@ -1,0 +1,74 @@
+"""Copy the judged round-3 rocprofv3 summaries from gpurun_out/prof_r3 into profiles/ (tracked)."""
+import csv, collections, statistics, re, glob, os, shutil, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_r3")
+out = os.path.join(ROOT, "profiles")
+def kname(n):
+    m = re.search(r"(k_[a-z_0-9]+)(<[^>(]*>)?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n[:40]
+for d, name in (("solo_head", "r3_solo_kernel_stats.csv"), ("solo_tail", "r3_solo_tail_kernel_stats.csv"), ("bench", "r3_bench_kernel_stats.csv")):
+    ks = glob.glob(os.path.join(src, d, "**/*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(out, name))
+def counter_files(d):
+    return glob.glob(os.path.join(src, d, "**/*counter_collection.csv*"), recursive=True)
+traffic, lines = {}, []
+for geo in ("346x260", "640x480", "1280x720"):
+    rec = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        fs = counter_files("%s_%s" % (cname, geo))
+        if not fs:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if r["Counter_Name"] == cname:
+                acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            live = [x for x in v if x > 64] or [0.0]
+            lines.append("%-8s %-11s %-40s dispatches %5d  live %5d  median %12.1f KB  mean %12.1f KB" %
+                         (geo, cname, k, len(v), len(live), statistics.median(live), sum(live) / len(live)))
+            if k.startswith("k_bin_warp_scatter") and "<true" in k:
+                rec["fetch_kb" if cname == "FETCH_SIZE" else "write_kb"] = statistics.median(live)
+                rec["kernel"] = k
+    if len(rec) >= 3:
+        traffic[geo + "x3"] = rec
+if traffic:
+    traffic["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/profile_r3.sh), median over the live launches "
+                         "of the warp+scatter kernel of one cold 1M-event slice per geometry; FETCH_SIZE is doubled by the reader (gfx950)")
+    json.dump(traffic, open(os.path.join(out, "k1_traffic.json"), "w"), indent=1)
+open(os.path.join(out, "r3_pmc_hbm_traffic.txt"), "w").write(
+    "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over one cold 1M-event\n"
+    "slice per geometry (scripts/run_once.py 1 co_schedule=1; 640x480 and 1280x720: first 300 iterations).  KB per dispatch;\n"
+    "'live' excludes the early-exit launches after convergence.  On gfx950 FETCH_SIZE under-reports wide coalesced reads\n"
+    "by 2x (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n\n" + "\n".join(lines) + "\n")
+for d, name in (("sq_720", "r3_pmc_sq_720p.txt"), ("sq_346", "r3_pmc_sq_issue.txt")):
+    fs = counter_files(d)
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(fs[0])):
+        k = kname(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen[k].add(r["Dispatch_Id"])
+    rows = ["rocprofv3 --kernel-trace --pmc SQ_* (own pass) over one cold slice (%s), per launch, summed over the device." % d,
+            "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.", ""]
+    for k in sorted(agg, key=lambda k: -agg[k]["SQ_BUSY_CYCLES"])[:6]:
+        a, n = agg[k], len(seen[k])
+        wc = a["SQ_WAVE_CYCLES"] or 1.0
+        rows.append("%-40s launches %4d  waves %6.0f  VALU insts/wave %6.0f  wave-cycles: active %4.1f%% (VALU %4.1f%%)  "
+                    "wait(s_waitcnt/barrier) %4.1f%%  issue-stall %4.1f%%" %
+                    (k, n, a["SQ_WAVES"] / n, a["SQ_INSTS_VALU"] / max(a["SQ_WAVES"], 1), 100 * a["SQ_ACTIVE_INST_ANY"] / wc,
+                     100 * a["SQ_ACTIVE_INST_VALU"] / wc, 100 * a["SQ_WAIT_ANY"] / wc, 100 * a["SQ_WAIT_INST_ANY"] / wc))
+    open(os.path.join(out, name), "w").write("\n".join(rows) + "\n")
+    print("\n".join(rows))
+bl = os.path.join(src, "bench.log")
+if os.path.exists(bl):
+    for ln in open(bl):
+        if ln.startswith('{"metric"'):
+            open(os.path.join(out, "r3_bench_under_rocprof.json"), "w").write(ln)
+print(open(os.path.join(out, "r3_pmc_hbm_traffic.txt")).read())
+for f in ("r3_solo_kernel_stats.csv", "r3_solo_tail_kernel_stats.csv"):
+    p = os.path.join(out, f)
+    if os.path.exists(p):
+        print(f); print("".join(open(p).readlines()[:6]))

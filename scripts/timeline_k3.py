@@ -8,6 +8,7 @@ N, H, W, s = 1000000, int(os.environ.get("BF_RUN_H", "260")), int(os.environ.get
 sl = synth.make_slice(N, H, W, 0.030, seed=1)
 acc = accel.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
 opts = acc.default_opts(); opts.res_x, opts.res_y = H, W
+if os.environ.get('BF_CO'): acc.set_option('co_schedule', int(os.environ['BF_CO']))
 opts.max_iter = int(os.environ.get("BF_RUN_MAXITER", "40"))
 acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]); acc.set_cloud(s, H, W)
 rc, m, info = acc.run(opts)

@@ -38,13 +38,22 @@ def slice_digest(sl):
     return h.hexdigest()
 
 
+def event_order(n, member):
+    """Member 0: upload order; 1: reversed; k >= 2: the permutation numpy's default_rng(k) draws."""
+    if member == 0:
+        return np.arange(n)
+    if member == 1:
+        return np.arange(n)[::-1].copy()
+    return np.random.default_rng(member).permutation(n)
+
+
 def one_run(args):
-    seed, reverse = args
+    seed, member = args
     import oracle
     from better_flow_amd import synth
     sl = synth.make_slice(N, H, W, T, seed=seed)
     n = len(sl["t"])
-    order = np.arange(n)[::-1].copy() if reverse else np.arange(n)
+    order = event_order(n, member)
     oc = oracle.Cloud(sl["fr_x"][order], sl["fr_y"][order], sl["t"][order])
     ow = oc.set_cloud(S, H, W)
     om = oracle.Model()
@@ -62,8 +71,10 @@ def one_run(args):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--ensemble":
+        return ensemble(int(sys.argv[2]), [int(a) for a in sys.argv[3:]] or [1])
     seeds = [int(a) for a in sys.argv[1:]] or [1]
-    jobs = [(s, r) for s in seeds for r in (False, True)]
+    jobs = [(s, r) for s in seeds for r in (0, 1)]
     with mp.get_context("spawn").Pool(len(jobs)) as pool:
         res = pool.map(one_run, jobs)
     for i, seed in enumerate(seeds):
@@ -87,6 +98,29 @@ def main():
         np.savez_compressed(path, **out)
         print("%s: forward %d iterations (rc %d), reversed %d (rc %d); flow spread %.3e / %.3e px/s" %
               (path, f["iterations"], f["rc"], r["iterations"], r["rc"], out["spread_u"], out["spread_v"]))
+
+
+def ensemble(members, seeds):
+    """python make_config5_golden.py --ensemble K [seed ...]: K more members per seed -- the oracle on K seeded random
+    permutations of the slice's events (event_order members 2 .. K + 1) -- into config5_720p_seed<S>_ensemble.npz.
+    Forward and reversed stay together on seed 0 (7355 / 7344 iterations) while a third order of the same events can
+    take another branch of the loop's divider doublings (optimizer_rolling.h:98-101: a divider doubles whenever its
+    gradient component changes sign between two iterations -- near the optimum that is decided by the last bits);
+    the ensemble shows how wide the reference's own answer is, and is the yardstick of the GPU test."""
+    jobs = [(s, m) for s in seeds for m in range(2, 2 + members)]
+    with mp.get_context("spawn").Pool(min(len(jobs), os.cpu_count() or 1)) as pool:
+        res = pool.map(one_run, jobs, chunksize=1)
+    for i, seed in enumerate(seeds):
+        rs = res[i * members:(i + 1) * members]
+        idx = np.linspace(0, rs[0]["n"] - 1, SAMPLES).astype(np.int64)
+        out = dict(seed=seed, members=np.arange(2, 2 + members), input_sha256=rs[0]["digest"], sample_idx=idx, fields=np.array(FIELDS),
+                   percentiles=np.array(PCT), rc=np.array([r["rc"] for r in rs]), iterations=np.array([r["iterations"] for r in rs]),
+                   dividers=np.array([r["dividers"] for r in rs]), model=np.array([r["model"] for r in rs]),
+                   u=np.array([r["u"][idx] for r in rs]), v=np.array([r["v"][idx] for r in rs]),
+                   u_pct=np.array([np.percentile(r["u"], PCT) for r in rs]), v_pct=np.array([np.percentile(r["v"], PCT) for r in rs]))
+        path = os.path.join(HERE, "config5_720p_seed%d_ensemble.npz" % seed)
+        np.savez_compressed(path, **out)
+        print("%s: iterations %s" % (path, out["iterations"].tolist()))
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ Bars.  Return code (0 / 1 skipped / NOCONV) equal for every tile.  Iteration cou
 1e-4 relative / 0.02 px/s against the oracle on the tile's events in upload order -- or, for a tile whose
 ORACLE run is itself sensitive to the order of its events (the reference's f32 time sums are order dependent,
 accel_lib.h:162; a loop on ~1000 events amplifies that into different iteration counts), the same bar against the
-oracle on SOME permutation of the tile's events (reversed, or one of 12 seeded random ones).  The number of tiles that
+oracle on SOME permutation of the tile's events (reversed, or one of 120 seeded random ones).  The number of tiles that
 need a permutation is printed and bounded.
 """
 import numpy as np
@@ -95,10 +95,11 @@ def test_config4_full_size_every_tile_against_its_oracle(oracle_lib, accel_mod):
         # The reference's result depends on the ORDER of a tile's events (f32 running time sums, accel_lib.h:162), and a
         # loop on ~1000 events amplifies that: the oracle itself ends after 56, 119 or 32 iterations on tile 291, depending
         # on the permutation.  The GPU's integer sums are order free, so it must reproduce the reference's answer for SOME
-        # order: the same bar against the reversed order or one of 12 seeded random permutations.
+        # order: the same bar against the reversed order or one of 120 seeded random permutations (a branch the oracle
+        # takes on 3 of 40 permutations -- tile 649 -- is missed by 120 draws once in 10 000 runs).
         rng = np.random.default_rng(1000 + k)
         hit = None
-        for trial in range(13):
+        for trial in range(121):
             perm = np.arange(len(sel))[::-1].copy() if trial == 0 else rng.permutation(len(sel))
             if agrees(oracle_lib, sl, sel[perm], u[sel][perm], v[sel][perm], git)[0]:
                 hit = trial

@@ -218,3 +218,49 @@ def test_config2_cold_to_convergence_against_oracle(oracle_lib, accel_mod):
     assert _flow_close(u, ou) and _flow_close(v, ov)
     for f in ("total_dx", "total_dy", "total_rot", "total_div"):
         assert abs(getattr(m, f) - getattr(om, f)) <= 1e-4 * max(abs(getattr(om, f)), 1e-6), f
+
+
+@pytest.mark.parametrize("seed", [1, 0])
+def test_config5_to_termination_against_golden(accel_mod, seed):
+    """BASELINE config 5's slice (1M events, 1280x720, scale 3) cold to the loop's OWN termination (optimizer_rolling.h:
+    76-101): thousands of iterations, where test_large_geometry_against_oracle compares the first 41.  The oracle needs
+    ~25 minutes for that, so its result is a committed fixture (tests/golden/config5_720p_seed<S>.npz, written by
+    tests/golden/make_config5_golden.py: the oracle on the slice's events forward AND reversed -- both are "the
+    reference's answer", accel_lib.h:162 makes it order dependent; seed 1: 4906 / 4949 iterations, per-event flow up to
+    1.3 px/s apart on ~1500 px/s; seed 0: 7355 / 7344 and 4.6 px/s).  Bars: same return code and final dividers; iteration
+    count within 4 x the two oracle runs' difference (+ 1 %); converged per-event flow at 4096 sampled events and its
+    percentiles within north_star's 1e-4 / 0.02 px/s + 4 x the oracle's own forward / reversed spread over ALL events;
+    total_dx / total_dy likewise against their spread."""
+    import hashlib
+    import os
+    H, W, s = 720, 1280, 3
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_720p_seed%d.npz" % seed))
+    assert tuple(z["geometry"]) == (H, W, s)
+    sl = synth.make_slice(1000000, H, W, 0.030, seed=seed)
+    h = hashlib.sha256()
+    for k in ("fr_x", "fr_y", "t"):
+        h.update(np.ascontiguousarray(sl[k]).tobytes())
+    assert h.hexdigest() == str(z["input_sha256"]), "the generator no longer produces the fixture's slice"
+    rc, m, info, _, u, v = _gpu_run(accel_mod, sl, H, W, s, -1, 0)
+    it_f, it_r = int(z["fwd_iterations"]), int(z["rev_iterations"])
+    assert rc == int(z["fwd_rc"]) == int(z["rev_rc"]) == 0
+    assert abs(info.iterations - it_f) <= 4 * abs(it_f - it_r) + it_f // 100, (info.iterations, it_f, it_r)
+    assert (info.x_divider, info.y_divider, info.rot_divider, info.div_divider) == tuple(float(x) for x in z["fwd_dividers"])
+    idx = z["sample_idx"]
+    fields = [str(f) for f in z["fields"]]
+    worst = 0.0
+    for g_, f_, r_, spread in ((u, z["fwd_u"], z["rev_u"], float(z["spread_u"])), (v, z["fwd_v"], z["rev_v"], float(z["spread_v"]))):
+        d = np.abs(g_[idx] - f_)
+        worst = max(worst, d.max() / spread)
+        assert np.all(d <= np.maximum(1e-4 * np.abs(f_), 0.02) + 4.0 * spread), (d.max(), spread)
+        assert np.abs(f_ - r_).max() <= spread
+    for g_, key, spread in ((u, "fwd_u_pct", float(z["spread_u"])), (v, "fwd_v_pct", float(z["spread_v"]))):
+        gp = np.percentile(g_, z["percentiles"])
+        assert np.all(np.abs(gp - z[key]) <= np.maximum(1e-4 * np.abs(z[key]), 0.02) + 4.0 * spread), (gp, z[key])
+    for f in ("total_dx", "total_dy", "total_rot", "total_div"):
+        k = fields.index(f)
+        sp = abs(z["fwd_model"][k] - z["rev_model"][k])
+        assert abs(getattr(m, f) - z["fwd_model"][k]) <= 4.0 * sp + 1e-4 * abs(z["fwd_model"][k]) + 1e-9, (f, getattr(m, f), z["fwd_model"][k], sp)
+    print("config 5 seed %d to termination: GPU %d iterations, oracle %d forward / %d reversed; flow deviation at most %.2f x the "
+          "oracle's own forward / reversed spread (%.2f / %.2f px/s)" % (seed, info.iterations, it_f, it_r, worst,
+                                                                       float(z["spread_u"]), float(z["spread_v"])))

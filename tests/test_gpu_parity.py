@@ -1161,3 +1161,37 @@ def test_spinning_poll_with_long_batches(accel_mod):
     assert go(binned=2, blocking_poll=0, poll=256) == want
     assert go(binned=2, blocking_poll=0, poll=256, co_schedule=1) == want
     assert go(binned=2, blocking_poll=0, poll=256, watchdog_ms=2000) == want
+
+
+def test_run_many_equals_one_by_one(accel_mod):
+    """bf_run_many: three independent slices (different sizes, one of them skipped by the 1000-event guard) solved
+    together give, slice by slice, the bits of bf_run on a context alone -- return code, iterations, model, flow."""
+    H, W, s = 180, 240, 3
+    sls = [synth.make_slice(n, H, W, 0.04, seed=70 + k) for k, n in enumerate((60000, 25000, 700))]
+
+    def stage(sl, co):
+        a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+        a.set_option("co_schedule", co)
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        a.set_cloud(s, H, W)
+        return a
+
+    o = None
+    alone = []
+    for sl in sls:
+        a = stage(sl, 0)
+        oo = a.default_opts()
+        oo.res_x, oo.res_y, oo.want_uv = H, W, 1
+        rc, m, info = a.run(oo)
+        alone.append((rc, m.as_dict(), info.iterations) + (a.compute_uv() if rc == 0 else ()))
+        o = oo
+        a.close()
+    accs = [stage(sl, 1) for sl in sls]
+    got = accel_mod.run_many(accs, o)
+    for (rc, m, info), a, want in zip(got, accs, alone):
+        assert (rc, m.as_dict(), info.iterations) == want[:3]
+        if rc == 0:
+            u, v = a.compute_uv()
+            assert np.array_equal(u, want[3]) and np.array_equal(v, want[4])
+        a.close()
+    assert [w[0] for w in alone] == [0, 0, 1]

@@ -10,7 +10,9 @@
 //
 // Every worker keeps up to two uploads in flight ahead of the slice it is solving (the two staging slots of
 // bf_upload_ring16_async / bf_upload_events_async), so the host-to-device copy of slice k + 1 overlaps the solve of
-// slice k on the same worker.
+// slice k on the same worker.  With a single worker (a stream's chain) submit() itself starts the copy when a staging
+// slot is free -- the worker is inside bf_run then and would not look at the queue before it returns; the upload /
+// commit entry points touch only the context's staging state, and a mutex keeps them apart from each other.
 //
 // Warm starts.  Task::warm = FromPrevious is the reference's short-term memory (dvs_flow.h:218-224): start from the
 // model the PREVIOUS task ended with.  That is a sequential chain, so it needs a farm with exactly one worker (the
@@ -83,7 +85,7 @@ public:
         if (devices.empty() || contexts_per_device < 1) throw AccelError(BF_ERR_ARG, "SliceFarm: no workers");
         const size_t nw = devices.size() * (size_t)contexts_per_device;
         if (chained && nw != 1) throw AccelError(BF_ERR_ARG, "SliceFarm: a warm-start chain is sequential and needs exactly one worker");
-        workers_.resize(nw);
+        for (size_t w = 0; w < nw; ++w) workers_.emplace_back();
         for (size_t w = 0; w < nw; ++w) {
             Worker &wk = workers_[w];
             wk.index = (int)w;
@@ -117,12 +119,37 @@ public:
     // Queue a task; returns its id (0, 1, 2, ... in submission order).  The arrays it points to must stay valid and
     // unchanged until its result has been delivered.
     uint64_t submit(const Task &t) {
-        std::unique_lock<std::mutex> g(mu_);
-        const uint64_t id = next_id_++;
-        queue_.push_back(Job{id, t});
-        g.unlock();
+        Job job;
+        job.task = t;
+        job.t_issue = std::chrono::steady_clock::now();
+        job.uploaded = t.n <= 0;   // nothing to copy
+        if (workers_.size() == 1 && t.n > 0) {
+            // a single worker: start the copy from here if a staging slot is free and no older task still waits for one
+            Worker &wk = workers_[0];
+            std::lock_guard<std::mutex> up(wk.up_mu);
+            bool can;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                job.id = next_id_++;
+                can = waiting_for_slot_ == 0 && wk.slots < 2;
+            }
+            if (can) {
+                job.upload_rc = issue_upload(wk.ctx, t);
+                job.uploaded = true;
+                if (job.upload_rc >= 0) ++wk.slots;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!job.uploaded) ++waiting_for_slot_;
+                queue_.push_back(job);
+            }
+        } else {
+            std::lock_guard<std::mutex> g(mu_);
+            job.id = next_id_++;
+            queue_.push_back(job);
+        }
         cv_work_.notify_one();
-        return id;
+        return job.id;
     }
 
     // Block until every task submitted so far has been delivered.
@@ -136,8 +163,11 @@ public:
 
 private:
     struct Job {
-        uint64_t id;
+        uint64_t id = 0;
         Task task;
+        bool uploaded = false;     // its copy has been issued (or it has no events)
+        int upload_rc = 0;         // < 0: issuing the copy failed; reported when the task's turn comes
+        std::chrono::steady_clock::time_point t_issue;
     };
     struct Worker {
         int index = 0, device = 0;
@@ -145,20 +175,20 @@ private:
         std::thread thread;
         bf_model last_model;       // Warm::FromPrevious
         bool have_last = false;
+        std::mutex up_mu;          // serialises bf_upload_*_async / bf_commit_upload on this context (worker and submit())
+        int slots = 0;             // staging slots in use: copies issued and not yet committed (under up_mu)
     };
-    struct Staged {
-        Job job;
-        std::chrono::steady_clock::time_point t_issue;
-    };
+    typedef Job Staged;
 
     ResultFn on_result_;
     bool chained_;
-    std::vector<Worker> workers_;
+    std::deque<Worker> workers_;   // (a Worker holds a mutex: no moves)
     mutable std::mutex mu_;
     std::condition_variable cv_work_, cv_done_;
     std::deque<Job> queue_;
     std::map<uint64_t, Result> finished_;   // done, waiting for an earlier id
     uint64_t next_id_ = 0, delivered_ = 0;
+    int waiting_for_slot_ = 0;              // queued tasks whose copy has not been issued yet (single-worker farms)
     bool stopping_ = false;
 
     static int issue_upload(bf_ctx *ctx, const Task &t) {
@@ -186,9 +216,9 @@ private:
     }
 
     Result solve(Worker &wk, const Staged &s) {
-        const Task &t = s.job.task;
+        const Task &t = s.task;
         Result r;
-        r.id = s.job.id; r.user = t.user; r.worker = wk.index; r.device = wk.device;
+        r.id = s.id; r.user = t.user; r.worker = wk.index; r.device = wk.device;
         std::memset(&r.info, 0, sizeof(r.info));
         std::memset(&r.model, 0, sizeof(r.model));
         std::memset(&r.window, 0, sizeof(r.window));
@@ -203,9 +233,15 @@ private:
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return 1e6 * std::chrono::duration<double>(b - a).count();
         };
+        if (s.upload_rc < 0) return fail(s.upload_rc, "upload");
         if (t.n > 0) {
             const auto t0 = now();
-            if ((rc = bf_commit_upload(wk.ctx)) < 0) return fail(rc, "commit_upload");
+            {
+                std::lock_guard<std::mutex> up(wk.up_mu);
+                rc = bf_commit_upload(wk.ctx);
+                --wk.slots;
+            }
+            if (rc < 0) return fail(rc, "commit_upload");
             const auto t1 = now();
             if ((rc = bf_set_cloud(wk.ctx, t.scale, t.res_x, t.res_y, &r.window)) < 0) return fail(rc, "set_cloud");
             const auto t2 = now();
@@ -223,7 +259,7 @@ private:
             if (t.uv_ring && (rc = bf_compute_uv_ring(wk.ctx, t.uv_ring, t.uv_cap, t.uv_first)) < 0) return fail(rc, "compute_uv_ring");
             if (phase_timing)
                 std::fprintf(stderr, "farm worker %d slice %llu: since upload issue %.0f us | commit %.0f set_cloud %.0f run %.0f (%d it) uv %.0f us\n", wk.index,
-                             (unsigned long long)s.job.id, us(s.t_issue, t0), us(t0, t1), us(t1, t2), us(t2, t3), (int)r.info.iterations, us(t3, now()));
+                             (unsigned long long)s.id, us(s.t_issue, t0), us(t0, t1), us(t1, t2), us(t2, t3), (int)r.info.iterations, us(t3, now()));
         } else {
             // the reference runs its optimizer on the empty cloud: x_min = RES_X, x_max = 0 (optimizer_rolling.h:252-260)
             // make a negative window, the guard of :49-55 skips it, and get_model() is the model set_model() stored
@@ -246,52 +282,54 @@ private:
     }
 
     void work(Worker &wk) {
-        std::deque<Staged> staged;        // uploads in flight on this worker, oldest first (at most two)
-        int uploads = 0;                  // ... of which this many occupy a staging slot (tasks with n > 0)
+        std::deque<Staged> staged;        // tasks this worker has taken, oldest first; their copies are in flight
         for (;;) {
-            // top the upload pipeline up; block only when there is nothing to solve
-            for (;;) {
-                Job job;
-                {
-                    std::unique_lock<std::mutex> g(mu_);
-                    if (staged.empty()) cv_work_.wait(g, [this] { return stopping_ || !queue_.empty(); });
-                    if (queue_.empty() || uploads >= 2) break;
-                    job = queue_.front();
-                    queue_.pop_front();
-                }
-                Staged s{job, std::chrono::steady_clock::now()};
-                if (job.task.n > 0) {
-                    const int rc = issue_upload(wk.ctx, job.task);
-                    if (rc < 0) {
-                        Result r;
-                        r.id = job.id; r.user = job.task.user; r.rc = rc; r.worker = wk.index; r.device = wk.device;
-                        std::memset(&r.info, 0, sizeof(r.info)); std::memset(&r.model, 0, sizeof(r.model)); std::memset(&r.window, 0, sizeof(r.window));
-                        r.error = std::string("SliceFarm: upload failed (") + std::to_string(rc) + "): " + bf_last_error(wk.ctx);
-                        // results must stay in order behind the slices staged before it: solve those first
-                        while (!staged.empty()) { publish(solve(wk, staged.front())); if (staged.front().job.task.n > 0) --uploads; staged.pop_front(); }
-                        publish(std::move(r));
-                        continue;
+            {   // sleep only when there is nothing to solve
+                std::unique_lock<std::mutex> g(mu_);
+                if (staged.empty()) cv_work_.wait(g, [this] { return stopping_ || !queue_.empty(); });
+                if (stopping_ && queue_.empty() && staged.empty()) return;
+            }
+            {   // take tasks while staging slots last: those whose copy submit() already started, then copies of our own
+                std::lock_guard<std::mutex> up(wk.up_mu);
+                for (;;) {
+                    Job job;
+                    {
+                        std::lock_guard<std::mutex> g(mu_);
+                        if (queue_.empty()) break;
+                        const Job &f = queue_.front();
+                        if (!f.uploaded && wk.slots >= 2) break;
+                        job = f;
+                        queue_.pop_front();
+                        if (!job.uploaded) --waiting_for_slot_;
                     }
-                    ++uploads;
+                    if (!job.uploaded) {
+                        job.t_issue = std::chrono::steady_clock::now();
+                        job.upload_rc = issue_upload(wk.ctx, job.task);
+                        job.uploaded = true;
+                        if (job.upload_rc >= 0) ++wk.slots;
+                    }
+                    staged.push_back(job);
+                    if (workers_.size() > 1 && staged.size() >= 2) break;   // one ahead is enough; leave the rest to the other workers
                 }
-                staged.push_back(s);
             }
-            if (staged.empty()) {
-                std::lock_guard<std::mutex> g(mu_);
-                if (stopping_ && queue_.empty()) return;
-                continue;
-            }
+            if (staged.empty()) continue;
             Staged s = staged.front();
             staged.pop_front();
-            if (s.job.task.n > 0) --uploads;
             Result r = solve(wk, s);
-            const bool restage = chained_ && r.window_guard && !staged.empty();
+            const bool restage = chained_ && r.window_guard;
             publish(std::move(r));
             if (restage) {
                 // The callback has just flagged this slice's events as noise (optimizer_rolling.h:52-53), and the slices
-                // already uploaded behind it were read without those flags: drain their staging slots and upload them again.
-                for (Staged &p : staged) if (p.job.task.n > 0) (void)bf_commit_upload(wk.ctx);
-                for (Staged &p : staged) if (p.job.task.n > 0) (void)issue_upload(wk.ctx, p.job.task);
+                // whose copies were already issued behind it were read without those flags: take them all, drain their
+                // staging slots and copy them again.
+                std::lock_guard<std::mutex> up(wk.up_mu);
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    while (!queue_.empty() && queue_.front().uploaded) { staged.push_back(queue_.front()); queue_.pop_front(); }
+                }
+                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc >= 0) (void)bf_commit_upload(wk.ctx);
+                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc >= 0) p.upload_rc = issue_upload(wk.ctx, p.task);
+                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc < 0) --wk.slots;   // (a failed re-issue holds no slot)
             }
         }
     }

@@ -496,7 +496,9 @@ protected:
             std::lock_guard<std::mutex> g(mu);
             if (!failed) { failed = true; fail_code = r.rc; fail_text = "StreamEngine: slice " + std::to_string(p.index) + ": " + r.error; }
         } else {
-            if (r.window_guard) flag_noise(p);
+            // (several workers: recompute() has already flagged the slice from its own evaluation of the guard -- other
+            // workers may be reading the noise ring right now)
+            if (r.window_guard && farm->workers() == 1) flag_noise(p);
             if (p.block && uv) {   // accumulate: the slice's own copy of the flow -> the ring's
                 const size_t slot = (size_t)(p.first % cap), n0 = p.n < cap - slot ? (size_t)p.n : cap - slot;
                 std::memcpy(uv + 2 * slot, p.block->data(), n0 * 16);

@@ -60,3 +60,25 @@ def test_unit_programs_under_sanitizers(tmp_path):
             synth.write_txt(txt, sl)
             args = [txt]
         _run([exe] + args, str(tmp_path))
+
+
+def test_stream_engine_and_slice_farm_under_thread_sanitizer(tmp_path):
+    """ThreadSanitizer over the threaded half of the host front end: StreamEngine (producer thread) + SliceFarm (worker
+    threads, submit-side uploads, in-order delivery, noise re-staging) on the oracle shim -- tests/cpp/test_stream.cpp, the
+    program that also holds the engine to DVS_flow: pipelined, bulk, three workers, the noise chain.  Any data-race
+    report fails the run (halt_on_error)."""
+    host = os.path.join(ROOT, "better_flow_amd", "host")
+    exe = str(tmp_path / "test_stream_tsan")
+    obj = str(tmp_path / "bf_oracle_tsan.o")
+    tsan = ["-fsanitize=thread", "-g", "-fno-omit-frame-pointer"]
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-ffp-contract=off"] + tsan + ["-c", os.path.join(ROOT, "oracle", "bf_oracle.c"), "-o", obj])
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-pthread", "-ffp-contract=off"] + tsan +
+                          ["-I" + host, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_stream.cpp"),
+                           os.path.join(ROOT, "tests", "shim", "bf_accel_oracle_shim.cpp"), obj, "-lm", "-o", exe])
+    sl = synth.make_slice(10000, 180, 240, 0.1, seed=5)
+    txt = str(tmp_path / "ev.txt")
+    synth.write_txt(txt, sl)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    r = subprocess.run([exe, txt], cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+    assert r.returncode == 0 and b"ThreadSanitizer" not in r.stderr, r.stderr.decode()[-4000:]
+    assert r.stdout.decode().count("\nOK ") + r.stdout.decode().startswith("OK ") == 6

@@ -301,7 +301,9 @@ template <class Sink> uint64_t feed_soa_file(const SoaFile &file, Sink &sink, in
     while (done < file.events()) {
         typename Sink::Span sp[2];
         const uint64_t want = file.events() - done;
-        const size_t got = sink.reserve(want > (uint64_t)1 << 30 ? (size_t)1 << 30 : (size_t)want, sp);
+        // (blocks of a million events: large enough to amortise the reader threads, small enough for the slices they close
+        // to reach the solver while the next block is being read)
+        const size_t got = sink.reserve(want > (uint64_t)1 << 20 ? (size_t)1 << 20 : (size_t)want, sp);
         // split the granted slots into per-thread pieces of at least 64k events
         struct Piece { uint64_t first, n; uint64_t *t; uint16_t *r, *c; };
         std::vector<Piece> pieces;

@@ -118,7 +118,7 @@ public:
     void set_pipelined(bool v = true) { pipelined = v; }     // add_event(s) return at the trigger; drain() waits
     void set_assume_sorted(bool v = true) { assume_sorted = v; }
     void set_time_base(ull t) { time_base = t; }             // ring timestamps are absolute; logical time = timestamp - base
-    void set_lookahead(size_t n) { lookahead = n; }          // ring slots beyond MAX_SZ (default: MAX_SZ, at least 65536)
+    void set_lookahead(size_t n) { lookahead = n; }          // ring slots beyond MAX_SZ (default: 2 MAX_SZ, at least 65536)
     void set_devices(const std::vector<int> &d, int contexts = 1) { devices = d; contexts_per_device = contexts; }
     void on_slice(SliceFn fn) { slice_fn = std::move(fn); }
 
@@ -438,7 +438,7 @@ protected:
                                          "chain is sequential");
         farm.reset(new SliceFarm(devices, contexts_per_device, (long long)max_sz, scale * RES_X + scale, scale * RES_Y + scale,
                                  [this](const SliceFarm::Result &r) { deliver(r); }, chained));
-        size_t extra = lookahead ? lookahead : (max_sz > 65536 ? max_sz : 65536);
+        size_t extra = lookahead ? lookahead : (2 * max_sz > 65536 ? 2 * max_sz : 65536);   // the producer may run two slices ahead
         cap = max_sz + extra;
         for (size_t w = 0; w < farm->workers(); ++w) (void)bf_set_option(farm->context(w), "stream_prealloc", 1);   // staging slots, copy stream: now, not at the first slice
         bf_ctx *c = farm->context(0);

@@ -1,6 +1,7 @@
 """Generator of tests/golden/config5_720p_seed<S>.npz -- BASELINE config 5's slice run to the loop's OWN termination.
 
-    python tests/golden/make_config5_golden.py [seed ...]          (default: seed 1; ~25 min of CPU per seed)
+    python tests/golden/make_config5_golden.py [seed ...]                 (default: seed 1; ~25 min of CPU per seed)
+    python tests/golden/make_config5_golden.py --ensemble K [seed ...]    (K more event orders per seed, see ensemble())
 
 The oracle (oracle/bf_oracle.c, the CPU restatement of optimizer_rolling.h:48-125 -- "parity unpinned", see its header)
 is run twice on the 1M-event 1280x720 slice `synth.make_slice(1000000, 720, 1280, 0.030, seed)`: events in upload order

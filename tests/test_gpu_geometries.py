@@ -224,43 +224,62 @@ def test_config2_cold_to_convergence_against_oracle(oracle_lib, accel_mod):
 def test_config5_to_termination_against_golden(accel_mod, seed):
     """BASELINE config 5's slice (1M events, 1280x720, scale 3) cold to the loop's OWN termination (optimizer_rolling.h:
     76-101): thousands of iterations, where test_large_geometry_against_oracle compares the first 41.  The oracle needs
-    ~25 minutes for that, so its result is a committed fixture (tests/golden/config5_720p_seed<S>.npz, written by
-    tests/golden/make_config5_golden.py: the oracle on the slice's events forward AND reversed -- both are "the
-    reference's answer", accel_lib.h:162 makes it order dependent; seed 1: 4906 / 4949 iterations, per-event flow up to
-    1.3 px/s apart on ~1500 px/s; seed 0: 7355 / 7344 and 4.6 px/s).  Bars: same return code and final dividers; iteration
-    count within 4 x the two oracle runs' difference (+ 1 %); converged per-event flow at 4096 sampled events and its
-    percentiles within north_star's 1e-4 / 0.02 px/s + 4 x the oracle's own forward / reversed spread over ALL events;
-    total_dx / total_dy likewise against their spread."""
+    ~25 minutes per run, so its results are committed fixtures (tests/golden/config5_720p_seed<S>.npz and
+    ..._ensemble.npz, written by tests/golden/make_config5_golden.py): the oracle on SIX orders of the slice's events --
+    upload order, reversed, four seeded random permutations.  All six are "the reference's answer": accel_lib.h:162 adds
+    the time image in f32 in container order, and the loop amplifies the last bits -- a divider doubles whenever its
+    gradient component changes sign between two iterations (optimizer_rolling.h:98-101), which near the optimum is decided
+    by rounding noise.
+      seed 1: 4891 .. 4958 iterations, per-event flow within 0.5 / 1.3 px/s across the six (on ~1500 px/s);
+      seed 0: 5389 .. 7355 iterations, and the row flow differs by 590 px/s between members -- on four of the six orders
+              the x divider has doubled away before total_dx got anywhere near the injected -600 px/s.  The reference
+              loop has no unique answer on this slice; it is kept because config 5's batch contains such slices.
+    The GPU (order-free integer sums) is one more member of that family.  Bars: return code 0; iteration count inside
+    the ensemble's range widened by a quarter of its width (+ 1 %); per-event flow at 4096 sampled events, its
+    percentiles and the model's totals inside the ensemble's envelope widened by its own (largest) width plus north_star's
+    1e-4 relative / 0.02 px/s."""
     import hashlib
     import os
     H, W, s = 720, 1280, 3
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_720p_seed%d.npz" % seed))
-    assert tuple(z["geometry"]) == (H, W, s)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gold, "config5_720p_seed%d.npz" % seed))
+    e = np.load(os.path.join(gold, "config5_720p_seed%d_ensemble.npz" % seed))
+    assert tuple(z["geometry"]) == (H, W, s) and str(e["input_sha256"]) == str(z["input_sha256"])
     sl = synth.make_slice(1000000, H, W, 0.030, seed=seed)
     h = hashlib.sha256()
     for k in ("fr_x", "fr_y", "t"):
         h.update(np.ascontiguousarray(sl[k]).tobytes())
     assert h.hexdigest() == str(z["input_sha256"]), "the generator no longer produces the fixture's slice"
     rc, m, info, _, u, v = _gpu_run(accel_mod, sl, H, W, s, -1, 0)
-    it_f, it_r = int(z["fwd_iterations"]), int(z["rev_iterations"])
-    assert rc == int(z["fwd_rc"]) == int(z["rev_rc"]) == 0
-    assert abs(info.iterations - it_f) <= 4 * abs(it_f - it_r) + it_f // 100, (info.iterations, it_f, it_r)
-    assert (info.x_divider, info.y_divider, info.rot_divider, info.div_divider) == tuple(float(x) for x in z["fwd_dividers"])
+    its = np.array([int(z["fwd_iterations"]), int(z["rev_iterations"])] + e["iterations"].tolist())
+    assert rc == 0 and int(z["fwd_rc"]) == int(z["rev_rc"]) == 0 and not e["rc"].any()
+    slack = 0.25 * (its.max() - its.min()) + 0.01 * its.mean()
+    assert its.min() - slack <= info.iterations <= its.max() + slack, (info.iterations, its.tolist())
     idx = z["sample_idx"]
+    assert np.array_equal(idx, e["sample_idx"])
+
+    def inside(g, members, what):
+        lo, hi = members.min(axis=0), members.max(axis=0)
+        # (six members under-sample the family: a seventh falls outside their range at every third event; it must stay
+        # within one ensemble width -- the widest over the sampled events -- of it)
+        w = (hi - lo).max() + np.maximum(1e-4 * np.maximum(np.abs(lo), np.abs(hi)), 0.02)
+        bad = (g < lo - w) | (g > hi + w)
+        assert not np.any(bad), (what, int(np.sum(bad)), float(np.max(np.maximum(lo - g, g - hi))), float((hi - lo).max()))
+        return float(np.max(np.maximum(lo - g, g - hi)))   # > 0: that far (px/s) outside the raw envelope
+
+    worst = max(inside(u[idx], np.vstack([z["fwd_u"], z["rev_u"], e["u"]]), "u"),
+                inside(v[idx], np.vstack([z["fwd_v"], z["rev_v"], e["v"]]), "v"))
+    inside(np.percentile(u, z["percentiles"]), np.vstack([z["fwd_u_pct"], z["rev_u_pct"], e["u_pct"]]), "u percentiles")
+    inside(np.percentile(v, z["percentiles"]), np.vstack([z["fwd_v_pct"], z["rev_v_pct"], e["v_pct"]]), "v percentiles")
     fields = [str(f) for f in z["fields"]]
-    worst = 0.0
-    for g_, f_, r_, spread in ((u, z["fwd_u"], z["rev_u"], float(z["spread_u"])), (v, z["fwd_v"], z["rev_v"], float(z["spread_v"]))):
-        d = np.abs(g_[idx] - f_)
-        worst = max(worst, d.max() / spread)
-        assert np.all(d <= np.maximum(1e-4 * np.abs(f_), 0.02) + 4.0 * spread), (d.max(), spread)
-        assert np.abs(f_ - r_).max() <= spread
-    for g_, key, spread in ((u, "fwd_u_pct", float(z["spread_u"])), (v, "fwd_v_pct", float(z["spread_v"]))):
-        gp = np.percentile(g_, z["percentiles"])
-        assert np.all(np.abs(gp - z[key]) <= np.maximum(1e-4 * np.abs(z[key]), 0.02) + 4.0 * spread), (gp, z[key])
+    models = np.vstack([z["fwd_model"], z["rev_model"], e["model"]])
     for f in ("total_dx", "total_dy", "total_rot", "total_div"):
         k = fields.index(f)
-        sp = abs(z["fwd_model"][k] - z["rev_model"][k])
-        assert abs(getattr(m, f) - z["fwd_model"][k]) <= 4.0 * sp + 1e-4 * abs(z["fwd_model"][k]) + 1e-9, (f, getattr(m, f), z["fwd_model"][k], sp)
-    print("config 5 seed %d to termination: GPU %d iterations, oracle %d forward / %d reversed; flow deviation at most %.2f x the "
-          "oracle's own forward / reversed spread (%.2f / %.2f px/s)" % (seed, info.iterations, it_f, it_r, worst,
-                                                                       float(z["spread_u"]), float(z["spread_v"])))
+        lo, hi = models[:, k].min(), models[:, k].max()
+        w = 2.0 * (hi - lo) + 1e-4 * max(abs(lo), abs(hi)) + 1e-9   # (four scalars of six members: two widths)
+        assert lo - w <= getattr(m, f) <= hi + w, (f, getattr(m, f), lo, hi)
+    print("config 5 seed %d to termination: GPU %d iterations, the oracle's six event orders %s; sampled flow %s the ensemble's "
+          "envelope (widest: %.2f px/s in u, %.2f in v)" %
+          (seed, info.iterations, its.tolist(), "inside" if worst <= 0 else "at most %.3f px/s outside" % worst,
+           float((np.vstack([z["fwd_u"], z["rev_u"], e["u"]]).max(0) - np.vstack([z["fwd_u"], z["rev_u"], e["u"]]).min(0)).max()),
+           float((np.vstack([z["fwd_v"], z["rev_v"], e["v"]]).max(0) - np.vstack([z["fwd_v"], z["rev_v"], e["v"]]).min(0)).max())))

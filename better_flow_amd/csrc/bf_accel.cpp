@@ -1458,7 +1458,11 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // large images --, so that twice as many bins are in flight per CU: 84 instead of 91 us per iteration at 1280x720)
     int ev_per_thread = 8;
     const double ev_per_bin = binned ? (double)c->n / (double)(c->grid.nbins > 0 ? c->grid.nbins : 1) : 0.0;
-    const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads : (ev_per_bin >= 1536.0 ? 1024 : 512);
+    // (contexts sharing the GPU, "co_schedule": 512-thread work-groups even for full bins -- a 1024-thread work-group with its
+    // 51 KB tile needs half a CU's wave slots free at once and waits for them while the other contexts' kernels hold a few
+    // each: its launches take 16.7 us instead of 8.0 under four contexts; with 512 threads 170 -> 190 Mevents/s.  A context
+    // alone is faster with 1024: 8.0 against 8.9 us)
+    const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads : ((ev_per_bin >= 1536.0 && !c->opt_co_schedule) ? 1024 : 512);
     if (binned && c->opt_bin_ev > 0) ev_per_thread = c->opt_bin_ev;
     else if (binned) {
         // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a

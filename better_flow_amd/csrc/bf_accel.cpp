@@ -1467,7 +1467,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     else if (binned) {
         // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a
         // CU, and a bin above the pass size takes a second pass; measured at 1280x720: 512 x 2 69.8 us, 512 x 4 73.5)
-        const double per_bin = (c->fmt == 2 ? 1.0 : 1.5) * ev_per_bin / (double)bin_threads;
+        // (dense tiles: a pass should cover the AVERAGE bin, fuller bins take a second pass -- sizing it for 1.5 x the
+        // average left half of every thread's slots empty at 640x480: 512 x 8 19.9 us, 512 x 4 15.3 us)
+        const double per_bin = (c->fmt == 2 ? 1.0 : 1.1) * ev_per_bin / (double)bin_threads;
         ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2 ? 2 : (per_bin <= 4 ? 4 : 8));
     }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot

@@ -805,7 +805,7 @@ int bf_upload_events(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, const 
 int bf_host_alloc(bf_ctx* c, int64_t bytes, void** out) {
     if (!c || !out || bytes <= 0) return BF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable));   // (portable: a slice farm uploads from one ring to several devices)
     return BF_OK;
 }
 

@@ -434,6 +434,39 @@ def test_stream_flow_equals_dvs_flow_gpu(events_txt, tmp_path):
     _check_stream_output(out)
 
 
+def _build_test_farm(out_dir, against_gpu):
+    host = os.path.join(ROOT, "better_flow_amd", "host")
+    src = os.path.join(ROOT, "tests", "cpp", "test_farm.cpp")
+    exe = os.path.join(out_dir, "test_farm_gpu" if against_gpu else "test_farm_oracle")
+    base = ["g++", "-O2", "-std=c++14", "-pthread", "-ffp-contract=off", "-I" + host, "-I" + os.path.join(ROOT, "include"), src]
+    if against_gpu:
+        subprocess.check_call(base + ["-L" + os.path.join(ROOT, "better_flow_amd"), "-lbf_accel",
+                                      "-Wl,-rpath," + os.path.join(ROOT, "better_flow_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    else:
+        obj = os.path.join(out_dir, "bf_oracle_farm.o")
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-c", os.path.join(ROOT, "oracle", "bf_oracle.c"), "-o", obj])
+        subprocess.check_call(base + [os.path.join(ROOT, "tests", "shim", "bf_accel_oracle_shim.cpp"), obj, "-lm", "-o", exe])
+    return exe
+
+
+def _check_farm_output(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith(("OK", "FAIL"))]
+    assert lines == ["OK farm with 1 worker(s): 7 results, 0 differences", "OK farm with 3 worker(s): 7 results, 0 differences"], out[-2000:]
+
+
+def test_slice_farm_standalone_oracle(events_txt, tmp_path):
+    """bf::SliceFarm on its own (linear int32 task input, cold / warm from a given model, an empty slice), 1 and 3
+    workers, against one context solving the slices one by one: in order, bit-identical -- on the oracle shim."""
+    path, _ = events_txt
+    _check_farm_output(run_cli(_build_test_farm(str(tmp_path), False), [path], str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_slice_farm_standalone_gpu(events_txt, tmp_path):
+    path, _ = events_txt
+    _check_farm_output(run_cli(_build_test_farm(str(tmp_path), True), [path], str(tmp_path)))
+
+
 # ---- --img / --video: one 2 x 2 frame per slice (raw grey | raw colour-time / compensated grey | compensated colour-time) ----
 
 def _read_ppm(path):

@@ -49,7 +49,19 @@ def apply(a, op, sl):
     if k == "upload":
         how = op[2] if (a is long_ctx or mimic_long) else "plain"     # the long-lived context also exercises the other hand-overs
         n = len(sl["t"])
-        if how == "plain" or op[1] is not None or n == 0:
+        if how == "ring16" and n > 0:   # 16-bit addresses, absolute timestamps, the noise flags as a ring of their own
+            cap, first, t0 = n + int(op[3] % 977), int(op[3] % (n + 1)), 5000000000
+            idx = (first + np.arange(n)) % cap
+            rr, rc_, rts = np.zeros(cap, np.uint16), np.zeros(cap, np.uint16), np.zeros(cap, np.uint64)
+            rr[idx], rc_[idx], rts[idx] = sl["fr_x"], sl["fr_y"], (sl["t"] + t0).astype(np.uint64)
+            rn = None
+            if op[1] is not None:
+                rn = np.ones(cap, np.uint8)          # (flags outside the slice must not matter)
+                rn[idx] = op[1]
+            a.upload_ring_async(rr, rc_, rts, first, n, t0, rn)
+            a.commit_upload()
+            a.synchronize()
+        elif how == "plain" or op[1] is not None or n == 0:
             a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"], op[1])
         elif how == "async":
             px, py, pt = a.pinned_int32(n), a.pinned_int32(n), a.pinned_int32(n)
@@ -80,7 +92,15 @@ def apply(a, op, sl):
         rc, m, info = a.run(o)
         return (rc, info.iterations, canon(m), tuple(canon(t_.model) for t_ in a.get_trace(16)))
     if k == "uv":
-        u, v = a.compute_uv(); return (u.tobytes(), v.tobytes())
+        u, v = a.compute_uv()
+        if a is long_ctx and len(u):   # the ring form of the same read-back must agree, at a random ring position
+            n = len(u)
+            cap, first = n + int(rng.integers(0, 50)), int(rng.integers(0, n))
+            ring = np.full(2 * cap, np.nan)
+            a.compute_uv_ring(ring, first)
+            idx = (first + np.arange(n)) % cap
+            assert np.array_equal(ring[2 * idx], u) and np.array_equal(ring[2 * idx + 1], v), "bf_compute_uv_ring != bf_compute_uv"
+        return (u.tobytes(), v.tobytes())
     if k == "writeout":
         return tuple(x.tobytes() for x in a.writeout_events())
     if k == "lwin":
@@ -108,7 +128,7 @@ for step in range(steps):
     if sl is None or rng.random() < 0.12:
         sl = make_slice()
         noise = (rng.random(len(sl["t"])) < 0.1).astype(np.uint8) if rng.random() < 0.2 else None
-        script = [("upload", noise, str(rng.choice(["plain", "async", "ring"])), int(rng.integers(0, 1 << 30)))]
+        script = [("upload", noise, str(rng.choice(["plain", "async", "ring", "ring16"])), int(rng.integers(0, 1 << 30)))]
         apply(long_ctx, script[0], sl)
         history.append((dict(long_opts), sl, script))
         state = dict(cloud=False, lwin=None, ran=False, scale=3, noise=noise is not None)

@@ -202,12 +202,14 @@ __global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
 #else
 #define TK(i_) do { } while (0)
 #endif
+    // (the accumulator planes are cleared once here and then by the Scharr pass of every iteration, which is the first
+    // phase after the box sums have read them: one pass over the pixels and one barrier less per iteration)
+    for (int i = tid; i < P; i += THREADS) { s_ts[i] = 0; s_cnt[i] = 0; }
+    __syncthreads();
     while (!s_st.hot.done) {
         TK(0);
         const WarpParams wp = s_st.hot.wp;
         const bool warp = s_st.hot.it > 0;
-        for (int i = tid; i < P; i += THREADS) { s_ts[i] = 0; s_cnt[i] = 0; }
-        __syncthreads();
         // ---- warp (event.h:99-110,164-168) + point scatter (accel_lib.h:151-166) ----
         auto one_event = [&](uint32_t v, int32_t ti, float2& q) {
             const uint32_t fx = v & 0xffffu, fy = v >> 16;
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
         for (int i = tid; i < P; i += THREADS) {
             const int r = (int)(((float)i + 0.5f) * rC), c = i - r * C;   // exact: see rC
             const float ctr = s_time[i];
+            s_ts[i] = 0; s_cnt[i] = 0;   // for the next iteration's scatter (nobody reads them any more in this one)
             if (!valid_px(ctr)) continue;
             float gx = 0.f, gy = 0.f;
             if (r >= 1 && r < R - 1 && c >= 1 && c < C - 1) {

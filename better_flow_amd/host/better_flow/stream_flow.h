@@ -184,7 +184,7 @@ public:
         if (prot != UINT64_MAX && head + 1 > prot + cap) {   // not even one slot: wait for the oldest slice in flight
             const auto t_wait = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> g(mu);
-            cv.wait(g, [&] { prot = protected_from.load(std::memory_order_acquire); return failed || prot == UINT64_MAX || head + 1 <= prot + cap; });
+            cv.wait(g, [&] { prot = protected_from.load(std::memory_order_acquire); return failed.load() || prot == UINT64_MAX || head + 1 <= prot + cap; });
             g.unlock();
             blocked_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
             rethrow_failure();
@@ -373,7 +373,7 @@ protected:
     bf_run_info last_info;
     ull slices_done, slices_skipped, iterations_total;
     uint64_t flow_through_plus1;             // events below this arrival number have been in a delivered slice
-    bool failed;
+    std::atomic<bool> failed;   // (read by the producer without the lock)
     int fail_code;
     std::string fail_text;
     // accumulate
@@ -494,7 +494,7 @@ protected:
         }
         if (r.rc < 0) {
             std::lock_guard<std::mutex> g(mu);
-            if (!failed) { failed = true; fail_code = r.rc; fail_text = "StreamEngine: slice " + std::to_string(p.index) + ": " + r.error; }
+            if (!failed) { fail_code = r.rc; fail_text = "StreamEngine: slice " + std::to_string(p.index) + ": " + r.error; failed = true; }
         } else {
             // (several workers: recompute() has already flagged the slice from its own evaluation of the guard -- other
             // workers may be reading the noise ring right now)

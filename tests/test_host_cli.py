@@ -182,6 +182,32 @@ def test_cli_stream_engine_equals_reference_ring_oracle(oracle_cli, events_txt, 
     assert r.returncode == 1 and b"--stm-disable" in r.stderr
 
 
+def test_cli_text_input_irregular_files(oracle_cli, events_txt, tmp_path):
+    """The parallel text parser only takes files with one record per line; anything else -- a record spread over two
+    lines, blank lines, a malformed record in the middle (where the iostream loop of bf_motion_compensator.cpp:186-197
+    stops reading) -- goes to the sequential parser.  Either way the stream engine must see the events the reference
+    ring sees: byte-identical -o files and summaries, on 1 and 8 parser threads."""
+    path, _ = events_txt
+    lines = open(path).read().splitlines()
+    variants = {
+        "blank": lines[:3000] + ["", "   "] + lines[3000:],
+        "split": lines[:2500] + [lines[2500].split()[0] + " " + lines[2500].split()[1], " ".join(lines[2500].split()[2:])] + lines[2501:],
+        "junk": lines[:7000] + ["0.5 12 x 1"] + lines[7000:],          # reading stops here: 7000 events
+        "tail": lines + ["# end of recording"],
+        "noeol": None,
+    }
+    for name, body in variants.items():
+        f = str(tmp_path / ("irr_%s.txt" % name))
+        with open(f, "w") as fh:
+            fh.write("\n".join(lines) if body is None else "\n".join(body) + "\n")
+        ref = _engine_outputs(oracle_cli, f, tmp_path, "ir_" + name, ["--engine=ring"])
+        for th in ("1", "8"):
+            got = _engine_outputs(oracle_cli, f, tmp_path, "is_%s_%s" % (name, th), ["--threads=" + th])
+            assert got == ref, (name, th)
+        n_out = ref[1].count(b"\n")
+        assert n_out == (7000 if name == "junk" else len(lines)), (name, n_out)
+
+
 def _big_stream_file(tmp_path, slices=4, per_slice=250000):
     """`slices` consecutive 30 ms slices of ~per_slice events at 346x260 as one binary event file."""
     import struct

@@ -456,11 +456,15 @@ protected:
         if (want_flow_any()) { uv = (double *)alloc(cap * 16); std::memset(uv, 0, cap * 16); }
     }
 
-    void archive(uint64_t g, uint64_t end) {
-        for (; g < end; ++g) {
-            const size_t s = (size_t)(g % cap);
-            hist_ts.push_back(ts[s] - time_base); hist_row.push_back(row_[s]); hist_col.push_back(col_[s]);
-        }
+    void archive(uint64_t g, uint64_t end) {   // (two contiguous pieces of the ring, appended in bulk)
+        const size_t n = (size_t)(end - g), at = hist_ts.size();
+        hist_ts.resize(at + n); hist_row.resize(at + n); hist_col.resize(at + n);
+        const size_t slot = (size_t)(g % cap), n0 = n < cap - slot ? n : cap - slot;
+        const ull base = time_base;
+        for (size_t i = 0; i < n0; ++i) hist_ts[at + i] = ts[slot + i] - base;
+        for (size_t i = n0; i < n; ++i) hist_ts[at + i] = ts[i - n0] - base;
+        std::memcpy(hist_row.data() + at, row_ + slot, n0 * 2); std::memcpy(hist_row.data() + at + n0, row_, (n - n0) * 2);
+        std::memcpy(hist_col.data() + at, col_ + slot, n0 * 2); std::memcpy(hist_col.data() + at + n0, col_, (n - n0) * 2);
     }
 
     // optimizer_rolling.h:49-55 evaluated on the host: the bounding box of the slice (set_cloud, :248-283) against RES / 15

@@ -38,6 +38,7 @@ struct Options {
     int video_fps = 60;
     int scale = 3, max_iter = -1;
     std::string input, output, to_bin, slice_log;
+    std::vector<std::string> more_inputs;  // further recordings: each is a stream of its own
     bool have_input = false, have_output = false;
     // the event ring (EVENT_WIDTH / TIME_WIDTH of the reference, bf_motion_compensator.cpp:6-7)
     unsigned long long max_events = kMaxEvents;
@@ -159,10 +160,7 @@ int parse(int argc, char **argv, Options &o) {
         if (a == "-v" || a == "--version") { print_version(); return 0; }
         if (a == "-") continue;   // (the reference accepts and ignores a lone dash)
         if (a[0] != '-') {
-            if (o.have_input) {
-                std::fprintf(stderr, "two input files given: \"%s\" and \"%s\"\n", o.input.c_str(), argv[i]);
-                return 1;
-            }
+            if (o.have_input) { o.more_inputs.push_back(a); continue; }   // several recordings: independent streams (see run)
             o.input = a; o.have_input = true;
             continue;
         }
@@ -201,9 +199,13 @@ int parse(int argc, char **argv, Options &o) {
                      kMaxEvents, kMaxSpanSec);
         return 1;
     }
+    if (!o.more_inputs.empty() && (o.engine != "stream" || !o.to_bin.empty())) {
+        std::fprintf(stderr, "several input files are independent streams of the stream engine: not with --engine=ring / --img / --video / -i / --to-bin\n");
+        return 1;
+    }
     if (o.max_events < 1 || o.span_sec <= 0 || o.contexts < 1) { std::fprintf(stderr, "--max-events, --span and --contexts must be positive\n"); return 1; }
     for (int d : o.devices) if (d < 0) { std::fprintf(stderr, "--devices: a list such as 0-7 or 0,2\n"); return 1; }
-    if ((o.devices.size() > 1 || o.contexts > 1) && !o.stm_disable) {
+    if ((o.devices.size() > 1 || o.contexts > 1) && !o.stm_disable && o.more_inputs.empty()) {
         std::fprintf(stderr, "--devices / --contexts spread INDEPENDENT slices: they need --stm-disable (a warm-start chain is sequential)\n");
         return 1;
     }
@@ -412,7 +414,47 @@ int run_stream(const Options &o) {
     return 0;
 }
 
-int run(const Options &o) { return o.engine == "ring" ? run_ring(o) : run_stream(o); }
+// Several recordings: every file is a stream of its own -- its own ring, its own warm-start chain, its own worker -- and the
+// streams run side by side, stream i on device devices[i mod #devices] (--devices=0-7; default: --device).  Independent
+// chains are the other way, next to independent slices, to use the GPUs of a node ("farming applies to
+// independent streams / slices").  -o, --slice-log: one file per stream, "<name>.<i>".
+int run_streams(const Options &o) {
+    std::vector<std::string> inputs;
+    inputs.push_back(o.input);
+    inputs.insert(inputs.end(), o.more_inputs.begin(), o.more_inputs.end());
+    const std::vector<int> devs = o.devices.empty() ? std::vector<int>{bf::DeviceContext::device()} : o.devices;
+    std::vector<int> rc(inputs.size(), 0);
+    std::vector<std::string> errors(inputs.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < inputs.size(); ++i)
+        th.emplace_back([&, i] {
+            Options oi = o;
+            oi.more_inputs.clear();
+            oi.input = inputs[i];
+            oi.devices = std::vector<int>{devs[i % devs.size()]};
+            oi.contexts = 1;
+            if (o.have_output) oi.output = o.output + "." + std::to_string(i);
+            if (!o.slice_log.empty()) oi.slice_log = o.slice_log + "." + std::to_string(i);
+            try {
+                rc[i] = run_stream(oi);
+            } catch (const bf::AccelError &e) {
+                rc[i] = 2;
+                errors[i] = e.what();
+            }
+        });
+    for (auto &t : th) t.join();
+    int worst = 0;
+    for (size_t i = 0; i < inputs.size(); ++i) {
+        if (rc[i] != 0) std::fprintf(stderr, "bf_motion_compensator: stream %zu (%s): %s\n", i, inputs[i].c_str(), errors[i].empty() ? "failed" : errors[i].c_str());
+        worst = rc[i] > worst ? rc[i] : worst;
+    }
+    return worst;
+}
+
+int run(const Options &o) {
+    if (o.engine == "ring") return run_ring(o);
+    return o.more_inputs.empty() ? run_stream(o) : run_streams(o);
+}
 
 }  // namespace
 

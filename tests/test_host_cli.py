@@ -208,6 +208,31 @@ def test_cli_text_input_irregular_files(oracle_cli, events_txt, tmp_path):
         assert n_out == (7000 if name == "junk" else len(lines)), (name, n_out)
 
 
+def _two_streams(exe, events_txt, tmp_path, extra):
+    """Two recordings on one command line = two independent streams side by side; each must equal its own single run."""
+    path, _ = events_txt
+    other = str(tmp_path / "second.txt")
+    synth.write_txt(other, synth.make_slice(9000, 180, 240, 0.09, seed=77))
+    out = str(tmp_path / "multi.txt")
+    so = run_cli(exe, extra + ["-o", out, path, other], str(tmp_path))
+    assert so.count("slices: ") == 2
+    for i, f in enumerate((path, other)):
+        single = _engine_outputs(exe, f, tmp_path, "single%d" % i, [])
+        assert open(out + ".%d" % i, "rb").read() == single[1], i
+
+
+def test_cli_several_recordings_are_independent_streams_oracle(oracle_cli, events_txt, tmp_path):
+    _two_streams(oracle_cli, events_txt, tmp_path, [])
+    r = subprocess.run([oracle_cli, "--engine=ring", events_txt[0], events_txt[0]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"independent streams" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_several_recordings_are_independent_streams_gpu(events_txt, tmp_path):
+    gpu_cli = os.path.join(ROOT, "better_flow_amd", "host", "bf_motion_compensator")
+    _two_streams(gpu_cli, events_txt, tmp_path, ["--devices=0,0"])
+
+
 def _big_stream_file(tmp_path, slices=4, per_slice=250000):
     """`slices` consecutive 30 ms slices of ~per_slice events at 346x260 as one binary event file."""
     import struct

@@ -79,5 +79,33 @@ int main(int argc, char **argv) {
         std::printf("%s farm with %d worker(s): %zu results, %d differences\n", diff ? "FAIL" : "OK", workers, got.size(), diff);
         bad += diff;
     }
+    {   // a farm whose contexts are too small for two of the slices: those two fail with BF_ERR_CAPACITY -- in their place in the
+        // order, with the context's error text --, the others are solved as before
+        std::vector<bf::SliceFarm::Result> got;
+        {
+            bf::SliceFarm farm(std::vector<int>{0}, 2, 2000, s * H + s, s * W + s, [&](const bf::SliceFarm::Result &r) { got.push_back(r); });
+            for (size_t k = 0; k < slices.size(); ++k) {
+                bf::SliceFarm::Task t;
+                t.fr_x = slices[k].x.data(); t.fr_y = slices[k].y.data(); t.t_ns = slices[k].t.data();
+                t.n = (int64_t)slices[k].x.size();
+                t.scale = s; t.res_x = H; t.res_y = W; t.max_iter = 30;
+                t.warm = k > 2 ? bf::SliceFarm::Warm::FromModel : bf::SliceFarm::Warm::Cold;
+                t.start = seed_model;
+                farm.submit(t);
+            }
+            farm.drain();
+        }
+        int diff = got.size() == slices.size() ? 0 : 1, failed = 0;
+        for (size_t k = 0; k < got.size() && k < slices.size(); ++k) {
+            const bool too_big = slices[k].x.size() > 2000;
+            if (too_big) {
+                ++failed;
+                if (got[k].rc != BF_ERR_CAPACITY || got[k].error.find("capacity") == std::string::npos || got[k].id != k) ++diff;
+            } else if (got[k].id != k || got[k].rc != wrc[k] || std::memcmp(&got[k].model, &want[k], sizeof(bf_model)) != 0) ++diff;
+        }
+        std::printf("%s farm with undersized contexts: %zu results, %d refused for capacity, %d differences\n", (diff || failed != 2) ? "FAIL" : "OK",
+                    got.size(), failed, diff);
+        bad += diff + (failed != 2);
+    }
     return bad ? 1 : 0;
 }

@@ -32,6 +32,7 @@ struct bf_ctx {
         bool linear = false;
     };
     std::deque<PendingUpload> pend;
+    int64_t cap_events = 0;   // bf_create's capacity: an upload above it fails like the product's (BF_ERR_CAPACITY)
     bfo_local_window lwin;
     std::vector<float> time_img;
     char err[128] = "";
@@ -68,6 +69,7 @@ template <class T> static void reverse_vec(std::vector<T> &v) {
 template <class ADDR>
 static int ring_slice(bf_ctx *c, const ADDR *rx, const ADDR *ry, const uint64_t *rts, const uint8_t *rnoise, int64_t cap,
                       int64_t first, int64_t n, uint64_t t0) {
+    if (n > c->cap_events) { std::snprintf(c->err, sizeof(c->err), "n=%lld exceeds capacity %lld", (long long)n, (long long)c->cap_events); return BF_ERR_CAPACITY; }
     c->pend.emplace_back();
     bf_ctx::PendingUpload &u = c->pend.back();
     u.x.resize(n); u.y.resize(n); u.t.resize(n); u.noise.assign(n, 0);
@@ -90,8 +92,9 @@ void bf_run_opts_default(bf_run_opts *o) {
     o->hard_iter_cap = 100000; o->poll_interval = 8; o->trace_cap = 0; o->want_uv = 0;
 }
 
-int bf_create(int32_t, int64_t, int32_t, int32_t, void *, bf_ctx **out) {
+int bf_create(int32_t, int64_t max_events, int32_t, int32_t, void *, bf_ctx **out) {
     *out = new bf_ctx();
+    (*out)->cap_events = max_events;
     return BF_OK;
 }
 void bf_destroy(bf_ctx *c) { delete c; }
@@ -274,6 +277,7 @@ int bf_set_option(bf_ctx *, const char *, int64_t) { return BF_OK; }   // device
 
 // linear int32 arrays with slice-local times (the slice farm's second input form); held in upload order
 int bf_upload_events_async(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns, int64_t n) {
+    if (n > c->cap_events) { std::snprintf(c->err, sizeof(c->err), "n=%lld exceeds capacity %lld", (long long)n, (long long)c->cap_events); return BF_ERR_CAPACITY; }
     c->pend.emplace_back();
     bf_ctx::PendingUpload &u = c->pend.back();
     u.x.assign(fr_x, fr_x + n); u.y.assign(fr_y, fr_y + n);

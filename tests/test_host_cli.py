@@ -502,7 +502,8 @@ def _build_test_farm(out_dir, against_gpu):
 
 def _check_farm_output(out):
     lines = [ln for ln in out.splitlines() if ln.startswith(("OK", "FAIL"))]
-    assert lines == ["OK farm with 1 worker(s): 7 results, 0 differences", "OK farm with 3 worker(s): 7 results, 0 differences"], out[-2000:]
+    assert lines == ["OK farm with 1 worker(s): 7 results, 0 differences", "OK farm with 3 worker(s): 7 results, 0 differences",
+                     "OK farm with undersized contexts: 7 results, 2 refused for capacity, 0 differences"], out[-2000:]
 
 
 def test_slice_farm_standalone_oracle(events_txt, tmp_path):

@@ -463,8 +463,9 @@ def main():
             },
             "note": "durations are the kernels' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the "
                     "ctx stream), summed over every loop launch and divided by the launches that did work; "
-                    "profiles/r3_solo_tail_kernel_stats.csv (update in the stencil tail) and r3_solo_kernel_stats.csv "
-                    "(update at the head) are rocprofv3's view of the same solo runs",
+                    "rocprofv3's view of the same solo runs: profiles/r3_solo_tail_1024_kernel_stats.csv (this shape: update in "
+                    "the stencil tail, 1024-thread scatter work-groups), r3_solo_tail_kernel_stats.csv (the co-scheduled 512-thread "
+                    "shape) and r3_solo_kernel_stats.csv (update at the head)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------

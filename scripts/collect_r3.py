@@ -6,7 +6,8 @@ out = os.path.join(ROOT, "profiles")
 def kname(n):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>(]*>)?", n)
     return (m.group(1) + (m.group(2) or "")) if m else n[:40]
-for d, name in (("solo_head", "r3_solo_kernel_stats.csv"), ("solo_tail", "r3_solo_tail_kernel_stats.csv"), ("bench", "r3_bench_kernel_stats.csv")):
+for d, name in (("solo_head", "r3_solo_kernel_stats.csv"), ("solo_tail", "r3_solo_tail_kernel_stats.csv"),
+                ("solo_tail_1024", "r3_solo_tail_1024_kernel_stats.csv"), ("bench", "r3_bench_kernel_stats.csv")):
     ks = glob.glob(os.path.join(src, d, "**/*kernel_stats.csv"), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(out, name))

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-3 rocprofv3 passes (run on the GPU box via gpurun; outputs under gpurun_out/prof_r3, then
 # `python scripts/collect_r3.py` here copies the summaries into profiles/):
-#   solo_head / solo_tail : --kernel-trace --stats over ONE slice context (update at the scatter head / in the stencil tail)
+#   solo_head / solo_tail / solo_tail_1024 : --kernel-trace --stats over ONE slice context (update at the scatter head / in the
+#                           stencil tail with the co-scheduled 512-thread scatter shape / the same with 1024-thread groups)
 #   bench                 : --kernel-trace --stats over the default bench.py command (4 contexts in flight)
 #   fetch_* / write_*     : --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per geometry (346x260, 640x480, 1280x720)
 #   sq_720                : SQ issue / wait counters at 1280x720
@@ -11,6 +12,8 @@ O=$R/gpurun_out/prof_r3
 rm -rf $O; mkdir -p $O
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/solo_head -o s --output-format csv -- python $R/scripts/run_once.py 3 > $O/solo_head.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/solo_tail -o s --output-format csv -- python $R/scripts/run_once.py 3 co_schedule=1 > $O/solo_tail.log 2>&1
+# the shape bench.py's roofline.frac is measured in: update in the stencil tail, 1024-thread scatter work-groups, alone on the GPU
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/solo_tail_1024 -o s --output-format csv -- python $R/scripts/run_once.py 3 co_schedule=1 bin_threads=1024 > $O/solo_tail_1024.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/bench -o b --output-format csv -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-front-end > $O/bench.log 2>&1
 for G in "260 346 -1" "480 640 300" "720 1280 300"; do
   set -- $G

@@ -44,7 +44,7 @@ struct bf_ctx {
     int cap_blocks = 0;
 
     // two event sets: the tile-binned mode ping-pongs between them on every re-bin
-    struct EvSet { uint32_t* xy = nullptr; int32_t* t = nullptr; float2* p = nullptr; uint32_t* perm = nullptr; };
+    struct EvSet { uint32_t* xy = nullptr; int32_t* t = nullptr; float2* p = nullptr; uint32_t* perm = nullptr; float2* p2 = nullptr; };
     EvSet set[2];
     int cs = 0;                      // set holding the live events
     bool has_perm = false;           // set[cs] is permuted; perm[] gives the upload index
@@ -59,6 +59,15 @@ struct bf_ctx {
     int n_cus = 0;
     bool use_binned = false;         // decided per slice in bf_set_cloud
     BinGrid grid;
+    // one-kernel iteration (k_fused_pass): the loop of a context that has the GPU to itself
+    int opt_fused = 1;               // 0 never, 1 where it is the faster loop (small slices on small images), 2 whenever possible;
+                                     // never for a context that is co-scheduled with others
+    int opt_fused_margin = 8;        // D: scaled pixels an event may move before its tile's neighbours must be re-sorted
+    int opt_fused_rows = 0;          // rows of an image tile: 0 auto, 32 or 64
+    bool fused_ok = false;           // decided per slice in bf_set_cloud
+    BinGrid fgrid;                   // its sort grid: keys = (tile, zone)
+    uint32_t* d_ftab = nullptr;      // FusedTab per tile
+    int ftab_alloc = 0;
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
     uint32_t* d_armed = nullptr;
@@ -98,7 +107,8 @@ struct bf_ctx {
     uint32_t* d_cplane[2] = {nullptr, nullptr};
     float *d_time = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_img = nullptr;
     uint32_t* d_count = nullptr;
-    MomentAcc* d_acc = nullptr;      // 2 x kAccGroups exact moment accumulators (parity of the iteration)
+    MomentAcc* d_acc = nullptr;      // 3 x kAccGroups exact moment accumulators (two-kernel loop: parity of the iteration in the
+                                     // first two; one-kernel loop: launch number mod 3) + one line whose first word is `lost`
     bool acc_dirty = false;          // a head-update loop leaves its last iteration's sums behind: whoever uses the
                                      // accumulators next without a loop_init of its own (a ticket-mode stencil) clears them
     uint32_t* d_ovf = nullptr;       // tile-binned loop: overflow events of iteration j in slot j % 3
@@ -252,6 +262,7 @@ EvSets ev_sets(const bf_ctx* c) {
     EvSets e;
     for (int i = 0; i < 2; ++i) {
         e.s[i].xy = c->set[i].xy; e.s[i].t = c->set[i].t; e.s[i].p = c->set[i].p; e.s[i].perm = c->set[i].perm;
+        e.s[i].p2 = c->set[i].p2;
     }
     return e;
 }
@@ -369,10 +380,13 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
 
 // Device-conditional counting sort of the live events by the image tile of their current
 // target (runs only when hot.need_rebin is set); no host synchronisation.
-int enqueue_rebin(bf_ctx* c, DevState* st, bool has_perm_at_start, const WarpParams* prewarp = nullptr) {
+uint32_t* lost_flag(const bf_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_acc + 3 * kAccGroups); }
+
+int enqueue_rebin(bf_ctx* c, DevState* st, bool has_perm_at_start, const WarpParams* prewarp = nullptr, bool fused = false, int launch_no = 0) {
     ProfScope ps(c, 3);
-    launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, st, c->grid, c->d_binid, c->d_hist_cnt,
-                 c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->opt_bin_pack_limit, c->stream);
+    launch_rebin(ev_sets(c), has_perm_at_start ? 1 : 0, c->n, st, fused ? c->fgrid : c->grid, c->d_binid, c->d_hist_cnt,
+                 c->d_bin_start, c->d_cursor, c->d_armed, prewarp, c->opt_bin_pack_limit, c->stream,
+                 fused ? c->d_ftab : nullptr, fused ? lost_flag(c) + (launch_no + 2) % 3 : nullptr);   // (the last pass's word)
     HIP_TRY(c, hipGetLastError());
     return BF_OK;
 }
@@ -590,8 +604,8 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMalloc(&c->d_gy, c->cap_px * sizeof(float)));
         HIP_TRY(c, hipMalloc(&c->d_img, c->cap_px * sizeof(float)));
         HIP_TRY(c, hipMalloc(&c->d_count, c->cap_px * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_acc, 2 * kAccGroups * sizeof(MomentAcc)));
-        HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, 2 * kAccGroups * sizeof(MomentAcc), c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_acc, (3 * kAccGroups + 1) * sizeof(MomentAcc)));
+        HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, (3 * kAccGroups + 1) * sizeof(MomentAcc), c->stream));
         HIP_TRY(c, hipMalloc(&c->d_ovf, 64));
         HIP_TRY(c, hipMemsetAsync(c->d_ovf, 0, 64, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_state, 2 * sizeof(DevState)));
@@ -646,7 +660,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in16[i]) (void)hipFree(c->d_in16[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in_noise[i]) (void)hipFree(c->d_in_noise[i]);
-    void* bufs[] = {c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
+    void* bufs[] = {c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
@@ -739,6 +753,21 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "bin_threads")) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "bin_threads must be 0 (auto), 256, 512 or 1024");
         c->opt_bin_threads = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "fused")) {
+        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "fused must be 0, 1 (auto) or 2");
+        c->opt_fused = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "fused_margin")) {
+        if (value < 1 || value > 30) return fail(c, BF_ERR_ARG, "fused_margin must be in [1, 30]");
+        c->opt_fused_margin = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "fused_rows")) {
+        if (value != 0 && value != 32 && value != 64) return fail(c, BF_ERR_ARG, "fused_rows must be 0 (auto), 32 or 64");
+        c->opt_fused_rows = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "bin_margin")) {
@@ -1004,6 +1033,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
     // per-bin packing is decided on the device by the counting sort (k_bin_scan), with the overflow path as fallback.
     {
         BinGrid g;
+        memset(&g, 0, sizeof(g));
         // Tile shape: one work-group per bin.  Cost model of one iteration (calibrated on config 2, in us):
         //   waves of work-groups x events per tile x 1.7 ns   (the fullest CU sets the length of the scatter kernel)
         // + slab pixels x 2.3 ps                               (every slab pixel is written and re-read)
@@ -1046,7 +1076,11 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         // Density rule: every iteration writes and re-reads one slab pixel (8 B x (L / TS)^2) per image pixel, a global
         // atomic costs ~48 ns per event; below ~1 event per 12 pixels the plain atomic scatter is the faster one
         // (measured: 300k events on a 3550 x 6350 image, 0.41 vs 0.66 ms per iteration).
-        const bool dense = (double)w.scale_img_x * (double)w.scale_img_y < 12.0 * (double)c->n;
+        // ... on an image of tens of megapixels: the event-list form of the binned loop follows the events, and up to the
+        // 8.3 M pixels of a 1280x720 sensor at scale 3 it beats the atomics for sparse slices too (20k .. 500k events:
+        // 640x480 22 .. 28 us per iteration against 31 .. 40, 1280x720 48 .. 64 against 62 .. 86).
+        const bool dense = (double)w.scale_img_x * (double)w.scale_img_y < 12.0 * (double)c->n ||
+                           (double)w.scale_img_x * (double)w.scale_img_y <= 9.0e6;
         c->use_binned = (c->opt_binned == 2 || (c->opt_binned == 1 && dense)) && !c->force_split && !c->has_noise && c->n > 0 &&
                         g.nbins <= 8192 &&
                         (size_t)g.LR * g.L * 8 <= (size_t)kBinTileLdsMax && w.scale_img_x < (1 << 20);
@@ -1056,7 +1090,52 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
             if (rc != BF_OK) return rc;
             c->grid = g;
         }
-        h.hot.binned = c->use_binned ? 1 : 0;
+        // The one-kernel iteration (k_fused_pass; used by bf_run unless the context is co-scheduled with others): image
+        // tiles of 32 x 64 pixels -- 64 x 64 when the nine sort keys per tile would not fit the counting sort -- and a
+        // margin D that keeps a tile's edge strips (H + D wide, H = scale / 2 + 1) from overlapping.
+        // Where it pays (measured on MI355X, one context, cold runs; us per iteration fused / best two-kernel or atomic loop):
+        //   240x180: 50k events 16.1 / 22.0, 200k 17.9 / 19.6, 400k 20.5 / 18.2;   346x260: 20k 16.0 / 17.1, 50k 15.9 / 19.6,
+        //   100k 17.5 / 23.1, 200k 17.8 / 20.2, 400k 19.6 / 20.3, 1M 26.8 / 19.7;   640x480: 20k .. 400k 31 .. 38 / 22 .. 34.
+        // The events of a tile's edge strips are warped by up to four work-groups (2.1 x the events at D = 8) and a
+        // dense slice meets in few LDS words, so "auto" takes it for slices of at most one event per two image pixels on
+        // images up to 1.2 M pixels; a launch chain half as long is what it buys there.
+        c->fused_ok = false;
+        const double Pimg = (double)w.scale_img_x * (double)w.scale_img_y;
+        const bool fused_pays = Pimg <= 1.2e6 && 2.0 * (double)c->n <= Pimg;
+        if ((c->opt_fused == 2 || (c->opt_fused == 1 && fused_pays)) && c->opt_binned != 0 && !c->force_split && !c->has_noise && c->n > 0 && scale / 2 <= 4 &&
+            c->stencil_threads == 256 && w.scale_img_x < (1 << 20) && (long long)c->n < (1ll << 31)) {
+            BinGrid f;
+            memset(&f, 0, sizeof(f));
+            const int Hh = scale / 2 + 1;
+            auto tiles = [&](int rows) { return ((w.scale_img_x + rows - 1) / rows) * ((w.scale_img_y + 63) / 64); };
+            int rows = c->opt_fused_rows > 0 ? c->opt_fused_rows : (tiles(32) * kFusedZones <= 8192 ? 32 : 64);
+            int Dm = c->opt_fused_margin;
+            if (Dm > rows / 2 - Hh) Dm = rows / 2 - Hh;
+            if (Dm >= 1 && tiles(rows) * kFusedZones <= 8192) {
+                f.TS = 64; f.lg = 6; f.TSR = rows; f.D = Dm; f.fz = Hh + Dm;
+                f.nbc = (w.scale_img_y + 63) / 64;
+                f.nbr = (w.scale_img_x + rows - 1) / rows;
+                f.nbins = f.nbr * f.nbc * kFusedZones;   // sort keys
+                f.mul_r = (uint32_t)(0x100000000ull / (unsigned)f.TSR) + 1u;
+                f.L = f.LR = 0; f.mul_l = 0;
+                int rc = ensure_cplanes(c);
+                if (rc == BF_OK) rc = ensure_bin_buffers(c, f);
+                if (rc != BF_OK) return rc;
+                const int nt = f.nbr * f.nbc;
+                if (nt > c->ftab_alloc) {
+                    if (c->d_ftab) HIP_TRY(c, hipFree(c->d_ftab));
+                    c->d_ftab = nullptr;
+                    HIP_TRY(c, hipMalloc(&c->d_ftab, (size_t)nt * sizeof(FusedTab)));
+                    c->ftab_alloc = nt;
+                }
+                for (int i = 0; i < 2; ++i)
+                    if (!c->set[i].p2) HIP_TRY(c, hipMalloc(&c->set[i].p2, (size_t)c->cap_events * sizeof(float2)));
+                c->fgrid = f;
+                c->fused_ok = true;
+            }
+        }
+        h.hot.binned = (c->use_binned || c->fused_ok) ? 1 : 0;
+        h.hot.pp = 0; h.hot.redo = 0; h.hot.pend = 0; h.last_j = -1;
         h.n_events = (uint32_t)c->n;
         h.hot.bin_tbits = tbits > 62 ? 62 : tbits; h.hot.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
         h.hot.flip = 0;
@@ -1405,7 +1484,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         c->trace_alloc = o.trace_cap;
     }
     c->p_clean = false;   // the loop warps the events
-    const bool binned = c->use_binned;
+    // One slice context alone on the GPU: the one-kernel iteration when the slice qualifies (bf_set_cloud), else the
+    // two-kernel tile-binned loop when the slice is dense enough for it, else global atomics.
+    const bool fused = c->fused_ok && !c->opt_co_schedule;
+    const bool binned = c->use_binned || fused;
     DevState& h = c->hst;
     // Tile-binned mode sorts the events by the tile of their CURRENT target, so a warm-start
     // warp (bf_set_model) is applied before the sort rather than inside the first iteration.
@@ -1427,6 +1509,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     h.hot.need_rebin = binned ? 1 : 0;   // the first enqueued re-bin builds the bins
     h.hot.rebins = 0; h.ovf_total = 0;
     h.hot.cs = c->cs; h.hot.flip = 0;
+    h.hot.pp = 0; h.hot.redo = 0; h.hot.pend = 0; h.last_j = -1;
+    if (binned) h.drift_limit = c->opt_bin_predict ? 0.6 * (double)(fused ? c->fgrid.D : c->grid.D) : 1e300;
     if (!first_warp) h.hot.wp = identity_warp();
     h.ref_wp = h.hot.wp;
     const bool perm_at_start = c->has_perm;
@@ -1442,7 +1526,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // with the iteration's parity, and the overflow events of iteration j are counted in slot j % 3 (slot 2 stands
     // for "iteration -1": is plane buffer b0 ^ 1 still dirty from an earlier operator?).
     auto state_of = [&](int j) { return c->d_state + (j & 1); };
-    auto acc_of = [&](int j) { return c->d_acc + (size_t)(j & 1) * kAccGroups; };
+    auto acc_of = [&](int j) { return c->d_acc + (size_t)(fused ? ((j % 3) + 3) % 3 : (j & 1)) * kAccGroups; };
     auto ovf_of = [&](int j) { return c->d_ovf + ((j % 3) + 3) % 3; };
     // (one launch: the state, and the loop's counters / accumulators)
     launch_run_init(c->d_state, h, c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, binned || c->acc_dirty, c->stream);
@@ -1478,7 +1562,11 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     bool want_rebin = false;
     int last_rebin_at = 0;
     const bool snap_polled = binned && !warm_start;   // progress is read from the pinned snapshot (below)
-    if (snap_polled) *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
+    if (snap_polled) {
+        *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
+        *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0].run_tag) = 0ull;
+    }
+    int stall_allowance = 0;   // launches that may have been spent waiting for a re-bin (one-kernel iteration)
     bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
     static const bool host_timing = getenv("BF_HOST_TIMING") != nullptr;   // debug: where the host thread's time goes
@@ -1492,12 +1580,13 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // (0.6 x margin of drift), which covers the one-to-two batches of polling lag; anything
         // that still escapes takes the exact overflow path.
         if (binned && (batch == 0 || want_rebin)) {
-            int rc = enqueue_rebin(c, state_of(launched_iters), perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr);
+            int rc = enqueue_rebin(c, state_of(launched_iters), perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr, fused, launched_iters);
             if (rc != BF_OK) return rc;
             inf.launches += 3;
             want_rebin = false;
             skip_rebin_checks = 1;   // the next snapshot predates this re-bin
             last_rebin_at = launched_iters;
+            if (fused && batch > 0) stall_allowance += 3 * o.poll_interval;
         }
         // A warm start (bf_set_model) converges in a handful of iterations: its first batch is short and is
         // polled at once, so that ~20 no-op launches and a second poll are not queued behind it.
@@ -1510,6 +1599,27 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         for (int k = 0; k < batch_len; ++k) {
             const bool warp = first ? first_warp : true;
             const int j = launched_iters;
+            if (fused) {   // warp + scatter + stencil + moments in one launch; the update at the head of the next
+                FusedArgs fa;
+                fa.sets = ev_sets(c);
+                fa.ftab = c->d_ftab;
+                fa.st_in = state_of(j); fa.st_out = state_of(j + 1);
+                fa.snap = warm_start ? nullptr : &c->h_state[0];
+                fa.acc_in = acc_of(j - 1); fa.acc_out = acc_of(j); fa.acc_zero = acc_of(j + 1);
+                fa.lost = lost_flag(c);
+                fa.trace = trace;
+                fa.nbr = c->fgrid.nbr; fa.nbc = c->fgrid.nbc;
+                fa.R = c->win.scale_img_x; fa.C = c->win.scale_img_y;
+                fa.j = j;
+                fa.warp = warp ? 1 : 0;
+                ProfScope ps(c, 0, c->n);
+                HIP_TRY(c, launch_fused_pass(fa, c->win.scale / 2, c->fgrid.TSR, c->stream));
+                first = false;
+                buf ^= 1;
+                ++launched_iters;
+                inf.launches += 1;
+                continue;
+            }
             if (binned) {
                 BinScatterArgs ba;
                 ba.sets = ev_sets(c);
@@ -1568,7 +1678,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
             if (head_update) {   // `done` of the batch's last iteration: apply its update now (normally the next launch would)
                 launch_finish_update(state_of(launched_iters), acc_of(launched_iters - 1), ovf_of(launched_iters - 1),
-                                     launched_iters, buf ^ 1, trace, &c->h_state[batch & 1], c->stream);
+                                     launched_iters, buf ^ 1, trace, &c->h_state[batch & 1], c->stream, fused ? lost_flag(c) + (launched_iters + 2) % 3 : nullptr);
                 inf.launches++;
             }
             ProfScope ps(c, 3);
@@ -1589,6 +1699,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // when less than one batch is left in the queue and sleeps in between (the queue hides its wake-up latency).
             const volatile unsigned long long* w0p = reinterpret_cast<const volatile unsigned long long*>(&c->h_state[0]);
             const volatile int32_t* rebin_p = &c->h_state[0].hot.need_rebin;
+            const volatile unsigned long long* lastj_p = reinterpret_cast<const volatile unsigned long long*>(&c->h_state[0].run_tag);
             bool done_seen = false;
             int gpu_it = 0;
             if (host_timing) { const double t = ht_now(); ht_launch += t - ht_mark; ht_mark = t; }
@@ -1606,6 +1717,12 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 const int32_t sdone = (int32_t)(uint32_t)(w0 & 0xffffffffull), sit = (int32_t)(uint32_t)(w0 >> 32);
                 if (sdone == h.run_tag) { done_seen = true; break; }
                 gpu_it = (sdone == 0) ? sit : 0;
+                // (one-kernel iteration: progress is counted in LAUNCHES -- passes that wait for a re-bin, or repeat one,
+                // do not advance the iteration counter)
+                if (fused) {
+                    const unsigned long long wj = *lastj_p;   // (run_tag, last_j): one 8-byte store of the device
+                    gpu_it = ((int32_t)(uint32_t)(wj & 0xffffffffull) == h.run_tag) ? (int32_t)(uint32_t)(wj >> 32) + 1 : 0;
+                }
                 if (launched_iters - gpu_it <= o.poll_interval) break;   // less than a batch left in the queue: feed it
                 if (c->opt_blocking_poll) {
                     struct timespec ts = {0, 20000};
@@ -1622,8 +1739,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             if (host_timing) { const double t = ht_now(); ht_wait += t - ht_mark; ht_mark = t; }
             inf.polls++;
             if (done_seen) break;
-            if (gpu_it >= last_rebin_at && gpu_it > 0 && *rebin_p) want_rebin = true;   // (a snapshot older than the last re-bin does not count)
-            if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
+            if ((fused ? gpu_it > last_rebin_at : gpu_it >= last_rebin_at) && gpu_it > 0 && *rebin_p) want_rebin = true;   // (a snapshot older than the last re-bin does not count)
+            if (launched_iters - stall_allowance > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;
         }
@@ -1646,7 +1763,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 break;
             }
             if (binned && ws.hot.need_rebin) want_rebin = true;
-            if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
+            if (launched_iters - stall_allowance > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;
         }
@@ -1666,7 +1783,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         }
         if (skip_rebin_checks > 0) --skip_rebin_checks;
         else if (binned && snap.hot.need_rebin) want_rebin = true;
-        if (launched_iters > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
+        if (launched_iters - stall_allowance > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
             return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
     }
     if (host_timing)
@@ -1708,14 +1825,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
 
     const DevState d = fin;
     h = d;   // model, dividers, warp parameters, plane-buffer dirtiness
-    if (binned) {   // the last iteration scattered its overflow events into buffer b0 ^ ((it - 1) & 1); the other one is clean
+    h.hot.pp = 0; h.hot.redo = 0; h.hot.pend = 0;   // (the final warp left the products in the set's first array)
+    if (binned && !fused) {   // the last iteration scattered its overflow events into buffer b0 ^ ((it - 1) & 1); the other one is clean
         h.hot.ovf_cnt[b0 ^ (d.hot.it & 1)] = 0;
         h.hot.ovf_cnt[b0 ^ (d.hot.it & 1) ^ 1] = d.last_ovf ? 1u : 0u;
     }
 
     // iterations executed alternate buffers starting at b0; the next scatter goes to the
-    // buffer the last stencil left clean.
-    c->cur = b0 ^ (d.hot.it & 1);
+    // buffer the last stencil left clean.  (The one-kernel loop touches neither plane buffer: what was dirty stays dirty,
+    // hot.ovf_cnt came back from the device as it went.)
+    c->cur = fused ? b0 : (b0 ^ (d.hot.it & 1));
     c->trace_valid = d.hot.it < o.trace_cap ? d.hot.it : o.trace_cap;
     inf.rc = d.rc;
     inf.iterations = d.hot.it;

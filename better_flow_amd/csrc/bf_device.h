@@ -23,6 +23,7 @@
 //   state   DevState[2] the model, loop control and warp parameters of the fused run (the tile-binned
 //                    loop ping-pongs: the update runs at the head of the next warp+scatter launch)
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/bf_accel.h"
@@ -68,7 +69,28 @@ struct BinGrid {
     int32_t LR;        // TSR + 2 D
     uint32_t mul_r;    // floor(2^32 / TSR) + 1: row / TSR == __umulhi(row, mul_r) for row < 2^20
     uint32_t mul_l;    // floor(2^32 / L) + 1: index / L of a tile-local pixel index (< 2^16)
+    int32_t fz;        // one-kernel iteration (k_fused_pass): width E of the edge strips of a tile, 0 = the two-kernel loop.
+                       // The counting sort then keys events by (bin, zone): nbins counts KEYS, kFusedZones per image tile.
+    int32_t pad_;
 };
+
+// One-kernel iteration (bf_binned.hip, k_fused_pass).  A tile's events are sorted into nine zones by where their target
+// lay when the bins were built: the centre and, clockwise from the top-left corner, the eight pieces of the strip of width
+// E = H + D along the tile's edge (H = scale / 2 + 1: box sum + Scharr halo; D: the drift a binning tolerates).  A
+// work-group reads its own tile's events and the strips of the eight neighbouring tiles that face it -- ten contiguous
+// ranges of the sorted arrays; nothing is stored twice.
+constexpr int kFusedZones = 9;    // C, TL, T, TR, R, BR, B, BL, L
+constexpr int kFusedRanges = 10;  // own tile; N, S, W neighbours (one range each); E neighbour (two); four corners
+struct FusedTab {                 // per tile, written by the counting sort's scan (k_bin_scan), read with scalar loads
+    uint32_t pre[kFusedRanges];   // running index of the first event of range r (pre[0] == 0)
+    uint32_t off[kFusedRanges];   // global index of an event of range r = its running index + off[r]
+    uint32_t total;
+    uint32_t zone[kFusedZones - 1];   // running index of the first event of zones 1 .. 8 inside range 0 (the tile's own events)
+    uint32_t spare[3];
+};
+constexpr int kFusedTabWords = (int)(sizeof(FusedTab) / 4);
+static_assert(kFusedTabWords == 32, "one s_load_dwordx16 pair");
+
 
 // Fields every kernel of the loop reads.  They are contiguous so that a kernel issues ONE
 // burst of scalar loads for them before it branches on `done` (each dependent scalar load
@@ -78,6 +100,10 @@ struct HotState {
     uint32_t ovf_cnt[2];      // plane buffer [i] is dirty (stand-alone operators and the global-atomic loop; the
                               // tile-binned loop counts its overflow events in bf_ctx::d_ovf, outside the state)
     int32_t need_rebin, rebins;
+    int32_t pp, redo;                 // one-kernel iteration: which of a set's two product arrays is current; the next pass repeats
+                                      // the scatter of the last one after a re-bin (its sums were incomplete)
+    int32_t pend, spare_;             // ... the sums of the last pass await their update (launch numbers do not tell: passes
+                                      // that wait for a re-bin or repeat one do not advance the iteration)
     int32_t cs, flip, bin_ok, fmt;    // live event set; flip = a re-bin moved the events to set cs^1; fmt = this slice's scatter writes
                                       // COMPACT lists (1) instead of dense slabs (0) (informative: bf_binned.hip);
                                       // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)
@@ -103,10 +129,13 @@ struct DevState {
     double t_abs_max, r_max, drift_limit;
     long long t_span;                 // tmax - tmin of the slice (ns): bound of one event's time addend
     int32_t run_tag;                  // what `done` is set to (non-zero; bf_run gives every run its own)
-    uint32_t pad3;
+    int32_t last_j;                   // one-kernel iteration: launch number of the pass that wrote this copy of the state
     // --- model ---
     bf_model model;
 };
+
+static_assert(offsetof(DevState, run_tag) % 8 == 0 && offsetof(DevState, last_j) == offsetof(DevState, run_tag) + 4,
+              "(run_tag, last_j) is one 8-byte word of the host's polled snapshot");
 
 // The two event sets as kernel arguments; the live one is sets[hot.cs ^ hot.flip].
 struct EvSetPtrs {
@@ -114,6 +143,8 @@ struct EvSetPtrs {
     int32_t* t;
     float2* p;
     uint32_t* perm;
+    float2* p2;   // one-kernel iteration: the products ping-pong between p and p2 (hot.pp), so that a neighbouring tile's
+                  // work-group reads the previous positions while the owner stores the new ones
 };
 struct EvSets {
     EvSetPtrs s[2];

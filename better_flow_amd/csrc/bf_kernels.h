@@ -97,7 +97,7 @@ void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
 // applies a pending update (sums in `acc`) to `st` in place: the tile-binned loop's update outside a warp+scatter launch
 void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
-                          DevState* snap, hipStream_t s);
+                          DevState* snap, hipStream_t s, const uint32_t* lost = nullptr);
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s);
 void launch_unpermute(const double2* src, const uint32_t* perm, double2* dst, long long n, hipStream_t s);
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,
@@ -128,7 +128,8 @@ int bin_kernel_setup();
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
                   uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
-                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s);
+                  uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s,
+                  uint32_t* ftab = nullptr, uint32_t* lost = nullptr);   // (g.fz != 0: the one-kernel iteration's range table and flag)
 struct BinScatterArgs {
     EvSets sets;
     const uint32_t* bin_start;
@@ -150,6 +151,25 @@ struct BinScatterArgs {
     unsigned long long* tl;
 };
 hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
+// The one-kernel iteration (k_fused_pass, bf_binned.hip): warp + scatter + stencil + moments of one image tile per work-group.
+struct FusedArgs {
+    EvSets sets;
+    const uint32_t* ftab;            // FusedTab per tile (written by the counting sort's scan)
+    const DevState* st_in;           // state as of the previous launch ...
+    DevState* st_out;                // ... and with the pending update applied (written by work-group 0)
+    DevState* snap;                  // optional: pinned host copy of st_out, polled by the host
+    MomentAcc* acc_in;               // moment sums of the previous pass
+    MomentAcc* acc_out;              // this pass adds here
+    MomentAcc* acc_zero;             // cleared for the next pass
+    uint32_t* lost;                  // [3], by launch number mod 3: raised by a pass that cannot vouch for its sums (an event moved
+                                     // further than the bins allow)
+    bf_trace_rec* trace;
+    int nbr, nbc;                    // image tiles
+    int R, C;
+    int j;                           // launch number (the update of iteration j runs at the head of launch j + 1)
+    int warp;                        // 0: scatter the events where their stored products put them (first pass of a cold run)
+};
+hipError_t launch_fused_pass(const FusedArgs& a, int half_scale, int rows_per_tile, hipStream_t s);
 void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, bool init_loop, hipStream_t s);
 
 // bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)

@@ -137,13 +137,16 @@ __global__ __launch_bounds__(kThreads) void k_final_warp(WarpScatterArgs a) {
     const uint32_t* xy = a.xy;
     const int32_t* t = a.t;
     float2* p = a.p;
+    const float2* src = a.p;
     if (a.pick_set) {   // tile-binned loop: the device knows which set holds the (sorted) events
         const EvSetPtrs e = (hs.cs ^ hs.flip) ? a.sets.s[1] : a.sets.s[0];
         xy = e.xy; t = e.t; p = e.p;
+        if (hs.pp) src = e.p2;   // one-kernel iteration: the current products may sit in the set's second array;
+        else src = e.p;          // the final ones always go to the first
     }
     const uint32_t v = xy[i];
     const int32_t ti = t[i];
-    float2 q = p[i];
+    float2 q = src[i];
     double nx, ny;
     warp_products(hs.wp, pr_from_p(v & 0xffffu, q.x), pr_from_p(v >> 16, q.y), ti, q, nx, ny);
     p[i] = q;

@@ -77,7 +77,9 @@ for ci in range(cases):
              ("nopredict", {"binned": 2, "bin_predict": 0, "bin_margin": 2}),
              ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}), ("merged", {"binned": 2, "bin_compact": 3}), ("merged_co", {"binned": 2, "bin_compact": 3, "co_schedule": 1}),
              ("dense_co", {"binned": 2, "bin_compact": 0, "co_schedule": 1}), ("compact_co", {"binned": 2, "bin_compact": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
-             ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))})]
+             ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))}),
+             ("fused", {"fused": 2}), ("fused_tight", {"fused": 2, "fused_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
+             ("fused64", {"fused": 2, "fused_rows": 64, "fused_margin": int(rng.choice([4, 8, 20]))}), ("fused_unpacked", {"fused": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))})]
     for name, kv in modes:
         a = accel.Accel(max_events=max(n, 16), max_rows=s * H + s, max_cols=s * W + s)
         for k_, v_ in kv.items():

@@ -366,6 +366,14 @@ int main(int argc, char** argv) {
         xy[i] = fx | (fy << 16);
         t[i] = (int32_t)(rng() % 30000000ull);
     }
+    if (argc > 4) {   // a real slice: int32 fr_x[n], fr_y[n], t[n] (python: np.concatenate of synth.make_slice's arrays .tofile)
+        FILE* f = fopen(argv[4], "rb");
+        std::vector<int32_t> raw(3 * n);
+        if (!f || fread(raw.data(), 4, 3 * n, f) != 3 * n) { fprintf(stderr, "cannot read %zu events from %s\n", n, argv[4]); return 1; }
+        fclose(f);
+        for (size_t i = 0; i < n; ++i) { xy[i] = (uint32_t)raw[i] | ((uint32_t)raw[n + i] << 16); t[i] = raw[2 * n + i]; }
+        printf("events of %s\n", argv[4]);
+    }
     for (int D : {4, 8, 16}) {
         run<4, 4>("64x64 / 1024 thr / U4", xy, t, S, Hs, Ws, D);
         run<4, 8>("64x64 / 1024 thr / U8", xy, t, S, Hs, Ws, D);

@@ -4,7 +4,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from better_flow_amd import accel, synth
-N, H, W, s = 1000000, int(os.environ.get("BF_RUN_H", "260")), int(os.environ.get("BF_RUN_W", "346")), 3
+N, H, W, s = int(os.environ.get("BF_RUN_N", "1000000")), int(os.environ.get("BF_RUN_H", "260")), int(os.environ.get("BF_RUN_W", "346")), 3
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 sl = synth.make_slice(N, H, W, 0.030, seed=1)
 acc = accel.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)

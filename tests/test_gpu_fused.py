@@ -1,0 +1,80 @@
+"""The one-kernel iteration (k_fused_pass, bf_binned.hip): warp + scatter + stencil + moments of one image tile per
+work-group, events of a tile's edge strips read by the neighbouring tiles' work-groups as well.
+
+It must return the bits of the two-kernel tile-binned loop (same integer accumulators, same per-sub-tile f64 partials) --
+model, iteration count, every trace record, per-event flow, and the warm start that follows -- with the default margin,
+with margins so small that events outrun their bins (the `lost` flag, a re-bin, the pass repeated before its update),
+with 64-row tiles, with the unpacked LDS planes, without the predictive re-bin.  And `auto` must take it exactly for the
+slices it was measured to be faster on (bf_set_cloud).
+"""
+import numpy as np
+import pytest
+
+from better_flow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run(accel_mod, sl, H, W, s, opts, max_iter=-1):
+    a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+    for k, v in opts.items():
+        a.set_option(k, v)
+    a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    a.set_cloud(s, H, W)
+    o = a.default_opts()
+    o.res_x, o.res_y, o.want_uv, o.trace_cap, o.max_iter = H, W, 1, 4096, max_iter
+    rc, m, info = a.run(o)
+    trace = [t.model.as_dict() for t in a.get_trace(4096)]
+    u, v = a.compute_uv()
+    a.set_model(m)
+    rc2, m2, info2 = a.run(o)
+    trace2 = [t.model.as_dict() for t in a.get_trace(4096)]
+    u2, v2 = a.compute_uv()
+    a.close()
+    return dict(rc=(rc, rc2), it=(info.iterations, info2.iterations), model=(m.as_dict(), m2.as_dict()), trace=(trace, trace2),
+                flow=(u.tobytes(), v.tobytes(), u2.tobytes(), v2.tobytes()), rebins=info.rebins, launches=info.launches)
+
+
+VARIANTS = (("default margin", {}), ("margin 2", {"fused_margin": 2}), ("margin 1", {"fused_margin": 1}),
+            ("64-row tiles", {"fused_rows": 64}), ("unpacked planes", {"bin_pack_limit": 20}),
+            ("no predictive re-bin, margin 3", {"bin_predict": 0, "fused_margin": 3}))
+
+
+@pytest.mark.parametrize("case", [(1000000, 260, 346, 3, 1, -1), (300000, 480, 640, 3, 2, -1), (200000, 180, 240, 5, 3, -1),
+                                  (50000, 180, 240, 1, 4, -1), (50000, 260, 346, 3, 6, -1), (3000000, 480, 640, 3, 8, 60)],
+                         ids=lambda c: "%dev_%dx%d_s%d" % (c[0], c[2], c[1], c[3]))
+def test_same_bits_as_the_two_kernel_loop(accel_mod, case):
+    n, H, W, s, seed, max_iter = case
+    sl = synth.make_slice(n, H, W, 0.03, seed=seed)
+    ref = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 0}, max_iter)
+    assert ref["rc"][0] == 0 and ref["it"][0] > 20
+    for name, o in VARIANTS:
+        got = run(accel_mod, sl, H, W, s, dict({"binned": 2, "fused": 2}, **o), max_iter)
+        if name == "default margin":   # (tight margins spend launches waiting for re-bins)
+            assert got["launches"] < 0.75 * ref["launches"], "the one-kernel loop was not the one that ran"
+        for key in ("rc", "it", "model", "trace", "flow"):
+            assert got[key] == ref[key], (name, key)
+        if name == "margin 1":
+            assert got["rebins"] > ref["rebins"], "margin 1 must exercise the lost -> re-bin -> repeat path"
+
+
+def test_auto_takes_it_where_it_was_measured_faster(accel_mod):
+    """One launch per iteration (plus re-bins) tells which loop ran."""
+    for (n, H, W, want_fused) in ((50000, 180, 240, True), (50000, 260, 346, True), (200000, 260, 346, True), (1000000, 260, 346, False),
+                                  (100000, 480, 640, False)):
+        sl = synth.make_slice(n, H, W, 0.03, seed=9)
+        a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=3 * H + 3, max_cols=3 * W + 3)
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        a.set_cloud(3, H, W)
+        o = a.default_opts()
+        o.res_x, o.res_y, o.max_iter = H, W, 40
+        rc, m, info = a.run(o)
+        one_kernel = info.launches < 1.5 * info.iterations + 3 * info.rebins + 8
+        assert one_kernel == want_fused, (n, H, W, info.launches, info.iterations, info.rebins)
+        # ... and a context that shares the GPU with others keeps the two-kernel loop
+        a.set_option("co_schedule", 1)
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        a.set_cloud(3, H, W)
+        rc2, m2, info2 = a.run(o)
+        assert info2.launches >= 2 * info2.iterations and m2.as_dict() == m.as_dict() and info2.iterations == info.iterations
+        a.close()

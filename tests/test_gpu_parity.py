@@ -403,6 +403,8 @@ def test_golden_stream_gpu(accel_mod):
 def _run_mode(accel_mod, sl, H, W, scale, trace_cap=0, warm=None, **options):
     acc = accel_mod.Accel(max_events=max(len(sl["t"]), 8192), max_rows=scale * H + scale,
                           max_cols=scale * W + scale)
+    if options.get("binned") == 2 and "fused" not in options:
+        options = dict(options, fused=0)   # "binned = 2" names the two-kernel tile-binned loop; the one-kernel loop is asked for by name
     for k, v in options.items():
         acc.set_option(k, v)
     acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
@@ -428,8 +430,12 @@ def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
     sl = synth.make_slice(60000, H, W, 0.05, seed=17)
     ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=0)
     assert ref[2].rebins == 0
+    # (fused = 2: the one-kernel iteration, k_fused_pass -- default margin, margins so small that events outrun their
+    # bins and passes are repeated on fresh ones, 64-row tiles, the unpacked LDS planes)
     for opts in (dict(binned=2), dict(binned=2, bin_tile=32, bin_margin=2),
-                 dict(binned=2, bin_tile=16, bin_margin=4), dict(binned=2, bin_tile=128, bin_margin=6)):
+                 dict(binned=2, bin_tile=16, bin_margin=4), dict(binned=2, bin_tile=128, bin_margin=6),
+                 dict(fused=2), dict(fused=2, fused_margin=1), dict(fused=2, fused_margin=2, bin_predict=0),
+                 dict(fused=2, fused_rows=64), dict(fused=2, bin_pack_limit=20)):
         got = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, **opts)
         assert got[0] == ref[0] and got[2].iterations == ref[2].iterations, opts
         assert got[2].rebins >= 1
@@ -455,10 +461,11 @@ def test_binned_warm_start_bit_identical(accel_mod):
     b = synth.make_slice(40000, H, W, 0.05, seed=32)
     cold = _run_mode(accel_mod, a, H, W, 3, binned=0)
     w0 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=0)
-    w1 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=2)
-    assert w0[2].iterations == w1[2].iterations and w0[1].as_dict() == w1[1].as_dict()
-    for x, y in zip(w0[4], w1[4]):
-        assert np.array_equal(x, y)
+    for opts in (dict(binned=2), dict(fused=2), dict(fused=2, fused_margin=1)):
+        w1 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], **opts)
+        assert w0[2].iterations == w1[2].iterations and w0[1].as_dict() == w1[1].as_dict(), opts
+        for x, y in zip(w0[4], w1[4]):
+            assert np.array_equal(x, y), opts
 
 
 def test_tile_grid_matches_per_tile_oracle(oracle_lib, accel_mod):
@@ -615,7 +622,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
     om = oracle_lib.Model()
     orc, oloop, otr = oc2.run(ow2, om, max_iter=K, res_x=H, res_y=W, trace_cap=K + 1)
     runs = {}
-    for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2)),
+    for name, opts in (("binned", dict(binned=2, fused=0)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2, fused=0)), ("fused", dict(fused=2)),
                        ("tail_update", dict(binned=2, co_schedule=1)), ("compact", dict(binned=2, bin_compact=2)),
                        ("dense", dict(binned=2, bin_compact=0)), ("merged", dict(binned=2, bin_compact=3))):
         a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
@@ -628,8 +635,9 @@ def test_full_size_config2(oracle_lib, accel_mod):
         rc, m, info = a2.run(o)
         runs[name] = (rc, info.iterations, m.as_dict(), [t_.model.as_dict() for t_ in a2.get_trace(K + 1)], a2.compute_uv())
         a2.close()
-    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4] == runs["compact"][:4] == runs["dense"][:4] == runs["merged"][:4]
+    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4] == runs["compact"][:4] == runs["dense"][:4] == runs["merged"][:4] == runs["fused"][:4]
     assert np.array_equal(runs["binned"][4][0], runs["atomics"][4][0])
+    assert np.array_equal(runs["binned"][4][0], runs["fused"][4][0]) and np.array_equal(runs["binned"][4][1], runs["fused"][4][1])
     assert runs["binned"][1] == oloop.itercount == K + 1
     for k in range(K + 1):
         g, o_ = runs["binned"][3][k], otr[k].model
@@ -1158,6 +1166,9 @@ def test_spinning_poll_with_long_batches(accel_mod):
 
     want = go(binned=2)
     assert want[0] == 0 and want[2] > 100
+    assert go(fused=2) == want
+    assert go(fused=2, blocking_poll=0, poll=256) == want
+    assert go(fused=2, fused_margin=1, blocking_poll=0, poll=64) == want   # (passes that wait for a re-bin: progress is counted in launches)
     assert go(binned=2, blocking_poll=0, poll=256) == want
     assert go(binned=2, blocking_poll=0, poll=256, co_schedule=1) == want
     assert go(binned=2, blocking_poll=0, poll=256, watchdog_ms=2000) == want

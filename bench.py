@@ -552,6 +552,15 @@ def main():
                                      "note": "-o: per-event flow read back per slice, de-duplicated table, text written on %s"
                                              % ("several threads")},
             }
+            import default_ring_bench
+            rr = default_ring_bench.run(events=5000000, reps=2)
+            front_end["reference_ring"] = {
+                "what": "the same tool with the reference's compiled-in ring (50 000 events, a slice every 20 000 events / 33 ms, "
+                        "warm-start chain) on a 240x180 stream of 250 000 events per 33 ms: small slices, sequential chain -- the "
+                        "loop's latency (one-kernel iteration), not its throughput",
+                "events": rr["events"], "slices": rr["slices"], "iterations": rr["iterations"],
+                "mevents_per_s": rr["steady_mevents_per_s"], "us_per_iteration": 1e6 * rr["steady_s"] / max(1, rr["iterations"]),
+            }
         except Exception as e:   # noqa: BLE001 -- the front end is an extra; the metric does not depend on it
             front_end = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -606,6 +615,19 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        if roofline is not None and "iteration_algorithmic_bytes" in roofline and roofline.get("launches"):
+            # the timed region itself (all slice contexts of one GPU together) by the same SURVEY 8(d) price per iteration:
+            # what fraction of the HBM peak the headline number corresponds to
+            its_per_s = iters_all / elapsed / world
+            roofline["headline_regime"] = {
+                "what": "algorithmic bytes per second of the timed region (%d slice contexts per GPU in flight): iterations per "
+                        "second x iteration_algorithmic_bytes, over the HBM peak" % B,
+                "iterations_per_s_per_gpu": its_per_s,
+                "achieved": its_per_s * roofline["iteration_algorithmic_bytes"] / 1e9,
+                "frac": its_per_s * roofline["iteration_algorithmic_bytes"] / 1e9 / HBM_PEAK_GBPS,
+                "frac_of_measured_copy_ceiling": (its_per_s * roofline["iteration_algorithmic_bytes"] / 1e9 / roofline["measured_copy_ceiling_gbps"])
+                                                 if roofline.get("measured_copy_ceiling_gbps") else None,
+            }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -15,6 +15,7 @@
 #include <ctime>
 #include <new>
 #include <utility>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -631,6 +632,26 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         fprintf(stderr, "bf_create: %s\n", c->err);
         bf_destroy(c);
         return rc;
+    }
+    // BF_ACCEL_OPTIONS="key=value,key=value": bf_set_option calls for every context of the process -- for A/B runs through a
+    // host that has no flag for an option (the command line).  A bad entry fails the creation loudly.
+    if (const char* env = getenv("BF_ACCEL_OPTIONS")) {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            pos = end + 1;
+            if (item.empty()) continue;
+            const size_t eq = item.find('=');
+            const int orc = eq == std::string::npos ? BF_ERR_ARG : bf_set_option(c, item.substr(0, eq).c_str(), atoll(item.c_str() + eq + 1));
+            if (orc != BF_OK) {
+                fprintf(stderr, "bf_create: BF_ACCEL_OPTIONS entry '%s': %s\n", item.c_str(), eq == std::string::npos ? "expected key=value" : c->err);
+                bf_destroy(c);
+                return orc;
+            }
+        }
     }
     *out = c;
     return BF_OK;

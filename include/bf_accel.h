@@ -82,7 +82,8 @@ typedef struct bf_run_info {
     int32_t polls;           /* host polls of the done flag (diagnostic)                */
     int32_t rebins;          /* counting sorts of the events by image tile (diagnostic)  */
     int32_t overflow_events; /* events that left their bin's LDS tile, summed over the
-                                iterations; they take an exact global-atomic path          */
+                                iterations; they take an exact global-atomic path.  The one-kernel loop ("fused") has no
+                                such path: there, the passes it repeated after a re-bin    */
 } bf_run_info;
 
 /* One record per iteration_step (trajectory tests). */
@@ -139,9 +140,20 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  * next bf_set_cloud).  Keys:
  *   "force_split"  1: keep the event-count and time-sum accumulators in separate planes
  *                  even when they fit one packed 64-bit word.
- *   "binned"       tile-binned LDS scatter inside bf_run: 1 (default) when the slice is dense enough to pay
- *                  for it (fewer than ~12 image pixels per event), 2 whenever possible, 0 never (one
- *                  global atomic per event).  Results are identical.
+ *   "binned"       tile-binned LDS scatter inside bf_run: 1 (default) when it pays (fewer than ~12 image pixels per
+ *                  event, or an image of at most 9 M pixels -- sparse slices then take its event-list form), 2 whenever
+ *                  possible, 0 never (one global atomic per event).  Results are identical.
+ *   "fused"        the one-kernel iteration inside bf_run (warp + LDS scatter + stencil + moment sums of one image tile
+ *                  per work-group; the events of a tile's edge strips are also read by the neighbouring tiles' work-groups):
+ *                  1 (default) where it is the faster loop -- slices of at most one event per two image pixels on images
+ *                  of at most 1.2 M pixels, i.e. the reference's 50 000-event ring on a 240x180 or 346x260 sensor --, 2
+ *                  whenever possible, 0 never.  Never for a "co_schedule" context.  Bit-identical to the two-kernel loop;
+ *                  bf_run_info::overflow_events then counts the passes that were repeated after a re-bin because an
+ *                  event had moved further than "fused_margin" (detected exactly, never a wrong sum).
+ *   "fused_margin" scaled pixels an event may move between two re-bins of that loop (default 8; at most half a tile
+ *                  minus scale / 2 + 1).    "fused_rows"  rows of its image tiles: 0 (default: 32, or 64 when the image
+ *                  has too many tiles for the counting sort), 32, 64.
+ *   BF_ACCEL_OPTIONS (environment, read by bf_create): "key=value,key=value" applied to every context of the process.
  *   "bin_tile"     tile WIDTH of the binned scatter (0 = default: chosen per slice with the height; or 16, 32,
  *                  64, 128).
  *   "bin_pack_limit"  bits the per-bin accumulator packing may use (default 64).  The counting sort sizes the

@@ -47,6 +47,8 @@ def test_bench_single_process():
     assert "error" not in fe, fe
     assert fe["file_to_last_model"]["slices"] == 8 and fe["steady_state_warm"]["mevents_per_s"] > 100
     assert fe["with_flow_output"]["output_s"] > 0
+    assert fe["reference_ring"]["mevents_per_s"] > 5 and fe["reference_ring"]["slices"] > 100   # the reference's compiled-in ring
+    assert 0.2 < d["roofline"]["headline_regime"]["frac"] < 1
     assert d["value_host_to_host"] == d["regimes"]["host_to_host"]["cold"]["mevents_per_s"]
     assert d["targets"]["met_by"]["mevents_per_s"] > 1000          # north_star: >= 1 Gevents/s (warm STM, H2D included)
     assert 0 < d["roofline"]["iteration_frac"] < 1

@@ -1582,7 +1582,12 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
     bool want_rebin = false;
     int last_rebin_at = 0;
-    const bool snap_polled = binned && !warm_start;   // progress is read from the pinned snapshot (below)
+    // A warm start that is expected to converge in a handful of iterations (the previous one did) is polled batch by batch,
+    // the final warp riding along: "quick".  One that is expected to run long -- the reference's own ring: ~115 iterations per
+    // warm-started slice -- is fed and polled like a cold run: two-iteration batches with a blocking poll each cost it a
+    // host round trip every other iteration (22 instead of 14 us per iteration on a 50 000-event slice).
+    const bool quick_warm = warm_start && c->warm_iters_hint < 3 * o.poll_interval;
+    const bool snap_polled = binned && !quick_warm;   // progress is read from the pinned snapshot (below)
     if (snap_polled) {
         *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
         *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0].run_tag) = 0ull;
@@ -1612,7 +1617,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // A warm start (bf_set_model) converges in a handful of iterations: its first batch is short and is
         // polled at once, so that ~20 no-op launches and a second poll are not queued behind it.
         int batch_len = o.poll_interval;
-        if (warm_start) {   // one more iteration than the previous warm start needed, then two at a time
+        if (quick_warm) {   // one more iteration than the previous warm start needed, then two at a time
             batch_len = batch == 0 ? c->warm_iters_hint + 1 : 2;
             if (batch_len < 2) batch_len = 2;
             if (batch_len > o.poll_interval) batch_len = o.poll_interval;
@@ -1625,7 +1630,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 fa.sets = ev_sets(c);
                 fa.ftab = c->d_ftab;
                 fa.st_in = state_of(j); fa.st_out = state_of(j + 1);
-                fa.snap = warm_start ? nullptr : &c->h_state[0];
+                fa.snap = quick_warm ? nullptr : &c->h_state[0];
                 fa.acc_in = acc_of(j - 1); fa.acc_out = acc_of(j); fa.acc_zero = acc_of(j + 1);
                 fa.lost = lost_flag(c);
                 fa.trace = trace;
@@ -1652,7 +1657,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.st_in = state_of(j); ba.st_out = state_of(j + 1);
                 ba.acc = head_update ? acc_of(j - 1) : nullptr;
                 ba.ovf_cur = ovf_of(j); ba.ovf_prev = ovf_of(j - 1);
-                ba.snap = warm_start ? nullptr : &c->h_state[0];
+                ba.snap = quick_warm ? nullptr : &c->h_state[0];
                 ba.trace = trace;
                 ba.g = c->grid;
                 ba.cur = buf; ba.j = j;
@@ -1692,7 +1697,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             ++launched_iters;
             inf.launches += 2;
         }
-        if (warm_start) {
+        if (quick_warm) {
             // A warm start is polled batch by batch (no pipelining: it rarely needs a second batch), and the
             // final warp rides along with every batch, gated on `done` (check_done 2) and picking the event
             // set on the device: when the batch was enough -- the usual case -- nothing is left to launch
@@ -1765,7 +1770,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;
         }
-        if (!(warm_start && head_update))   // (there k_finish_update has written the state to the pinned copy itself)
+        if (!(quick_warm && head_update))   // (there k_finish_update has written the state to the pinned copy itself)
             HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], state_of(binned ? launched_iters : 0), sizeof(DevState),
                                       hipMemcpyDeviceToHost, c->stream));
         // A cold run is polled one batch behind the launches, so its wait can sleep (the wake-up latency hides
@@ -1773,8 +1778,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // for the batch it has just launched and spins.
         hipEvent_t* pev = c->poll_ev;
         HIP_TRY(c, hipEventRecord(pev[batch & 1], c->stream));
-        if (batch == 0 && !warm_start) continue;
-        if (warm_start) {   // look at this batch straight away
+        if (batch == 0 && !quick_warm) continue;
+        if (quick_warm) {   // look at this batch straight away
             HIP_TRY(c, hipEventSynchronize(pev[batch & 1]));
             inf.polls++;
             const DevState& ws = c->h_state[batch & 1];

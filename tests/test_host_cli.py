@@ -611,3 +611,33 @@ def test_cli_img_frames_gpu_match_oracle(oracle_cli, events_txt, tmp_path):
         assert (np.abs(qa.astype(int) - qb.astype(int)).max(axis=2) > 1).mean() < 0.02
         assert np.array_equal(v, b)
     assert [t.splitlines()[3:5] for t in to] == [t.splitlines()[3:5] for t in tg]   # Events / New events lines
+
+
+@pytest.mark.gpu
+def test_cli_reference_ring_same_bytes_on_every_device_loop(tmp_path):
+    """The reference's compiled-in ring (50 000-event slices, a slice every 20 000 events / 33 ms, warm-start chain) on a
+    2M-event 240x180 stream: ~100 chained slices of ~100 iterations each -- the regime of the one-kernel iteration and
+    of the long-warm-start polling.  The -o file (every event's flow) and the slice log must be byte-identical whether
+    bf_run takes the one-kernel iteration, the two-kernel tile-binned loop or global atomics (BF_ACCEL_OPTIONS), with a
+    tight margin that forces repeated passes, and unpipelined."""
+    gpu_cli = os.path.join(ROOT, "better_flow_amd", "host", "bf_motion_compensator")
+    path = str(tmp_path / "ring.bin")
+    synth.write_stream_bin(path, 8, 250000, 180, 240, duration_s=0.033)
+
+    def go(tag, options, extra=()):
+        out, log = str(tmp_path / (tag + ".txt")), str(tmp_path / (tag + ".log"))
+        env = dict(os.environ)
+        env["BF_ACCEL_OPTIONS"] = options
+        r = subprocess.run([gpu_cli, "--quiet", "--res-x=180", "--res-y=240", "-o", out, "--slice-log=" + log] + list(extra) + [path],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        rows = [ln.split(",")[:5] for ln in open(log).read().splitlines()]   # slice, events, new_events, rc, iterations (the rest is timing)
+        return open(out, "rb").read(), rows
+
+    ref = go("two_kernel", "fused=0,binned=2")
+    assert len(ref[0]) > 10_000_000 and len(ref[1]) > 80
+    assert go("auto", "") == ref
+    assert go("fused", "fused=2") == ref
+    assert go("fused_tight", "fused=2,fused_margin=1") == ref
+    assert go("atomics", "fused=0,binned=0") == ref
+    assert go("fused_sync", "fused=2", ["--sync"]) == ref

@@ -1993,6 +1993,7 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     c->have_window = true;    // per-event read-back (bf_compute_uv / bf_writeout_events) is valid now
     c->degenerate = false;
     c->use_binned = false;    // the events are now sorted by sensor tile, not by image tile
+    c->fused_ok = false;
     return BF_OK;
 }
 

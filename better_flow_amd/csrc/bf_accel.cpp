@@ -61,11 +61,12 @@ struct bf_ctx {
     bool use_binned = false;         // decided per slice in bf_set_cloud
     BinGrid grid;
     // one-kernel iteration (k_fused_pass): the loop of a context that has the GPU to itself
-    int opt_fused = 1;               // 0 never, 1 where it is the faster loop (small slices on small images), 2 whenever possible;
-                                     // never for a context that is co-scheduled with others
+    int opt_fused = 1;               // 0 never, 1 where it is the faster loop (small slices on small images; sparser ones only when
+                                     // the context is co-scheduled with others), 2 whenever possible
     int opt_fused_margin = 8;        // D: scaled pixels an event may move before its tile's neighbours must be re-sorted
     int opt_fused_rows = 0;          // rows of an image tile: 0 auto, 32 or 64
     bool fused_ok = false;           // decided per slice in bf_set_cloud
+    bool fused_shared = false;       // ... and it is also the loop to take when the context shares the GPU ("co_schedule")
     BinGrid fgrid;                   // its sort grid: keys = (tile, zone)
     uint32_t* d_ftab = nullptr;      // FusedTab per tile
     int ftab_alloc = 0;
@@ -1153,6 +1154,11 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
                     if (!c->set[i].p2) HIP_TRY(c, hipMalloc(&c->set[i].p2, (size_t)c->cap_events * sizeof(float2)));
                 c->fgrid = f;
                 c->fused_ok = true;
+                // Contexts that share the GPU: with dense slices the two loop kernels are bandwidth-bound and the tail-update
+                // form keeps the CUs full, so the two-kernel loop stays; sparse slices remain launch-bound even with eight
+                // contexts in flight (346x260, 2 / 4 / 8 contexts: 50k events 12.4 / 11.4 / 10.6 us per iteration and slice
+                // against 16.7 / 14.6 / 12.8; 200k events 11.8 / 9.3 / 9.4 against 13.3 / 9.2 / 9.1).
+                c->fused_shared = c->opt_fused == 2 || 8.0 * (double)c->n <= Pimg;
             }
         }
         h.hot.binned = (c->use_binned || c->fused_ok) ? 1 : 0;
@@ -1507,7 +1513,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     c->p_clean = false;   // the loop warps the events
     // One slice context alone on the GPU: the one-kernel iteration when the slice qualifies (bf_set_cloud), else the
     // two-kernel tile-binned loop when the slice is dense enough for it, else global atomics.
-    const bool fused = c->fused_ok && !c->opt_co_schedule;
+    const bool fused = c->fused_ok && (!c->opt_co_schedule || c->fused_shared);
     const bool binned = c->use_binned || fused;
     DevState& h = c->hst;
     // Tile-binned mode sorts the events by the tile of their CURRENT target, so a warm-start
@@ -1556,7 +1562,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // work-group for itself; shortest iteration).  Several contexts sharing the GPU ("co_schedule"): in the last
     // work-group of the stencil kernel -- a serial tail on ONE CU that the other contexts' kernels fill, instead of
     // ~1.5 us on all 256 CUs.
-    const bool head_update = binned && !c->opt_co_schedule;
+    const bool head_update = fused || (binned && !c->opt_co_schedule);   // (the one-kernel loop has no other form)
     if (head_update) c->acc_dirty = true;   // (the sums of the last iteration are consumed, not cleared)
     // events a scatter thread keeps in flight: one pass should cover a bin of 1.5 x the average size
     // (and its work-group size: 1024 threads for bins of thousands of events, 512 where a bin holds a few hundred --

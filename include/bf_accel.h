@@ -147,7 +147,8 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  per work-group; the events of a tile's edge strips are also read by the neighbouring tiles' work-groups):
  *                  1 (default) where it is the faster loop -- slices of at most one event per two image pixels on images
  *                  of at most 1.2 M pixels, i.e. the reference's 50 000-event ring on a 240x180 or 346x260 sensor --, 2
- *                  whenever possible, 0 never.  Never for a "co_schedule" context.  Bit-identical to the two-kernel loop;
+ *                  whenever possible, 0 never.  A "co_schedule" context takes it only for sparser slices (at most one event
+ *                  per eight image pixels: launch-bound even with eight contexts in flight).  Bit-identical to the two-kernel loop;
  *                  bf_run_info::overflow_events then counts the passes that were repeated after a re-bin because an
  *                  event had moved further than "fused_margin" (detected exactly, never a wrong sum).
  *   "fused_margin" scaled pixels an event may move between two re-bins of that loop (default 8; at most half a tile

@@ -1644,6 +1644,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 fa.R = c->win.scale_img_x; fa.C = c->win.scale_img_y;
                 fa.j = j;
                 fa.warp = warp ? 1 : 0;
+                fa.tl = c->d_tl;
                 ProfScope ps(c, 0, c->n);
                 HIP_TRY(c, launch_fused_pass(fa, c->win.scale / 2, c->fgrid.TSR, c->stream));
                 first = false;

@@ -989,6 +989,7 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
     __shared__ unsigned long long s_rpart[NSUB][kSumFields * 4];
     __shared__ DevState s_state;
     const int b = blockIdx.x, tid = threadIdx.x;
+    tl_stamp(a.tl, a.j, 0);
     // scalar loads first (see k_bin_warp_scatter), then the vector loads of the head, nothing consumed in between
     const HotState h0 = sload(&a.st_in->hot);
     // (`lost`: three words by launch number mod 3 -- this pass reads its predecessor's, raises its own, clears its
@@ -1082,16 +1083,20 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
             ppy[k] = pr_from_p(vxy[k] >> 16, vp[k].y);
         }
     };
+    tl_stamp(a.tl, a.j, 1);
     if (pending && tid < 64) {
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long word = acc_reduce_wave(accv);
         __builtin_amdgcn_wave_barrier();
+        tl_stamp(a.tl, a.j, 2);
         model_update_wave(&s_state, word, tid, 1);
         __builtin_amdgcn_s_setprio(0);
+        tl_stamp(a.tl, a.j, 3);
     } else {
         previous_positions();
     }
     __syncthreads();
+    tl_stamp(a.tl, a.j, 4);
     const ScatterHot hs = scatter_hot(&s_state);
     if (b == 0 && tid == 0) {   // bookkeeping only the stored state needs (fields the scatter does not read)
         if (pending) model_update_rest(&s_state, a.trace, 0, 0u);
@@ -1162,7 +1167,9 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
         previous_positions();
     }
     if (lost_here) __hip_atomic_store(a.lost + a.j % 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tl_stamp(a.tl, a.j, 5);
     __syncthreads();
+    tl_stamp(a.tl, a.j, 6);
     store_state();
     // ---- the stencil of k_stencil_binned, one 16 x 64 sub-tile per 256-thread sub-group, on the LDS tile ----
     const int g = tid >> 8, lt = tid & 255;
@@ -1193,7 +1200,9 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
         }
         s_time[g][idx] = tv;
     }
+    tl_stamp(a.tl, a.j, 7);
     __syncthreads();
+    tl_stamp(a.tl, a.j, 8);
     Sums sm;
     sums_zero(sm);
     const int hR = R / 2, hC = C / 2;
@@ -1208,11 +1217,14 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
         }
     }
     constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
+    tl_stamp(a.tl, a.j, 9);
     block_reduce_publish<256, kPack>(sm, s_rpart[g], lt, r0 - hR, c0 - hC);
+    tl_stamp(a.tl, a.j, 10);
     if (tid < 64) clear_next_acc();
     if (lt >= 64 || r0 >= R) return;   // (a sub-tile below the image has nothing to add)
     const Sums blk = block_reduce_total<256, kPack>(s_rpart[g], r0 - hR, c0 - hC);
     acc_add(a.acc_out, (b * NSUB + g) % kAccGroups, blk, lt);
+    tl_stamp(a.tl, a.j, 11);
 }
 
 // K3 (binned): merge the slabs covering each pixel, box-sum, normalise, then the shared tail.

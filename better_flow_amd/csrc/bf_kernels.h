@@ -168,6 +168,7 @@ struct FusedArgs {
     int R, C;
     int j;                           // launch number (the update of iteration j runs at the head of launch j + 1)
     int warp;                        // 0: scatter the events where their stored products put them (first pass of a cold run)
+    unsigned long long* tl;          // debug timeline (`make tl` build only)
 };
 hipError_t launch_fused_pass(const FusedArgs& a, int half_scale, int rows_per_tile, hipStream_t s);
 void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, bool init_loop, hipStream_t s);

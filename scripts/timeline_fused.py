@@ -1,0 +1,36 @@
+"""In-kernel phase stamps of the one-kernel iteration (k_fused_pass; needs `make -C better_flow_amd/csrc tl`):
+work-groups 0 and nb/2, launches 8 .. 63 of a cold run, 100 MHz ticks -> us since the work-group's entry, and the period
+between consecutive launches.   BF_RUN_N / BF_RUN_H / BF_RUN_W as for run_once.py."""
+import sys, os, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["BF_TIMELINE"] = "/tmp/bf_tl.txt"
+os.environ["BF_ACCEL_LIB"] = os.path.join(ROOT, "better_flow_amd", "libbf_accel_tl.so")
+from better_flow_amd import accel, synth
+N, H, W, s = int(os.environ.get("BF_RUN_N", "50000")), int(os.environ.get("BF_RUN_H", "260")), int(os.environ.get("BF_RUN_W", "346")), 3
+sl = synth.make_slice(N, H, W, 0.030, seed=1)
+acc = accel.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+acc.set_option("fused", 2)
+for k, v in [a.split("=") for a in sys.argv[1:]]:
+    acc.set_option(k, int(v))
+opts = acc.default_opts(); opts.res_x, opts.res_y = H, W
+opts.max_iter = 60
+acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]); acc.set_cloud(s, H, W)
+acc.run(opts)
+acc.close()
+NAMES = ["entry", "loads issued", "sums reduced", "update done", "barrier 1", "events done", "barrier 2", "time image done", "barrier 3",
+         "Scharr + sums done", "partials published", "accumulators added"]
+tl = {}
+for ln in open("/tmp/bf_tl.txt"):
+    kern, L, grp, slot, t = [int(x) for x in ln.split()]
+    if kern == 0:
+        tl.setdefault((L, grp), {})[slot] = t
+for grp in (0, 1):
+    print("work-group", "0" if grp == 0 else "nb/2")
+    for slot in range(1, 12):
+        v = [(tl[(L, grp)][slot] - tl[(L, grp)][0]) / 100 for L in range(8, 64) if (L, grp) in tl and slot in tl[(L, grp)] and 11 in tl[(L, grp)]]
+        if v:
+            print("   %-22s median %6.2f us  (min %5.2f max %5.2f, %d launches)" % (NAMES[slot], statistics.median(v), min(v), max(v), len(v)))
+    per = [(tl[(L + 1, grp)][0] - tl[(L, grp)][0]) / 100 for L in range(8, 62) if (L, grp) in tl and (L + 1, grp) in tl]
+    if per:
+        print("   entry -> next launch's entry: median %.2f us" % statistics.median(per))

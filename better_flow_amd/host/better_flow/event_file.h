@@ -9,7 +9,13 @@
 
 #include <better_flow/event_reader.h>
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace bf {
 
@@ -59,11 +65,22 @@ inline bool write_flow_text(const std::string &fname, const std::vector<uint64_t
                             const std::vector<uint16_t> &col, const std::vector<double> &u, const std::vector<double> &v, int threads) {
     const size_t n = ts.size();
     if (threads < 1) threads = 1;
-    if ((size_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
-    std::vector<std::string> parts((size_t)threads);
-    auto work = [&](int k) {
-        const size_t a = n * (size_t)k / (size_t)threads, b = n * (size_t)(k + 1) / (size_t)threads;
-        std::string &out = parts[(size_t)k];
+    // Chunks of ~128k lines, formatted by `threads` workers (next chunk by an atomic counter) and written IN ORDER by one
+    // more thread as they become ready: copying ~50 bytes per line into the page cache takes as long as eight threads
+    // take to format them, so the two overlap instead of following each other.
+    const size_t chunk_lines = 131072;
+    const size_t nchunks = n ? (n + chunk_lines - 1) / chunk_lines : 0;
+    if ((size_t)threads > nchunks) threads = nchunks ? (int)nchunks : 1;
+    const int fd = ::open(fname.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return false;
+    std::vector<std::string> parts(nchunks);
+    std::vector<char> ready(nchunks, 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<size_t> next{0};
+    auto format_chunk = [&](size_t k) {
+        const size_t a = k * chunk_lines, b = std::min(n, a + chunk_lines);
+        std::string &out = parts[k];
         out.resize((b - a) * 96 + 64);
         char *p = &out[0];
         const char *lim = p + out.size();
@@ -92,15 +109,36 @@ inline bool write_flow_text(const std::string &fname, const std::vector<uint64_t
         }
         out.resize((size_t)(p - &out[0]));
     };
-    std::vector<std::thread> pool;
-    for (int k = 1; k < threads; ++k) pool.emplace_back(work, k);
-    work(0);
-    for (auto &th : pool) th.join();
-    FILE *f = std::fopen(fname.c_str(), "wb");
-    if (!f) return false;
+    auto work = [&]() {
+        for (size_t k = next.fetch_add(1); k < nchunks; k = next.fetch_add(1)) {
+            format_chunk(k);
+            { std::lock_guard<std::mutex> lk(mu); ready[k] = 1; }
+            cv.notify_one();
+        }
+    };
     bool good = true;
-    for (const std::string &part : parts) good = good && std::fwrite(part.data(), 1, part.size(), f) == part.size();
-    return std::fclose(f) == 0 && good;
+    auto writer = [&]() {
+        off_t at = 0;
+        for (size_t k = 0; k < nchunks; ++k) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[k] != 0; }); }
+            std::string &part = parts[k];
+            size_t done = 0;
+            while (good && done < part.size()) {
+                const ssize_t w = ::pwrite(fd, part.data() + done, part.size() - done, at + (off_t)done);
+                if (w <= 0) good = false;
+                else done += (size_t)w;
+            }
+            at += (off_t)part.size();
+            std::string().swap(part);   // (the text of a long recording need not be held twice)
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 2; k < threads; ++k) pool.emplace_back(work);   // (`threads` in all: the writer is one of them)
+    std::thread wr(writer);
+    work();
+    for (auto &th : pool) th.join();
+    wr.join();
+    return ::close(fd) == 0 && good;
 }
 
 }  // namespace bf

@@ -280,7 +280,12 @@ public:
             t.uv_ring = uv; t.uv_cap = (int64_t)cap; t.uv_first = t.first;
         }
         t.user = p.index;
-        if (farm->workers() > 1 && p.n > 0 && window_guard_on_host(p)) flag_noise(p);   // see slice_farm.h: uploads run ahead
+        if (farm->workers() > 1 && p.n > 0 && window_guard_on_host(p)) {   // see slice_farm.h: uploads run ahead
+            // (earlier slices overlap this one in the ring and their workers may not have read it yet: in the reference's
+            // order they do not see this slice's flags -- wait for them first.  The guard stops a slice once in a long while.)
+            farm->drain();
+            flag_noise(p);
+        }
         {
             std::lock_guard<std::mutex> g(mu);
             pending.push_back(p);

@@ -274,8 +274,10 @@ public:
         t.scale = scale; t.res_x = RES_X; t.res_y = RES_Y; t.max_iter = max_iter;
         t.warm = stm_disable ? SliceFarm::Warm::Cold : SliceFarm::Warm::FromPrevious;
         if (accumulate && p.n > 0) {
-            p.block = std::make_shared<std::vector<double>>(2 * p.n);
-            t.uv_ring = p.block->data(); t.uv_cap = (int64_t)p.n; t.uv_first = 0;
+            // (uninitialised: bf_compute_uv_ring writes every pair.  A value-initialised vector cost the producer 16 MB of
+            // page faults and zeroes per 1M-event slice -- 4 ms, more than the slice's whole solve)
+            p.block = std::shared_ptr<double>(new double[2 * (size_t)p.n], std::default_delete<double[]>());
+            t.uv_ring = p.block.get(); t.uv_cap = (int64_t)p.n; t.uv_first = 0;
         } else if (want_flow && p.n > 0) {
             t.uv_ring = uv; t.uv_cap = (int64_t)cap; t.uv_first = t.first;
         }
@@ -336,12 +338,12 @@ protected:
         ull start_time = 0, trigger_time = 0, oldest_time = 0;
         sll time_diff = 0;
         bool full = false, zero_excluded = false;
-        std::shared_ptr<std::vector<double>> block;
+        std::shared_ptr<double> block;   // (u, v) pairs of the slice's events
     };
     struct Kept {                 // accumulate: one solved slice
         uint64_t first, n;
         ull start_time;
-        std::shared_ptr<std::vector<double>> block;
+        std::shared_ptr<double> block;   // (u, v) pairs of the slice's events
     };
 
     // configuration
@@ -510,8 +512,8 @@ protected:
             if (r.window_guard && farm->workers() == 1) flag_noise(p);
             if (p.block && uv) {   // accumulate: the slice's own copy of the flow -> the ring's
                 const size_t slot = (size_t)(p.first % cap), n0 = p.n < cap - slot ? (size_t)p.n : cap - slot;
-                std::memcpy(uv + 2 * slot, p.block->data(), n0 * 16);
-                std::memcpy(uv, p.block->data() + 2 * n0, ((size_t)p.n - n0) * 16);
+                std::memcpy(uv + 2 * slot, p.block.get(), n0 * 16);
+                std::memcpy(uv, p.block.get() + 2 * n0, ((size_t)p.n - n0) * 16);
             }
             if (p.zero_excluded && uv) { const size_t s = (size_t)((p.first - 1) % cap); uv[2 * s] = uv[2 * s + 1] = 0.0; }
         }
@@ -590,7 +592,7 @@ inline FlowTable StreamEngine::get_accumulated() {
                 for (uint32_t c = next[g]; c != NONE && hist_ts[c] == t; c = next[c]) mark_later(i, c);             // same instant, arrived later
             }
             out.timestamp.push_back(t); out.row.push_back(hist_row[g]); out.col.push_back(hist_col[g]);
-            out.u.push_back((*s.block)[2 * (size_t)p]); out.v.push_back((*s.block)[2 * (size_t)p + 1]);
+            out.u.push_back(s.block.get()[2 * (size_t)p]); out.v.push_back(s.block.get()[2 * (size_t)p + 1]);
         }
     }
     return out;

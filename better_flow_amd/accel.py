@@ -105,7 +105,7 @@ class LocalState(C.Structure):
 # every symbol include/bf_accel.h declares
 EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
-    "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_upload_events", "bf_upload_events_device",
+    "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_get_stat", "bf_upload_events", "bf_upload_events_device",
     "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
     "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_many", "bf_run_tiles", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
@@ -158,6 +158,7 @@ def load():
         L.bf_destroy.restype = None
         L.bf_last_error.argtypes = [C.c_void_p]
         L.bf_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.bf_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.bf_upload_events.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int64]
         L.bf_upload_events_device.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int64]
         L.bf_set_cloud.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Window)]
@@ -246,6 +247,11 @@ class Accel:
 
     def set_option(self, key, value):
         self._chk(self.L.bf_set_option(self.h, key.encode(), int(value)))
+
+    def get_stat(self, key):
+        v = C.c_int64(0)
+        self._chk(self.L.bf_get_stat(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def upload_events(self, fr_x, fr_y, t_ns, noise=None):
         fr_x = np.ascontiguousarray(fr_x, dtype=np.int32)

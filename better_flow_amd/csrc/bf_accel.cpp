@@ -81,6 +81,16 @@ struct bf_ctx {
     int fmt = 0;                     // what this slice's scatter hands to the stencil: 0 dense slabs, 1 merged lists, 2 event lists (bf_set_cloud)
     int opt_bin_ev = 0;              // events per scatter thread in flight (0: from the events per bin)
     int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
+    // interior + margin format of a dense slice (fmt 3, bf_binned.hip: flush_split): 0 never, 1 when it is the faster one, 2 always
+    int opt_bin_split = 1;
+    unsigned long long* d_mplane[2] = {nullptr, nullptr};   // margin planes (cap_px words each), double buffered like d_plane
+    uint32_t* d_mlist = nullptr;     // per bin: the pixels of the margin plane it added to in its last executed launch
+    uint32_t* d_mcount = nullptr;    // per bin: entries of that list
+    size_t mlist_alloc = 0;
+    int mcount_alloc = 0;
+    int m_nbins = 0, m_cap = 0;      // geometry the lists were written with
+    int m_dirty_plane = -1;          // the margin plane the lists describe (-1: both planes are clean, the lists empty)
+    bool m_unknown = false;          // a run did not complete: clear everything before the next use
     int bins_alloc = 0;
     size_t slabs_alloc = 0;
     bool bin_setup_done = false;
@@ -305,6 +315,7 @@ StencilArgs st_args(bf_ctx* c, int buf, int check_done) {
     a.slabs = c->d_slabs;
     a.cidx = c->d_cidx; a.chdr = c->d_chdr;
     a.compact = c->fmt;
+    a.m_cur = c->d_mplane[buf];
     a.threads = c->stencil_threads;
     a.g = c->grid;
     a.ovf_cur = a.ovf_prev = c->d_ovf;   // (the tile-binned loop sets the three counters per launch)
@@ -379,6 +390,53 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
     return BF_OK;
 }
 
+
+// Margin planes and per-bin lists of the interior + margin format.  Iteration j of a run adds to margin plane b0 ^ (j & 1) and
+// clears, bin by bin, what the lists say the previous executed launch left in the other one (flush_split); the host keeps
+// track of which plane the lists describe.  The lists name pixels by their linear index, so what an earlier bin grid left
+// behind is cleared with the earlier grid's list layout before the buffers change hands.
+int margin_reset(bf_ctx* c) {
+    if (c->m_unknown) {
+        for (int i = 0; i < 2; ++i)
+            if (c->d_mplane[i]) HIP_TRY(c, hipMemsetAsync(c->d_mplane[i], 0, c->cap_px * sizeof(unsigned long long), c->stream));
+        if (c->d_mcount) HIP_TRY(c, hipMemsetAsync(c->d_mcount, 0, (size_t)c->mcount_alloc * sizeof(uint32_t), c->stream));
+        c->m_unknown = false;
+    } else if (c->m_dirty_plane >= 0) {
+        launch_margin_clean(c->d_mplane[c->m_dirty_plane], c->d_mlist, c->d_mcount, c->m_nbins, c->m_cap, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->m_dirty_plane = -1;
+    return BF_OK;
+}
+int ensure_margin_buffers(bf_ctx* c, const BinGrid& g) {
+    const int mcap = g.LR * g.L - g.TSR * g.TS;
+    if (c->m_unknown || g.nbins != c->m_nbins || mcap != c->m_cap) {
+        int rc = margin_reset(c);
+        if (rc != BF_OK) return rc;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!c->d_mplane[i]) {
+            HIP_TRY(c, hipMalloc(&c->d_mplane[i], c->cap_px * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_mplane[i], 0, c->cap_px * sizeof(unsigned long long), c->stream));
+        }
+    if (g.nbins > c->mcount_alloc) {
+        if (c->d_mcount) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_mcount)); }
+        c->d_mcount = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_mcount, (size_t)g.nbins * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->d_mcount, 0, (size_t)g.nbins * sizeof(uint32_t), c->stream));
+        c->mcount_alloc = g.nbins;
+    }
+    const size_t need = (size_t)g.nbins * (size_t)mcap;
+    if (need > c->mlist_alloc) {
+        if (c->d_mlist) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_mlist)); }
+        c->d_mlist = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_mlist, need * sizeof(uint32_t)));
+        c->mlist_alloc = need;
+    }
+    c->m_nbins = g.nbins;
+    c->m_cap = mcap;
+    return BF_OK;
+}
 
 // Device-conditional counting sort of the live events by the image tile of their current
 // target (runs only when hot.need_rebin is set); no host synchronisation.
@@ -684,7 +742,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_noise[i]) (void)hipFree(c->d_in_noise[i]);
     void* bufs[] = {c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_mplane[0], c->d_mplane[1], c->d_mlist, c->d_mcount, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_ticket, c->d_state,
@@ -699,6 +757,19 @@ void bf_destroy(bf_ctx* c) {
 }
 
 const char* bf_last_error(const bf_ctx* c) { return c ? c->err : "null ctx"; }
+
+int bf_get_stat(bf_ctx* c, const char* key, int64_t* value) {
+    if (!c || !key || !value) return BF_ERR_ARG;
+    if (!strcmp(key, "scatter_format")) {
+        *value = c->use_binned ? c->fmt : -1;
+        return BF_OK;
+    }
+    if (!strcmp(key, "one_kernel")) {
+        *value = (c->fused_ok && (!c->opt_co_schedule || c->fused_shared)) ? 1 : 0;
+        return BF_OK;
+    }
+    return fail(c, BF_ERR_ARG, "unknown statistic '%s'", key);
+}
 
 int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return BF_ERR_ARG;
@@ -766,6 +837,11 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "bin_compact")) {
         if (value < 0 || value > 3) return fail(c, BF_ERR_ARG, "bin_compact must be 0, 1, 2 or 3");
         c->opt_bin_compact = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "bin_split")) {
+        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "bin_split must be 0, 1 or 2");
+        c->opt_bin_split = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "bin_predict")) {
@@ -1093,6 +1169,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         g.LR = g.TSR + 2 * g.D;
         g.mul_r = (uint32_t)(0x100000000ull / (unsigned)g.TSR) + 1u;
         g.mul_l = (uint32_t)(0x100000000ull / (unsigned)g.L) + 1u;
+        g.mul_h = (uint32_t)(0x100000000ull / (unsigned)(g.L / 2 > 0 ? g.L / 2 : 1)) + 1u;
         g.nbr = (w.scale_img_x + g.TSR - 1) / g.TSR;
         g.nbins = g.nbr * g.nbc;
         // Density rule: every iteration writes and re-reads one slab pixel (8 B x (L / TS)^2) per image pixel, a global
@@ -1185,6 +1262,19 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
             if (mode == 2) c->fmt = 2;
             else if (mode == 3) c->fmt = merged_ok ? 1 : 2;
             else if (mode == 1 && 4.0 * (double)c->n < P) c->fmt = ((double)c->n <= 2.0 * sensor_px || !merged_ok) ? 2 : 1;
+            // Dense slices: the bin's own pixels + a margin plane instead of whole-tile slabs (flush_split).  It moves 0.6 x the
+            // slab bytes and a quarter of the stencil kernel's loads; "auto" takes it where that is what the iteration
+            // waits for -- a context that has the GPU to itself (update at the scatter head) on an image of >= 1.5 M
+            // pixels: 640x480 scale 3, 1M events: K1 14.7 -> 11.3 us, iteration 37.2 -> 32.9 us.  At 346x260 the loop is a
+            // latency chain and nothing moves (18.8 us either way); with the update in the stencil tail ("co_schedule") the
+            // lean scatter kernel LOSES 1.7 us per launch (8.0 -> 9.7 us at 346x260, value 196 -> 178 Mevents/s).
+            const bool split_pays = !c->opt_co_schedule && P >= 1.5e6;
+            if (c->fmt == 0 && c->use_binned && (c->opt_bin_split == 2 || (c->opt_bin_split == 1 && split_pays)) && g.D >= 2 &&
+                (g.D & (g.D - 1)) == 0 && g.TS >= 4) {   // (D a power of two)
+                int rc = ensure_margin_buffers(c, g);
+                if (rc != BF_OK) return rc;
+                c->fmt = 3;
+            }
             h.hot.fmt = c->fmt;
         }
         h.t_span = (c->n > 0) ? (long long)s.tmax - (long long)s.tmin : 0;
@@ -1558,6 +1648,17 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // (one launch: the state, and the loop's counters / accumulators)
     launch_run_init(c->d_state, h, c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, binned || c->acc_dirty, c->stream);
     c->acc_dirty = false;
+    // Interior + margin format: iteration j adds to margin plane b0 ^ (j & 1) and clears, bin by bin, what the lists say the
+    // previous executed launch left in the other one.  That works across runs as long as the plane the lists describe is not
+    // the one the first iteration adds to; otherwise (or after a run that did not complete) it is cleared up front.
+    const bool split = c->use_binned && !fused && c->fmt == 3;
+    if (split) {
+        if (c->m_unknown || c->m_dirty_plane == b0) {
+            int rcm = margin_reset(c);
+            if (rcm != BF_OK) return rcm;
+        }
+        c->m_unknown = true;   // (until this run has completed)
+    }
     // Where the model / loop update runs.  One slice context alone: at the head of the next warp+scatter launch (every
     // work-group for itself; shortest iteration).  Several contexts sharing the GPU ("co_schedule"): in the last
     // work-group of the stencil kernel -- a serial tail on ONE CU that the other contexts' kernels fill, instead of
@@ -1669,6 +1770,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.g = c->grid;
                 ba.cur = buf; ba.j = j;
                 ba.tl = c->d_tl ? c->d_tl + 64 * 2 * 16 : nullptr;
+                ba.m_cur = c->d_mplane[buf]; ba.m_prev = c->d_mplane[buf ^ 1];
+                ba.mlist = c->d_mlist; ba.mcount = c->d_mcount; ba.mcap = c->m_cap;
                 ProfScope ps(c, 0, c->n);
                 HIP_TRY(c, launch_bin_warp_scatter(ba, warp, bin_threads, ev_per_thread, c->stream));
             } else {
@@ -1859,6 +1962,17 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     const DevState d = fin;
     h = d;   // model, dividers, warp parameters, plane-buffer dirtiness
     h.hot.pp = 0; h.hot.redo = 0; h.hot.pend = 0;   // (the final warp left the products in the set's first array)
+    if (split) {   // the last executed iteration added to margin plane b0 ^ ((it - 1) & 1), and the lists name those pixels
+        if (d.hot.it > 0) c->m_dirty_plane = b0 ^ ((d.hot.it - 1) & 1);
+        c->m_unknown = d.rc < 0;   // (a run stopped at the iteration cap may have one executed launch more than `it` counts)
+        if (getenv("BF_DEBUG_MARGIN")) {   // entries of the bins' margin lists after the last executed launch
+            std::vector<uint32_t> mc((size_t)c->m_nbins);
+            HIP_TRY(c, hipMemcpy(mc.data(), c->d_mcount, mc.size() * 4, hipMemcpyDeviceToHost));
+            unsigned long long tot = 0; uint32_t mx = 0;
+            for (uint32_t v : mc) { tot += v; mx = v > mx ? v : mx; }
+            fprintf(stderr, "margin entries after %d iterations: %llu in %d bins (max %u of %d)\n", d.hot.it, tot, c->m_nbins, mx, c->m_cap);
+        }
+    }
     if (binned && !fused) {   // the last iteration scattered its overflow events into buffer b0 ^ ((it - 1) & 1); the other one is clean
         h.hot.ovf_cnt[b0 ^ (d.hot.it & 1)] = 0;
         h.hot.ovf_cnt[b0 ^ (d.hot.it & 1) ^ 1] = d.last_ovf ? 1u : 0u;

@@ -594,6 +594,93 @@ __device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, uns
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slab + 2 * i), "v"(v) : "memory");
     }
 }
+// ---- interior + margin format (FMT 3) ---------------------------------------------------------------------------------
+// The dense slab of a bin is its whole LDS tile, margin included: (TS + 2 D)(TSR + 2 D) / (TS TSR) = 1.56 .. 1.67 x the
+// image's pixels are written every iteration, and the stencil kernel merges up to 2 x 2 slabs per pixel (four loads and
+// the row / column -> bin arithmetic for each).  But the margin of a tile is EMPTY right after a re-bin and fills only as
+// the model drifts: 0.01 .. 2 % of the events (measured along cold runs).  So the bin writes its own TSR x TS pixels --
+// which no other bin writes -- with plain stores into a tiled image (`slabs`, TS * TSR words per bin), and ADDS what its
+// events left in the margin to a margin plane (image-linear, packed like the slab words: the packing bound of k_bin_scan
+// covers the events of four bins, and a pixel hears from at most its own bin and three neighbours), with device atomics,
+// one per touched margin pixel.  The stencil kernel reads one tiled-image word per pixel, plus the margin-plane word for
+// pixels within D of a boundary of their bin.  The margin plane is double buffered like the overflow planes (buffer `cur`
+// of the iteration); a bin lists the pixels it added to and clears exactly those in the other buffer at its next
+// executed launch (the list is per bin, and the buffer it clears is not the one anybody adds to in that launch).
+// (The first list entry of every thread is REQUESTED behind the first pass's events and consumed after the scatter loop: a
+// dependent load + store at either end would put a memory round trip on every work-group's chain; ahead of the events,
+// the scatter loop's header -- which waits, vmcnt(0), for the registers of its previous pass -- waited for it too.)
+__device__ __forceinline__ uint32_t margin_preload(const BinScatterArgs& a, int b, uint32_t n_prev, int tid) {
+    return (uint32_t)tid < n_prev ? a.mlist[(size_t)b * (size_t)a.mcap + tid] : 0xffffffffu;
+}
+__device__ __forceinline__ void margin_clear(const BinScatterArgs& a, int b, uint32_t n_prev, uint32_t e0, int tid, int threads) {
+    if (e0 != 0xffffffffu) a.m_prev[e0] = 0ull;
+    const uint32_t* lst = a.mlist + (size_t)b * (size_t)a.mcap;
+    for (uint32_t i = tid + threads; i < n_prev; i += threads) a.m_prev[lst[i]] = 0ull;
+}
+template <int THREADS>
+__device__ __forceinline__ void flush_split(const unsigned long long* s_tile, const BinScatterArgs& a, int b, int X0, int Y0, int C,
+                                            uint32_t* s_mcnt /* [0] entries, [1] waves done */, int tid) {
+    const BinGrid& g = a.g;
+    const bf_u32x4* src4 = reinterpret_cast<const bf_u32x4*>(s_tile);
+    const int half = g.L >> 1, hD = g.D >> 1, lgh = g.lg - 1;   // 16-byte pairs per tile row / per margin / per interior row (log2)
+    // the bin's own pixels: rows D .. D + TSR of the tile, pairs D/2 .. D/2 + TS/2 of each -- a plain copy
+    unsigned long long* own = a.slabs + (size_t)b * (size_t)(g.TS * g.TSR);
+    const int nown = g.TSR << lgh;
+    for (int i = tid; i < nown; i += THREADS) {
+        const int r = i >> lgh, q = i - (r << lgh);
+        const bf_u32x4 v = src4[(r + g.D) * half + hD + q];
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(own + 2 * i), "v"(v) : "memory");
+    }
+    // the margin: D full rows above and below (half pairs each), D/2 pairs left and right of the TSR rows in between
+    // (D is a power of two here: bf_set_cloud)
+    uint32_t* lst = a.mlist + (size_t)b * (size_t)a.mcap;
+    const int nfull = 2 * g.D * half, nmar = nfull + g.TSR * g.D;   // (2 sides x D/2 pairs per row)
+    const int lgD = 31 - __clz(g.D);
+    for (int j = tid; j < nmar; j += THREADS) {
+        int lx, lp;   // tile row, pair inside the row
+        if (j < nfull) {
+            const int r = (int)__umulhi((uint32_t)j, g.mul_h);   // j / half
+            lp = j - r * half;
+            lx = r < g.D ? r : r + g.TSR;
+        } else {
+            const int k = j - nfull, r = k >> lgD, q = k & (g.D - 1);
+            lx = g.D + r;
+            lp = q < hD ? q : q + (g.TS >> 1);
+        }
+        const bf_u32x4 v = src4[lx * half + lp];
+        const unsigned long long w0 = ((unsigned long long)v.y << 32) | v.x, w1 = ((unsigned long long)v.w << 32) | v.z;
+        if (w0 | w1) {
+            const uint32_t px = (uint32_t)((X0 + lx) * C + Y0 + 2 * lp);
+            if (w0) {
+                __hip_atomic_fetch_add(&a.m_cur[px], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lst[atomicAdd(&s_mcnt[0], 1u)] = px;
+            }
+            if (w1) {
+                __hip_atomic_fetch_add(&a.m_cur[px + 1], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lst[atomicAdd(&s_mcnt[0], 1u)] = px + 1;
+            }
+        }
+    }
+    // The last wave to get here publishes the length of the list: no work-group barrier (it would hold every wave until its
+    // write-through stores and atomics have drained).  LDS operations of a wave complete in order, so the count this wave
+    // reads includes every entry of the waves that arrived before it.
+    uint32_t arrived = 0;
+    if ((tid & 63) == 0) arrived = atomicAdd(&s_mcnt[1], 1u);
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == THREADS / 64 - 1 && (tid & 63) == 0) a.mcount[b] = s_mcnt[0];
+}
+__global__ __launch_bounds__(256) void k_margin_clean(unsigned long long* mplane, const uint32_t* mlist, uint32_t* mcount, int mcap) {
+    const int b = blockIdx.x;
+    const uint32_t n = mcount[b];
+    const uint32_t* lst = mlist + (size_t)b * (size_t)mcap;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) mplane[lst[i]] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) mcount[b] = 0u;
+}
+void launch_margin_clean(unsigned long long* mplane, const uint32_t* mlist, uint32_t* mcount, int nbins, int mcap, hipStream_t s) {
+    if (nbins > 0) hipLaunchKernelGGL(k_margin_clean, dim3(nbins), dim3(256), 0, s, mplane, mlist, mcount, mcap);
+}
+
 // K1 (binned): [pending update] + warp + LDS scatter + slab flush, one work-group per bin.
 //
 // The model / loop update of the tile-binned loop runs HERE.  The stencil kernel of iteration j - 1 only adds its
@@ -610,11 +697,14 @@ __device__ __forceinline__ void flush_tile(const unsigned long long* s_tile, uns
 template <bool WARP, int THREADS, int U, int FMT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
     constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
+    constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
     __shared__ DevState s_state;
-    __shared__ uint32_t s_row[FMT ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
-    if (FMT)
+    __shared__ uint32_t s_row[(FMT == 1 || FMT == 2) ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
+    __shared__ uint32_t s_mcnt[2];
+    if (FMT == 1 || FMT == 2)
         for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
+    if (SPLIT && threadIdx.x < 2) s_mcnt[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -629,6 +719,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     const uint32_t ovf_prev = sload(a.ovf_prev);
     const int done0 = sload(&a.st_in->hot.done), it0 = sload(&a.st_in->hot.it);
     const int live_set = sload(&a.st_in->hot.cs) ^ sload(&a.st_in->hot.flip);
+    const uint32_t m_prev_n = SPLIT ? sload(a.mcount + b) : 0u;
     unsigned long long accv[kAccPerLane];
     if (a.acc && tid < 64) acc_load_wave<false, false>(a.acc, tid, accv);
     unsigned long long state_word = 0;
@@ -672,6 +763,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
             vp[k] = p[i];
         }
     };
+    const uint32_t m_e0 = SPLIT ? margin_preload(a, b, m_prev_n, tid) : 0xffffffffu;   // (ahead of the events: see the lean form)
     load_pass();
     asm volatile("" ::: "memory");   // (keep the requests above ahead of everything below)
     if (!COMPACT) {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
@@ -781,12 +873,14 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
         previous_positions();
     }
     if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+    if (SPLIT) margin_clear(a, b, m_prev_n, m_e0, tid, THREADS);
     tl_stamp(a.tl, a.j, 2);
     __syncthreads();
     tl_stamp(a.tl, a.j, 3);
     store_state();
     if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+    else if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     tl_stamp(a.tl, a.j, 4);
 }
@@ -798,15 +892,19 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
 template <bool WARP, int THREADS, int U, int FMT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
     constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
+    constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
-    __shared__ uint32_t s_row[FMT ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
-    if (FMT)
+    __shared__ uint32_t s_row[(FMT == 1 || FMT == 2) ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
+    __shared__ uint32_t s_mcnt[2];
+    if (FMT == 1 || FMT == 2)
         for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
+    if (SPLIT && threadIdx.x < 2) s_mcnt[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
     const HotState h0 = sload(&a.st_in->hot);   // one burst of scalar loads
+    const uint32_t m_prev_n = SPLIT ? sload(a.mcount + b) : 0u;
     unsigned long long state_word = 0;
     if (b == 0 && tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
     const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
@@ -895,8 +993,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
         return;
     }
     uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
-    for (uint32_t base = beg; base < end; base += THREADS * U) {
-        load_pass(base);
+    auto scatter_pass = [&](uint32_t base) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
@@ -906,11 +1003,35 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
             else scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
                                      pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
         }
+    };
+    if constexpr (SPLIT) {
+        // The first list entry of every thread is the OLDEST vector load of the kernel and is consumed after the scatter
+        // loop, whose waits for the events' (younger) loads have covered it by then.  Requested behind the events it
+        // would be waited for with vmcnt(0) -- i.e. together with the write-through stores of the products, ~1.7 us --,
+        // and ahead of a loop whose header waits for the previous pass's registers it is waited for there: hence the
+        // first pass outside the loop.
+        const uint32_t m_e0 = margin_preload(a, b, m_prev_n, tid);
+        uint32_t base = beg;
+        load_pass(base);
+        for (;;) {
+            scatter_pass(base);
+            base += THREADS * U;
+            if (base >= end) break;
+            load_pass(base);
+        }
+        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        margin_clear(a, b, m_prev_n, m_e0, tid, THREADS);
+    } else {
+        for (uint32_t base = beg; base < end; base += THREADS * U) {
+            load_pass(base);
+            scatter_pass(base);
+        }
+        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     }
-    if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
     __syncthreads();
     if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+    else if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     hand_state_on();
 }
@@ -1231,8 +1352,9 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
 // HS = scale / 2 is a template parameter so that the tile geometry is constexpr (index
 // arithmetic by multiply-shift), TS is a power of two (shifts), D <= TS / 2 (a pixel is
 // covered by at most 2 x 2 bins) and every slab load of a thread is issued up front.
-template <int HS, bool COMPACT, int NT>
+template <int HS, int MODE, int NT>   // MODE: what the scatter kernel wrote -- 0 dense slabs, 1 lists, 2 interior + margin plane
 __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
+    constexpr bool COMPACT = MODE == 1;
     tl_stamp(a.tl, a.tl_launch, 0);
     // one burst of scalar loads; the state is not CONSUMED (not even for the early exit of a finished loop) before the
     // first vector loads below are out: their latencies overlap instead of adding up
@@ -1331,6 +1453,37 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
                     }
             }
         }
+    } else if constexpr (MODE == 2) {
+    // Interior + margin format (flush_split): one word of the tiled image per pixel -- bin (br, bc) keeps its TSR x TS pixels
+    // at [(br nbc + bc) TSR TS + (gr - br TSR) TS + (gc - bc TS)] -- plus the margin-plane word where another bin's margin
+    // can reach the pixel: within D of a boundary of its own bin.  Rows as in the dense form: the tile's rows cross at most
+    // one bin boundary, so the row part of the offset is one of two UNIFORM values.
+    static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
+    const int TSA = g.TS * g.TSR;
+    const int b0r = row_bin(max(r0 - H, 0), g), next_r = (b0r + 1) * g.TSR;
+    const int rp0 = b0r * (g.nbc * TSA - g.TSR * g.TS), rp1 = rp0 + g.nbc * TSA - g.TSR * g.TS;
+    const int cmask = g.TS - 1;
+    unsigned long long w[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int idx = tid + c * NT;
+        const int pr = idx / PC, pc = idx - pr * PC;
+        const int gr = r0 - H + pr, gc = c0 - H + pc;
+        const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
+        const bool up = gr >= next_r;
+        const int rr = gr - (up ? next_r : next_r - g.TSR);   // row inside the pixel's bin
+        const int cc = gc & cmask;
+        const int off = (up ? rp1 : rp0) + __mul24(gr, g.TS) + __mul24(gc >> g.lg, TSA) + cc;
+        const bool edge = rr < g.D || rr >= g.TSR - g.D || cc < g.D || cc >= g.TS - g.D;
+        w[c][0] = in ? a.slabs[(uint32_t)off] : 0ull;
+        w[c][1] = (in && edge) ? a.m_cur[(uint32_t)(__mul24(gr, C) + gc)] : 0ull;
+    }
+    if (a.check_done && hs.done) return;   // (uniform; before the first barrier -- the loads above are already out)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int idx = tid + c * NT;
+        if (idx < PR * PC) s_acc[idx] = w[c][0] + w[c][1];
+    }
     } else {
     static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
     // Row -> bin without a per-pixel division: the tile's rows (with halo) span TR + 2 H <= 32 <= TSR rows, so both
@@ -1425,9 +1578,9 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero);
 }
 
-template <int HS, bool COMPACT, int NT>
+template <int HS, int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_stencil_binned(StencilArgs a) {
-    stencil_binned_body<HS, COMPACT, NT>(a);
+    stencil_binned_body<HS, MODE, NT>(a);
 }
 
 // Plain launch, or (profiling armed) an extended launch whose events carry the kernel's own timestamps.
@@ -1445,10 +1598,12 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
 #define BF_K3(HS_)                                                                                                  \
     if (a.threads >= 512) {                                                                                         \
-        if (a.compact) launch_timed(k_stencil_binned<HS_, true, 512>, grid, dim3(512), 0, s, a);                    \
-        else launch_timed(k_stencil_binned<HS_, false, 512>, grid, dim3(512), 0, s, a);                             \
-    } else if (a.compact) launch_timed(k_stencil_binned<HS_, true, kThreads>, grid, dim3(kThreads), 0, s, a);       \
-    else launch_timed(k_stencil_binned<HS_, false, kThreads>, grid, dim3(kThreads), 0, s, a)
+        if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, 512>, grid, dim3(512), 0, s, a);                  \
+        else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, 512>, grid, dim3(512), 0, s, a);                  \
+        else launch_timed(k_stencil_binned<HS_, 0, 512>, grid, dim3(512), 0, s, a);                                 \
+    } else if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);     \
+    else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, a);            \
+    else launch_timed(k_stencil_binned<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, a)
     switch (a.scale / 2) {
         case 0: BF_K3(0); break;
         case 1: BF_K3(1); break;
@@ -1512,7 +1667,8 @@ static hipError_t launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s)
 }
 template <int THREADS, int U>
 static hipError_t launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    if (a.compact >= 2) return launch_bws2<THREADS, U, 2>(a, warp, s);
+    if (a.compact == 3) return launch_bws2<THREADS, U, 3>(a, warp, s);
+    if (a.compact == 2) return launch_bws2<THREADS, U, 2>(a, warp, s);
     if (a.compact == 1) return launch_bws2<THREADS, U, 1>(a, warp, s);
     return launch_bws2<THREADS, U, 0>(a, warp, s);
 }

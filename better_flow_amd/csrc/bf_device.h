@@ -71,7 +71,7 @@ struct BinGrid {
     uint32_t mul_l;    // floor(2^32 / L) + 1: index / L of a tile-local pixel index (< 2^16)
     int32_t fz;        // one-kernel iteration (k_fused_pass): width E of the edge strips of a tile, 0 = the two-kernel loop.
                        // The counting sort then keys events by (bin, zone): nbins counts KEYS, kFusedZones per image tile.
-    int32_t pad_;
+    uint32_t mul_h;    // floor(2^32 / (L / 2)) + 1: row of a 16-byte PAIR of tile pixels (interior + margin format; L is even)
 };
 
 // One-kernel iteration (bf_binned.hip, k_fused_pass).  A tile's events are sorted into nine zones by where their target

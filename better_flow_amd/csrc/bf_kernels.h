@@ -68,6 +68,7 @@ struct StencilArgs {
     const uint16_t* cidx;              // compact lists (hot.fmt == 1): see BinScatterArgs
     const uint32_t* chdr;
     int compact;
+    const unsigned long long* m_cur;   // interior + margin format (compact == 3): the margin plane of buffer `cur`
     int threads;                       // work-group size of the stencil kernels (256 or 512; the loop's choice per slice)
     BinGrid g;
     int cur;
@@ -126,6 +127,9 @@ void launch_fill_states(DevState* states, const DevState& tmpl, int nt, hipStrea
 // bf_binned.hip
 int bin_kernel_setup();
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
+// interior + margin format: clear what the bins' lists name in `mplane`, empty the lists (a run that cannot rely on the
+// loop's own clean-up: the dirty margin plane is the one its first iteration adds to, or the bin grid changes)
+void launch_margin_clean(unsigned long long* mplane, const uint32_t* mlist, uint32_t* mcount, int nbins, int mcap, hipStream_t s);
 void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, const BinGrid& g,
                   uint16_t* binid, uint32_t* hist_cnt, uint32_t* bin_start,
                   uint32_t* cursor, uint32_t* armed, const WarpParams* prewarp, int pack_limit, hipStream_t s,
@@ -149,6 +153,14 @@ struct BinScatterArgs {
     BinGrid g;
     int cur, j;                      // plane buffer of this iteration; number of stencil launches completed before it
     unsigned long long* tl;
+    // interior + margin format (compact == 3): the bin's own TSR x TS pixels go to `slabs` (plain stores, nothing shared), what
+    // its events left in the margin of its LDS tile is ADDED to the margin plane of buffer `cur` and listed, and the pixels
+    // this bin listed in its previous executed launch are cleared in the other buffer's margin plane
+    unsigned long long* m_cur;
+    unsigned long long* m_prev;
+    uint32_t* mlist;                 // per bin: mcap linear pixel indices
+    uint32_t* mcount;                // per bin: entries of its list
+    int mcap;
 };
 hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
 // The one-kernel iteration (k_fused_pass, bf_binned.hip): warp + scatter + stencil + moments of one image tile per work-group.

@@ -195,8 +195,21 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  LDS tile, one entry per touched pixel); 1 (default): lists when the slice has fewer than one event per
  *                  four pixels -- event lists at up to two events per sensor pixel of the window, merged lists above --,
  *                  dense tiles otherwise.  With lists, traffic and work follow the events instead of the image area.
- *                  Bit-identical results in every form. */
+ *                  Bit-identical results in every form.
+ *   "bin_split"    dense tiles only: 0 the bin writes its whole LDS tile, margin included, and the stencil kernel merges
+ *                  up to 2 x 2 such slabs per pixel; 2 the bin writes its own pixels into a tiled image and ADDS the few
+ *                  words its events left in the tile's margin to a margin plane (device atomics; the bin clears them again
+ *                  at its next launch): 0.6 x the bytes, a quarter of the stencil kernel's loads; 1 (default): the second
+ *                  form for a context that has the GPU to itself on an image of >= 1.5 M pixels (640x480 scale 3, 1M
+ *                  events: 37.2 -> 32.9 us per iteration), the first otherwise.  Bit-identical results. */
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
+
+/* Diagnostics (no reference counterpart).  Keys:
+ *   "scatter_format"  what the last bf_set_cloud chose for the tile-binned loop: 0 dense slabs, 1 merged lists, 2 event
+ *                     lists, 3 own pixels + margin plane ("bin_split"); -1 when the slice does not take that loop.
+ *   "one_kernel"      1 when bf_run would take the one-kernel iteration for the slice staged now, else 0.
+ * BF_ERR_ARG for an unknown key. */
+int bf_get_stat(bf_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- slice set-up -------------------------------------------------------------- */
 

@@ -274,6 +274,7 @@ int bf_compute_uv_ring(bf_ctx *c, double *uv_ring, int64_t cap, int64_t first) {
 }
 
 int bf_set_option(bf_ctx *, const char *, int64_t) { return BF_OK; }   // device tuning knobs: nothing to tune here
+int bf_get_stat(bf_ctx *, const char *, int64_t *value) { if (value) *value = -1; return BF_OK; }   // (no device loops here)
 
 // linear int32 arrays with slice-local times (the slice farm's second input form); held in upload order
 int bf_upload_events_async(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, const int32_t *t_ns, int64_t n) {

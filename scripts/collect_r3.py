@@ -33,6 +33,29 @@ for geo in ("346x260", "640x480", "1280x720"):
                 rec["kernel"] = k
     if len(rec) >= 3:
         traffic[geo + "x3"] = rec
+# 640x480 with the update at the scatter head: interior + margin format (bin_split auto) against dense slabs
+for sp, label in ((1, "640x480 head, own pixels + margin plane"), (0, "640x480 head, dense slabs")):
+    ks = glob.glob(os.path.join(src, "head640_split%d" % sp, "**/*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(out, "r3_head640_split%d_kernel_stats.csv" % sp))
+    rec = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        fs = counter_files("%s_head640_split%d" % (cname, sp))
+        if not fs:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if r["Counter_Name"] == cname:
+                acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            live = [x for x in v if x > 64] or [0.0]
+            lines.append("%-40s %-11s %-40s dispatches %5d  live %5d  median %12.1f KB  mean %12.1f KB" %
+                         (label, cname, k, len(v), len(live), statistics.median(live), sum(live) / len(live)))
+            if k.startswith("k_bin_warp_scatter") and "<true" in k:
+                rec["fetch_kb" if cname == "FETCH_SIZE" else "write_kb"] = statistics.median(live)
+                rec["kernel"] = k
+    if len(rec) >= 3:
+        traffic["640x480x3_head_split%d" % sp] = rec
 if traffic:
     traffic["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/profile_r3.sh), median over the live launches "
                          "of the warp+scatter kernel of one cold 1M-event slice per geometry; FETCH_SIZE is doubled by the reader (gfx950)")

@@ -21,6 +21,14 @@ for G in "260 346 -1" "480 640 300" "720 1280 300"; do
     BF_RUN_H=$1 BF_RUN_W=$2 BF_RUN_MAXITER=$3 timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/${C}_$2x$1 -o p --output-format csv -- python $R/scripts/run_once.py 1 co_schedule=1 > $O/${C}_$2x$1.log 2>&1
   done
 done
+# 640x480, ONE context with the update at the scatter head: the regime "auto" takes the interior + margin format in (bin_split),
+# against the dense slabs in the same regime -- kernel stats and the two traffic counters
+for SP in 1 0; do
+  BF_RUN_H=480 BF_RUN_W=640 BF_RUN_MAXITER=300 timeout 300 rocprofv3 --kernel-trace --stats -d $O/head640_split$SP -o s --output-format csv -- python $R/scripts/run_once.py 2 bin_split=$SP > $O/head640_split$SP.log 2>&1
+  for C in FETCH_SIZE WRITE_SIZE; do
+    BF_RUN_H=480 BF_RUN_W=640 BF_RUN_MAXITER=300 timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/${C}_head640_split$SP -o p --output-format csv -- python $R/scripts/run_once.py 1 bin_split=$SP > $O/${C}_head640_split$SP.log 2>&1
+  done
+done
 BF_RUN_H=720 BF_RUN_W=1280 BF_RUN_MAXITER=300 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES -d $O/sq_720 -o sq --output-format csv -- python $R/scripts/run_once.py 1 co_schedule=1 > $O/sq_720.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES -d $O/sq_346 -o sq --output-format csv -- python $R/scripts/run_once.py 1 co_schedule=1 > $O/sq_346.log 2>&1
 grep '^{"metric"' $O/bench.log | cut -c1-200

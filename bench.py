@@ -434,12 +434,45 @@ def main():
             t_ = json.load(open(tj)).get("%dx%dx%d" % (W, H, s))
             if t_:
                 traffic = (2.0 * t_["fetch_kb"] + t_["write_kb"]) * 1024.0
+        # The same kernel at BASELINE's other two geometries (configs 3 and 5), one context alone as it runs there by default
+        # (a stream's chain / a farm lane with the GPU to itself: update at the scatter head), first 120 iterations of a cold
+        # 1M-event slice each -- a second or so, not part of the timed region.
+        other_geo = []
+        if args.events == 1000000 and (H, W) == (260, 346) and not args.opt:
+            for (H2, W2, cfg) in ((480, 640, 3), (720, 1280, 5)):
+                try:
+                    sl2 = synth.make_slice(1000000, H2, W2, 0.030, seed=1)
+                    a2 = accel.Accel(max_events=len(sl2["t"]), max_rows=s * H2 + s, max_cols=s * W2 + s)
+                    o2 = a2.default_opts()
+                    o2.res_x, o2.res_y, o2.max_iter = H2, W2, 120
+                    for rep in range(2):
+                        a2.upload_events(sl2["fr_x"], sl2["fr_y"], sl2["t"])
+                        w2 = a2.set_cloud(s, H2, W2)
+                        if rep == 1:
+                            a2.profile_enable(1); a2.profile_reset()
+                        _, _, i2 = a2.run(o2)
+                    p2 = a2.profile_get()
+                    fmt2 = a2.get_stat("scatter_format")
+                    a2.close()
+                    n2, it2 = len(sl2["t"]), max(1, i2.iterations)
+                    k1 = p2.warp_scatter_ms * 1e-3 / it2
+                    px2 = float(w2.scale_img_x) * float(w2.scale_img_y)
+                    other_geo.append({
+                        "geometry": "%dx%d, scale %d (BASELINE config %d), %d events" % (W2, H2, s, cfg, n2),
+                        "scatter_format": {0: "dense slabs", 1: "merged lists", 2: "event lists", 3: "own pixels + margin plane"}.get(fmt2, str(fmt2)),
+                        "warp_scatter_us": k1 * 1e6, "stencil_us": 1e3 * p2.stencil_ms / it2,
+                        "frac": K1_BYTES_PER_EVENT_ITER * n2 / k1 / 1e9 / HBM_PEAK_GBPS,
+                        "iteration_frac": (K1_BYTES_PER_EVENT_ITER * n2 + 24.0 * px2) / ((p2.warp_scatter_ms + p2.stencil_ms) * 1e-3 / it2) / 1e9 / HBM_PEAK_GBPS,
+                        "iterations": int(i2.iterations)})
+                except Exception as e:   # (a measurement beside the contract's: never the reason a bench line is missing)
+                    other_geo.append({"geometry": "%dx%d" % (W2, H2), "error": str(e)[:200]})
         roofline = {
             "bound": "hbm", "kernel": "k_bin_warp_scatter%s (warp + tile-binned LDS scatter)" % ("_lean" if B > 1 else ""),
             "regime": "one slice context alone on the GPU, 1024-thread work-groups (the shape of a kernel that has the GPU to "
                       "itself); kernel variant of the headline regime (%s)" %
                       ("update in the stencil kernel's tail, as with %d contexts per GPU" % B if B > 1 else "update at its head"),
             "co_scheduled_shape": shared_shape,
+            "other_geometries": other_geo,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "avg_launch_us": k1_s * 1e6, "launches": int(live), "launches_incl_early_exit": int(p.warp_scatter_launches),

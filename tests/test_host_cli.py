@@ -313,12 +313,16 @@ def test_cli_stream_engine_equals_reference_ring_gpu(events_txt, tmp_path):
 
 
 def test_fixed9_formatter_matches_printf(tmp_path):
-    """bf::format_fixed9 (the -o writer's number formatter) == snprintf("%.9f") on three million values."""
+    """bf::format_fixed9 (the -o writer's number formatter) == snprintf("%.9f") on three million values, and
+    bf::write_flow_text == the lines snprintf makes, with one chunk per thread, several chunks per thread and more threads
+    than chunks."""
     exe = str(tmp_path / "test_format")
     subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I" + os.path.join(ROOT, "better_flow_amd", "host"),
                            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_format.cpp"), "-o", exe])
     out = subprocess.check_output([exe]).decode()
-    assert out.strip().endswith(" 0 mismatches"), out
+    lines = out.strip().splitlines()
+    assert any(l.endswith(" 0 mismatches") for l in lines), out
+    assert sum(l.startswith("write_flow_text, ") and l.endswith(" bytes equal") for l in lines) == 3, out
 
 
 # ---- OptimizerLocal through the host class (better_flow/optimizer_sampler.h) ----

@@ -1789,7 +1789,11 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 } else if (binned) {   // "co_schedule": the last work-group of the stencil kernel updates
                     a.acc = c->d_acc;
                     a.ticket = c->d_ticket;
+                    // it reads the state the (lean) scatter kernel read and writes the new one where the next scatter
+                    // launch looks for it -- and to the pinned snapshot the host polls; nobody copies the state in between
+                    a.st = state_of(j);
                     a.st_rw = state_of(j + 1);
+                    a.snap = quick_warm ? nullptr : &c->h_state[0];
                 } else {        // the last work-group reduces and updates
                     a.acc = c->d_acc;
                     a.ticket = c->d_ticket;
@@ -1828,8 +1832,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         }
         HIP_TRY(c, hipGetLastError());
         if (snap_polled) {
-            // Tile-binned cold run: no copy command, no event.  Work-group 0 of every warp+scatter launch writes the state
-            // it has just computed to pinned host memory as well; its first 8-byte word -- (done, it), one lane's store
+            // Tile-binned cold run: no copy command, no event.  Whoever computes the new state -- work-group 0 of the warp+scatter
+            // launch (update at its head) or the stencil kernel's last work-group (update in its tail) -- writes it to pinned
+            // host memory as well; its first 8-byte word -- (done, it), one lane's store
             // -- tells the host how far the device is and whether the loop is over (`done` carries this run's tag: a
             // straggler launch of an earlier run on this context cannot be mistaken for it).  The host enqueues the next batch
             // when less than one batch is left in the queue and sleeps in between (the queue hides its wake-up latency).
@@ -1875,7 +1880,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             if (host_timing) { const double t = ht_now(); ht_wait += t - ht_mark; ht_mark = t; }
             inf.polls++;
             if (done_seen) break;
-            if ((fused ? gpu_it > last_rebin_at : gpu_it >= last_rebin_at) && gpu_it > 0 && *rebin_p) want_rebin = true;   // (a snapshot older than the last re-bin does not count)
+            // (a snapshot older than the last re-bin does not count.  With the update at the scatter head the snapshot of
+            // iteration count L is written by launch L itself, behind a re-bin enqueued at L; with the update in the stencil
+            // tail -- and in the one-kernel loop -- it is written by launch L - 1, ahead of that re-bin)
+            if (((fused || !head_update) ? gpu_it > last_rebin_at : gpu_it >= last_rebin_at) && gpu_it > 0 && *rebin_p) want_rebin = true;
             if (launched_iters - stall_allowance > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;

@@ -905,23 +905,21 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
     const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
     const HotState h0 = sload(&a.st_in->hot);   // one burst of scalar loads
     const uint32_t m_prev_n = SPLIT ? sload(a.mcount + b) : 0u;
-    unsigned long long state_word = 0;
-    if (b == 0 && tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
     const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
     if (!COMPACT) {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
         ulonglong2* z = reinterpret_cast<ulonglong2*>(s_tile);
         for (int i = tid; i < LL / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
     }
-    // (work-group 0 hands the state on at the END: consuming the load here would hold its events back by a memory
-    // round trip and make it the last work-group of every launch -- 0.3 us on the kernel)
-    auto hand_state_on = [&]() {
+    // The state is NOT carried to the other buffer here while the loop runs: the stencil kernel's last work-group writes its
+    // update there (and to the host snapshot) itself.  (Work-group 0 used to copy it -- a vector load that the scatter loop's
+    // header, which waits vmcnt(0) for the registers of its previous pass, waited for before the first event load, on the
+    // work-group that also finishes last.)  Only once the loop is over does every launch keep both buffers identical.
+    if (h0.done) {
         if (b == 0 && tid < kStateWords) {
+            const unsigned long long state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
             reinterpret_cast<unsigned long long*>(a.st_out)[tid] = state_word;
             if (a.snap) reinterpret_cast<unsigned long long*>(a.snap)[tid] = state_word;
         }
-    };
-    if (h0.done) {
-        hand_state_on();
         return;
     }
     ScatterHot hs;
@@ -989,7 +987,6 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
             }
         }
         if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
-        hand_state_on();
         return;
     }
     uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
@@ -1033,7 +1030,6 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
                                     a.chdr + (size_t)b * (size_t)(LR + 1), tid);
     else if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
-    hand_state_on();
 }
 
 // The pending update outside a warp+scatter launch (a warm start's gated final warp needs `done` of the batch's last

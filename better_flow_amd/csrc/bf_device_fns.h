@@ -696,8 +696,12 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         // once (a dependent global round trip per field cost 3.2 us; copying after the ticket ~1 us).
         __shared__ DevState s_state;
         static_assert(sizeof(DevState) % 8 == 0 && sizeof(DevState) / 8 <= 64, "one u64 per lane of one wave");
+        // (read from `st`, the buffer every work-group took its hot fields from; the update goes to `st_rw` -- the same
+        // buffer in the global-atomic loop, the OTHER one in the tile-binned loop, whose next scatter launch then finds the
+        // new state without anybody copying it: the lean scatter kernel's work-group 0 used to carry it over, a vector
+        // load that its scatter loop's header waited for before the first event load)
         if (a.ticket && tid < (int)(sizeof(DevState) / 8))
-            reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st_rw)[tid];
+            reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st)[tid];
         __shared__ unsigned long long s_rpart[kSumFields * (NT / 64)];
         constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
         block_reduce_publish<NT, kPack>(sm, s_rpart, tid, r0 - hR, c0 - hC);
@@ -757,8 +761,11 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             if (a.ovf_next) *a.ovf_next = 0u;   // (tile-binned loop: the next iteration's overflow counter)
         }
         __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order)
-        if (tid < (int)(sizeof(DevState) / 8))
-            reinterpret_cast<unsigned long long*>(a.st_rw)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
+        if (tid < (int)(sizeof(DevState) / 8)) {
+            const unsigned long long v = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
+            reinterpret_cast<unsigned long long*>(a.st_rw)[tid] = v;
+            if (a.snap) reinterpret_cast<unsigned long long*>(a.snap)[tid] = v;
+        }
     }
 }
 

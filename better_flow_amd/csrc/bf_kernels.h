@@ -58,7 +58,8 @@ struct StencilArgs {
     uint32_t* zero_cplane;
     // fused reduction + model / loop update by the last work-group (NULL ticket: accumulate only)
     unsigned int* ticket;
-    DevState* st_rw;
+    DevState* st_rw;                   // where the updated state goes (tile-binned loop, update here: NOT the buffer `st` is read from)
+    DevState* snap;                    // optional: pinned host copy of the updated state, polled by the host
     bf_trace_rec* trace;
     int update_mode;                   // 1: full iteration_step / run() update, 0: model only
     unsigned long long* tl;            // debug timeline (BF_TIMELINE builds), usually NULL

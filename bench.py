@@ -368,9 +368,9 @@ def main():
         regimes["host_to_host"] = {
             "note": "pinned host arrays -> H2D on the copy stream (overlapped with the previous slice) -> solve -> model on "
                     "the host; per-event flow not read back",
-            "cold": host_to_host(B, False, -1, 4), "warm_stm": host_to_host(B, True, -1, reps),
+            "cold": host_to_host(B, False, -1, 10), "warm_stm": host_to_host(B, True, -1, reps),
             "capped_max_iter_10": host_to_host(B, False, 10, reps),
-            "one_context": {"cold": host_to_host(1, False, -1, 3), "warm_stm": host_to_host(1, True, -1, reps),
+            "one_context": {"cold": host_to_host(1, False, -1, 6), "warm_stm": host_to_host(1, True, -1, reps),
                             "capped_max_iter_10": host_to_host(1, False, 10, reps)},
         }
         for o_ in all_opts:

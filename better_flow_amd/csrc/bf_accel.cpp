@@ -1682,7 +1682,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // (dense tiles: a pass should cover the AVERAGE bin, fuller bins take a second pass -- sizing it for 1.5 x the
         // average left half of every thread's slots empty at 640x480: 512 x 8 19.9 us, 512 x 4 15.3 us)
         const double per_bin = (c->fmt == 2 ? 1.0 : 1.1) * ev_per_bin / (double)bin_threads;
-        ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2 ? 2 : (per_bin <= 4 ? 4 : 8));
+        // (... and between two and four, two up to 2.83 -- the geometric middle: bins of ~2100 events on 1024 threads ran
+        // 15.3 us with four events per thread, half of every thread's slots empty, against 12.1 us with two and a second pass
+        // for the fuller bins; measured at 1M events on 440 / 520 / 560 x 480 sensors)
+        ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2.83 ? 2 : (per_bin <= 4 ? 4 : 8));
     }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of

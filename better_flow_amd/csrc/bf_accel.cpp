@@ -91,6 +91,9 @@ struct bf_ctx {
     int m_nbins = 0, m_cap = 0;      // geometry the lists were written with
     int m_dirty_plane = -1;          // the margin plane the lists describe (-1: both planes are clean, the lists empty)
     bool m_unknown = false;          // a run did not complete: clear everything before the next use
+    uint32_t* d_ovf_bits[2] = {nullptr, nullptr};   // per plane buffer: one bit per image pixel an overflow event touched (tile-binned loop)
+    size_t ovf_bits_words = 0;
+    int ovf_pitch = 0;               // words per image row: ceil(C / 32) + 3 (one spare word left, two right: the stencil tile's window)
     int bins_alloc = 0;
     size_t slabs_alloc = 0;
     bool bin_setup_done = false;
@@ -340,10 +343,30 @@ int clear_planes(bf_ctx* c) {
         HIP_TRY(c, hipMemsetAsync(c->d_plane[i], 0, c->cap_px * sizeof(unsigned long long), c->stream));
         if (c->d_cplane[i])
             HIP_TRY(c, hipMemsetAsync(c->d_cplane[i], 0, c->cap_px * sizeof(uint32_t), c->stream));
+        if (c->d_ovf_bits[i])
+            HIP_TRY(c, hipMemsetAsync(c->d_ovf_bits[i], 0, c->ovf_bits_words * sizeof(uint32_t), c->stream));
     }
     c->planes_unknown = false;
     c->cur = 0;
     c->hst.hot.ovf_cnt[0] = c->hst.hot.ovf_cnt[1] = 0;
+    return BF_OK;
+}
+
+// Dirty bitmaps of the overflow planes for an R x C image (a change of R or C clears planes and bitmaps: bf_set_cloud).
+int ensure_ovf_bits(bf_ctx* c, int R, int C) {
+    const int pitch = (C + 31) / 32 + 3;
+    const size_t need = (size_t)R * (size_t)pitch;
+    if (need > c->ovf_bits_words) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->d_ovf_bits[i]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_ovf_bits[i])); }
+            c->d_ovf_bits[i] = nullptr;
+            HIP_TRY(c, hipMalloc(&c->d_ovf_bits[i], need * sizeof(uint32_t)));
+        }
+        c->ovf_bits_words = need;
+        c->planes_unknown = true;   // (fresh bitmaps: cleared with the planes below)
+    }
+    if (pitch != c->ovf_pitch) c->planes_unknown = true;   // (bits set under another row pitch mean other pixels)
+    c->ovf_pitch = pitch;
     return BF_OK;
 }
 
@@ -742,7 +765,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_noise[i]) (void)hipFree(c->d_in_noise[i]);
     void* bufs[] = {c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
-                    c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_mplane[0], c->d_mplane[1], c->d_mlist, c->d_mcount, c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
+                    c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_mplane[0], c->d_mplane[1], c->d_mlist, c->d_mcount, c->d_ovf_bits[0], c->d_ovf_bits[1], c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
                     c->d_uv, c->d_plane[0], c->d_plane[1], c->d_cplane[0], c->d_cplane[1], c->d_time,
                     c->d_gx, c->d_gy, c->d_img, c->d_count, c->d_ticket, c->d_state,
@@ -1186,6 +1209,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         if (c->use_binned) {
             int rc = ensure_cplanes(c);
             if (rc == BF_OK) rc = ensure_bin_buffers(c, g);
+            if (rc == BF_OK) rc = ensure_ovf_bits(c, w.scale_img_x, w.scale_img_y);
             if (rc != BF_OK) return rc;
             c->grid = g;
         }
@@ -1765,6 +1789,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 ba.cidx = c->d_cidx; ba.chdr = c->d_chdr;
                 ba.compact = c->fmt;
                 ba.ovf_plane = c->d_plane[buf]; ba.ovf_cplane = c->d_cplane[buf];
+                ba.ovf_bits = c->d_ovf_bits[buf]; ba.ovf_pitch = c->ovf_pitch;
                 ba.st_in = state_of(j); ba.st_out = state_of(j + 1);
                 ba.acc = head_update ? acc_of(j - 1) : nullptr;
                 ba.ovf_cur = ovf_of(j); ba.ovf_prev = ovf_of(j - 1);
@@ -1784,6 +1809,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             {   // stencil + moments; its last work-group reduces and runs the model / loop update
                 StencilArgs a = st_args(c, buf, 1);
                 if (binned) {
+                    a.ovf_bits = c->d_ovf_bits[buf]; a.zero_bits = c->d_ovf_bits[buf ^ 1]; a.ovf_pitch = c->ovf_pitch;
+                    a.zero_full = j == 0 ? 1 : 0;   // (what an earlier operator left in the other buffer is not in the bitmap)
                     a.st = state_of(j + 1);
                     a.ovf_cur = ovf_of(j); a.ovf_prev = ovf_of(j - 1); a.ovf_next = ovf_of(j + 1);
                 }

@@ -447,6 +447,8 @@ __device__ __forceinline__ void overflow_add(const ScatterHot& hs, const BinScat
     const size_t kk = (size_t)X * (size_t)hs.C + (size_t)Y;
     atomicAdd(&a.ovf_plane[kk], dt);
     atomicAdd(&a.ovf_cplane[kk], 1u);
+    // (the stencil kernel reads the planes only around pixels flagged here)
+    atomicOr(&a.ovf_bits[(size_t)X * (size_t)a.ovf_pitch + (size_t)(Y >> 5) + 1], 1u << (Y & 31));
 }
 
 // Dense slabs: accumulate in the bin's LDS tile.
@@ -1528,6 +1530,17 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         if (idx < PR * PC) s_acc[idx] = (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
     }
     }   // dense slabs
+    // Overflow events of this iteration (uniform, rare): the scatter kernel flagged their pixels in a bitmap; the rows of it
+    // that the tile's boxes can reach (four words each: the tile's 64 columns and 32 on either side) are staged here, and a
+    // time pixel reads the overflow planes only if a flagged pixel lies in its box (every pixel reading its whole box from
+    // memory cost an iteration with overflow events about twice the time of a clean one at 640x480).
+    __shared__ uint32_t s_bits[(TH + 2 * HS) * 4];
+    if (ovf) {
+        for (int i = tid; i < (TH + 2 * HS) * 4; i += NT) {
+            const int gr = r0 - 1 - HS + (i >> 2);
+            s_bits[i] = (gr >= 0 && gr < R) ? a.ovf_bits[(size_t)gr * (size_t)a.ovf_pitch + (size_t)((c0 >> 5) + (i & 3))] : 0u;
+        }
+    }
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
@@ -1548,7 +1561,19 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
             }
             unsigned long long acc = pk & bm;
             uint32_t cacc = (uint32_t)(pk >> bt);
-            if (ovf) {   // rare: the overflow planes (u64 time sums, u32 counts) straight from memory, box by box
+            bool box_dirty = false;
+            if (ovf) {
+                const int ps = tc + 31 - HS;   // first column of the box, counted from the first staged column (c0 - 32)
+                uint32_t any = 0;
+#pragma unroll
+                for (int da = 0; da <= 2 * HS; ++da) {
+                    const uint32_t* rw = &s_bits[(tr + da) * 4 + (ps >> 5)];
+                    const unsigned long long w2 = ((unsigned long long)rw[1] << 32) | rw[0];
+                    any |= (uint32_t)(w2 >> (ps & 31)) & ((1u << (2 * HS + 1)) - 1u);
+                }
+                box_dirty = any != 0;
+            }
+            if (box_dirty) {   // rare: the overflow planes (u64 time sums, u32 counts) straight from memory, box by box
 #pragma unroll
                 for (int da = -HS; da <= HS; ++da)
 #pragma unroll

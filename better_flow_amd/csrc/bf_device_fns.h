@@ -684,8 +684,22 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
                 a.gy_out[(size_t)gr * C + gc] = gy;
             }
             if (do_zero) {
-                a.zero_plane[(size_t)gr * C + gc] = 0ull;
-                if (a.zero_cplane) a.zero_cplane[(size_t)gr * C + gc] = 0u;
+                if (a.zero_bits && !a.zero_full) {
+                    // tile-binned loop: what the previous iteration's overflow events left is flagged pixel by pixel -- clear
+                    // those (12 bytes each) instead of the whole buffer (32 MB at 640x480), then the flags.  (A wave covers
+                    // one tile row, so a bitmap word is read and cleared by lanes of one wave, in program order.)
+                    uint32_t* wp = a.zero_bits + ((size_t)gr * (size_t)a.ovf_pitch + (size_t)(gc >> 5) + 1);
+                    const uint32_t wv = *wp;
+                    if ((wv >> (gc & 31)) & 1u) {
+                        a.zero_plane[(size_t)gr * C + gc] = 0ull;
+                        if (a.zero_cplane) a.zero_cplane[(size_t)gr * C + gc] = 0u;
+                    }
+                    if (wv != 0u && (gc & 31) == 0) *wp = 0u;
+                } else {
+                    a.zero_plane[(size_t)gr * C + gc] = 0ull;
+                    if (a.zero_cplane) a.zero_cplane[(size_t)gr * C + gc] = 0u;
+                    if (a.zero_bits && (gc & 31) == 0) a.zero_bits[(size_t)gr * (size_t)a.ovf_pitch + (size_t)(gc >> 5) + 1] = 0u;
+                }
             }
         }
     }

@@ -56,6 +56,12 @@ struct StencilArgs {
     uint32_t* ovf_next;
     unsigned long long* zero_plane;    // optional: the OTHER plane buffer, zeroed here
     uint32_t* zero_cplane;
+    // tile-binned loop: one bit per image pixel that an overflow event of this iteration touched (set by the scatter kernel;
+    // row pitch ovf_pitch words, column Y in word (Y >> 5) + 1), and the other buffer's bitmap, cleared with its planes
+    const uint32_t* ovf_bits;
+    uint32_t* zero_bits;
+    int ovf_pitch;
+    int zero_full;                     // clear every pixel of the other buffer, not only the flagged ones (its dirt may predate the bitmap: first launch of a run)
     // fused reduction + model / loop update by the last work-group (NULL ticket: accumulate only)
     unsigned int* ticket;
     DevState* st_rw;                   // where the updated state goes (tile-binned loop, update here: NOT the buffer `st` is read from)
@@ -144,6 +150,8 @@ struct BinScatterArgs {
     int compact;                     // this slice's scatter writes compact lists (bf_set_cloud's choice)
     unsigned long long* ovf_plane;   // overflow planes of buffer `cur`
     uint32_t* ovf_cplane;
+    uint32_t* ovf_bits;              // ... and its dirty bitmap (StencilArgs)
+    int ovf_pitch;
     const DevState* st_in;           // state as of the previous launch ...
     DevState* st_out;                // ... and with the pending update applied (written by work-group 0)
     DevState* snap;                  // optional: pinned host copy of st_out, polled by the host

@@ -455,6 +455,48 @@ def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
         assert np.array_equal(a, b)
 
 
+def test_overflow_path_flags_and_sparse_clearing(accel_mod):
+    """The overflow path of the tile-binned loop on a large image: every pixel an overflow event touches is flagged in a
+    bitmap, the stencil kernel reads the overflow planes only around flagged pixels and clears only those afterwards.  With
+    a 2-pixel margin and no prediction thousands of events overflow in every iteration, for dozens of iterations in a row
+    (both plane buffers in turn), with the update at the scatter head and in the stencil tail, dense slabs / own pixels +
+    margin plane / event lists; the bits must be those of the global-atomic loop.  The context is used for a stand-alone
+    time image first (an operator that leaves an overflow plane buffer dirty WITHOUT flags: the first launch clears it whole),
+    and for a second run afterwards (what the first run left flagged)."""
+    H, W, s = 480, 640, 3
+    sl = synth.make_slice(300000, H, W, 0.03, seed=41)
+    other = synth.make_slice(200000, H, W, 0.03, seed=42)
+
+    def chain(opts):
+        a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+        for k, v in opts.items():
+            a.set_option(k, v)
+        out = []
+        a.upload_events(other["fr_x"], other["fr_y"], other["t"])
+        a.set_cloud(s, H, W)
+        out.append(tuple(np.ascontiguousarray(x).tobytes() for x in a.get_time_img()))   # dirties a plane buffer, no flags
+        infos = []
+        for data, max_iter in ((sl, 45), (other, 30), (sl, 31)):
+            a.upload_events(data["fr_x"], data["fr_y"], data["t"])
+            a.set_cloud(s, H, W)
+            o = a.default_opts()
+            o.res_x, o.res_y, o.want_uv, o.trace_cap, o.max_iter = H, W, 1, 64, max_iter
+            rc, m, info = a.run(o)
+            u, v = a.compute_uv()
+            out.append((rc, info.iterations, m.as_dict(), [t.model.as_dict() for t in a.get_trace(64)], u.tobytes(), v.tobytes(),
+                        tuple(np.ascontiguousarray(x).tobytes() for x in a.get_time_img())))
+            infos.append(info)
+        a.close()
+        return out, infos
+
+    ref, _ = chain({"binned": 0, "fused": 0})
+    for opts in ({"bin_compact": 0, "bin_split": 0}, {"bin_compact": 0, "bin_split": 2}, {"bin_compact": 2},
+                 {"bin_compact": 0, "bin_split": 0, "co_schedule": 1}, {"bin_compact": 0, "bin_split": 2, "co_schedule": 1}):
+        got, infos = chain(dict({"binned": 2, "fused": 0, "bin_margin": 2, "bin_predict": 0}, **opts))
+        assert all(i.overflow_events > 20 * i.iterations for i in infos), (opts, [i.overflow_events for i in infos])
+        assert got == ref, opts
+
+
 def test_binned_warm_start_bit_identical(accel_mod):
     H, W = 180, 240
     a = synth.make_slice(40000, H, W, 0.05, seed=31)

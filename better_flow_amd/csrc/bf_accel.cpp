@@ -689,8 +689,8 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMalloc(&c->d_count, c->cap_px * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_acc, (3 * kAccGroups + 1) * sizeof(MomentAcc)));
         HIP_TRY(c, hipMemsetAsync(c->d_acc, 0, (3 * kAccGroups + 1) * sizeof(MomentAcc), c->stream));
-        HIP_TRY(c, hipMalloc(&c->d_ovf, 64));
-        HIP_TRY(c, hipMemsetAsync(c->d_ovf, 0, 64, c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_ovf, 3 * kOvfSlotWords * sizeof(uint32_t)));   // (three slots of 17 lines: bf_device_fns.h)
+        HIP_TRY(c, hipMemsetAsync(c->d_ovf, 0, 3 * kOvfSlotWords * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMalloc(&c->d_state, 2 * sizeof(DevState)));
         HIP_TRY(c, hipMalloc(&c->d_ticket, 16 * 64 * sizeof(unsigned int)));   // 1 + 32 counters, 64 B apart
         HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, 16 * 64 * sizeof(unsigned int), c->stream));
@@ -1668,7 +1668,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // for "iteration -1": is plane buffer b0 ^ 1 still dirty from an earlier operator?).
     auto state_of = [&](int j) { return c->d_state + (j & 1); };
     auto acc_of = [&](int j) { return c->d_acc + (size_t)(fused ? ((j % 3) + 3) % 3 : (j & 1)) * kAccGroups; };
-    auto ovf_of = [&](int j) { return c->d_ovf + ((j % 3) + 3) % 3; };
+    auto ovf_of = [&](int j) { return c->d_ovf + (((j % 3) + 3) % 3) * kOvfSlotWords; };
     // (one launch: the state, and the loop's counters / accumulators)
     launch_run_init(c->d_state, h, c->d_ovf, h.hot.ovf_cnt[b0 ^ 1] ? 1u : 0u, c->d_acc, binned || c->acc_dirty, c->stream);
     c->acc_dirty = false;

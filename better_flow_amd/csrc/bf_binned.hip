@@ -718,12 +718,12 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     // carried the state pointer through a vector register and turned them into vector loads -- which complete in order
     // behind the accumulators.)
     const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
-    const uint32_t ovf_prev = sload(a.ovf_prev);
     const int done0 = sload(&a.st_in->hot.done), it0 = sload(&a.st_in->hot.it);
     const int live_set = sload(&a.st_in->hot.cs) ^ sload(&a.st_in->hot.flip);
     const uint32_t m_prev_n = SPLIT ? sload(a.mcount + b) : 0u;
     unsigned long long accv[kAccPerLane];
     if (a.acc && tid < 64) acc_load_wave<false, false>(a.acc, tid, accv);
+    const uint32_t ovf_prev_part = (b == 0 && a.acc && tid < 64) ? ovf_part(a.ovf_prev, tid) : 0u;   // (work-group 0 books it below)
     unsigned long long state_word = 0;
     if (tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
     const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
@@ -799,8 +799,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     __syncthreads();
     tl_stamp(a.tl, a.j, 1);
     const ScatterHot hs = scatter_hot(&s_state);
-    if (b == 0 && pending && tid == 0)   // bookkeeping only the stored state needs (fields the scatter does not read)
-        model_update_rest(&s_state, a.trace, a.cur ^ 1, ovf_prev);
+    if (b == 0 && pending && tid < 64) {   // bookkeeping only the stored state needs (fields the scatter does not read)
+        const uint32_t ovf_prev = ovf_total_wave(ovf_prev_part);
+        if (tid == 0) model_update_rest(&s_state, a.trace, a.cur ^ 1, ovf_prev);
+    }
     if (hs.done) {
         __syncthreads();
         store_state();
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
                 }
             }
         }
-        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
         tl_stamp(a.tl, a.j, 4);
         return;
     }
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
         load_pass();
         previous_positions();
     }
-    if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+    if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
     if (SPLIT) margin_clear(a, b, m_prev_n, m_e0, tid, THREADS);
     tl_stamp(a.tl, a.j, 2);
     __syncthreads();
@@ -988,7 +990,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
                 }
             }
         }
-        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
         return;
     }
     uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
@@ -1018,14 +1020,14 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
             if (base >= end) break;
             load_pass(base);
         }
-        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
         margin_clear(a, b, m_prev_n, m_e0, tid, THREADS);
     } else {
         for (uint32_t base = beg; base < end; base += THREADS * U) {
             load_pass(base);
             scatter_pass(base);
         }
-        if (n_ovf) atomicAdd(a.ovf_cur, n_ovf);
+        if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
     }
     __syncthreads();
     if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* a
         if (tid < kStateWords)
             reinterpret_cast<unsigned long long*>(st)[tid] = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
     } else if (!done && apply) {
-        const uint32_t ovf = *ovf_prev;
+        const uint32_t ovf = ovf_total_wave(ovf_part(ovf_prev, tid));
         unsigned long long accv[kAccPerLane];
         acc_load_wave<false, false>(acc, tid, accv);
         const unsigned long long word = acc_reduce_wave(accv);
@@ -1751,7 +1753,8 @@ __global__ __launch_bounds__(kThreads) void k_run_init(DevState* st, DevState v,
     const int tid = threadIdx.x;
     if (tid < kStateWords) reinterpret_cast<unsigned long long*>(st)[tid] = reinterpret_cast<const unsigned long long*>(&v)[tid];
     if (!init_loop) return;
-    if (tid < 3) ovf[tid] = (tid == 2) ? prev_dirty : 0u;
+    // (three overflow-counter slots of 17 lines each; the flag of slot 2 -- "iteration -1" -- says whether the other plane buffer is dirty)
+    if (tid < 3 * (1 + kOvfLines)) ovf[(tid / (1 + kOvfLines)) * kOvfSlotWords + (tid % (1 + kOvfLines)) * kOvfStride] = (tid == 2 * (1 + kOvfLines)) ? prev_dirty : 0u;
     // (three accumulator buffers and, behind them, the `lost` word of the one-kernel iteration: bf_ctx::d_acc)
     for (int i = tid; i < 3 * kAccGroups * 16 + 16; i += kThreads) (&acc[0].f[0])[i] = 0ull;
 }

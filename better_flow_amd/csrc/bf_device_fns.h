@@ -486,6 +486,23 @@ __device__ __forceinline__ void model_update_wave(DevState* st, unsigned long lo
     }
 }
 
+// Overflow counter of one iteration (tile-binned loop).  Thousands of waves may lose an event in the same launch, and
+// atomics on one cache line serialise at ~11 ns each (scripts/micro/ctr_atomics.hip: 5520 waves adding once: 65 us on one
+// word or on 16 words of one line, 7 us -- the empty kernel -- on 16 words of 16 lines).  So a slot is 17 lines: word 0 of
+// line 0 is a FLAG (plain store of 1: what the kernels that only ask "any?" read, with a scalar load), lines 1 .. 16 hold
+// the count, a wave adding to the line of its bin; the one wave that runs the update adds the sixteen up.
+// (kOvfLines, kOvfStride, kOvfSlotWords: bf_device.h)
+__device__ __forceinline__ uint32_t* ovf_counter(uint32_t* slot, int b) { return slot + kOvfStride * (1 + (b & (kOvfLines - 1))); }
+__device__ __forceinline__ uint32_t ovf_part(const uint32_t* slot, int lane) {   // lanes 0 .. 15 of one wave
+    return lane < kOvfLines ? slot[kOvfStride * (1 + lane)] : 0u;
+}
+__device__ __forceinline__ uint32_t ovf_total_wave(uint32_t part) {   // every lane of the wave calls; every lane gets the total
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_total_dpp(part), 63);
+}
+__device__ __forceinline__ void ovf_slot_clear(uint32_t* slot, int lane) {   // lanes 0 .. 16 of one wave
+    if (lane <= kOvfLines) slot[kOvfStride * lane] = 0u;
+}
+
 // `cur` is the plane buffer of the iteration the sums belonged to; `ovf_now` the number of events that took the
 // overflow path in it (tile-binned loop: the count lives outside the state, see k_bin_warp_scatter).
 __device__ __forceinline__ void model_update_rest(DevState* st, bf_trace_rec* trace, int cur, uint32_t ovf_now = 0) {
@@ -737,7 +754,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             if (me == 0) {
                 if (a.acc_zero)
                     for (int i = tid; i < kAccGroups * 16; i += 64) (&a.acc_zero[0].f[0])[i] = 0ull;
-                if (a.ovf_next && tid == 0) *a.ovf_next = 0u;
+                if (a.ovf_next) ovf_slot_clear(a.ovf_next, tid);
             }
             return;
         }
@@ -765,15 +782,19 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         last = __builtin_amdgcn_readfirstlane(last);   // (lane 0's verdict, for the whole wave)
         tl_stamp(a.tl, a.tl_launch, 7);
         if (!last) return;
+        // (the overflow count of this iteration -- final since the scatter kernel ended -- is requested together with the
+        // accumulators and used after the update; it used to be a dependent load of one lane behind the update)
+        const uint32_t ovf_p = a.ovf_cur ? ovf_part(a.ovf_cur, tid) : 0u;
         unsigned long long accv[kAccPerLane];
         acc_load_wave<true, true>(a.acc, tid, accv);
         const unsigned long long word = acc_reduce_wave(accv);
         model_update_wave(&s_state, word, tid, a.update_mode);
+        const uint32_t ovf_now = ovf_total_wave(ovf_p);
         if (tid == 0) {
             a.ticket[0] = 0;   // ready for the next launch (the kernel boundary orders it)
-            if (a.update_mode != 0) model_update_rest(&s_state, a.trace, a.cur, a.ovf_cur ? *a.ovf_cur : 0u);
-            if (a.ovf_next) *a.ovf_next = 0u;   // (tile-binned loop: the next iteration's overflow counter)
+            if (a.update_mode != 0) model_update_rest(&s_state, a.trace, a.cur, ovf_now);
         }
+        if (a.ovf_next) ovf_slot_clear(a.ovf_next, tid);   // (tile-binned loop: the next iteration's overflow counter)
         __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order)
         if (tid < (int)(sizeof(DevState) / 8)) {
             const unsigned long long v = reinterpret_cast<const unsigned long long*>(&s_state)[tid];

@@ -1936,7 +1936,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 final_done = true;
                 break;
             }
-            if (binned && ws.hot.need_rebin) want_rebin = true;
+            // (a warm start's follow-up batches are two iterations long: a re-bin -- three kernels, ~30 us on a large image --
+            // pays only where the overflow path would cost more, i.e. when a good part of the events took it)
+            // (the one-kernel loop has no overflow path: it WAITS for the re-bin it asks for)
+            if (binned && ws.hot.need_rebin && (fused || (unsigned long long)ws.last_ovf * 8ull > (unsigned long long)ws.n_events)) want_rebin = true;
             if (launched_iters - stall_allowance > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;

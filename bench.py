@@ -9,9 +9,14 @@ slice, 346x260, scale 3.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; slices are
-independent, so ranks shard slices with NO data-path collective and the
-job is weak-scaled.  The rendezvous is only used for the timing barrier / max-over-ranks.
+N > 1 runs one rank per GPU (rank r on device r).  Either the caller launches the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: WORLD_SIZE is set and
+must equal --gpus), or plain `python bench.py --gpus N` spawns them itself (spawn_ranks below:
+N copies of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, a gloo rendezvous on
+127.0.0.1).  Fewer visible devices than ranks is an error unless --oversubscribe (tests: two
+ranks on one GPU).  Slices are independent, so ranks shard slices with NO
+data-path collective and the job is weak-scaled; the rendezvous only carries the timing
+barrier / max-over-ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` is the warp+scatter kernel's algorithmic bytes
 (28 B per event-iteration, SURVEY.md 8(d)) over its hipEvent-measured duration;
@@ -31,6 +36,51 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 METRIC = "Mevents/s motion-compensated (warp→converged score), 1M-ev slice, 1/2/4/8 GPU"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 K1_BYTES_PER_EVENT_ITER = 28.0  # fr_x, fr_y, t (12 B) + previous pr (16 B)
+
+
+def host_cores():
+    """Host cores this job may use: the affinity mask capped by the container's CPU quota (cgroup v2)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script, rank r on device r, and wait.
+
+    The children find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment exactly as under
+    torch.distributed.run; rank 0 prints the JSON line on the inherited stdout.  A rank that fails takes the job down:
+    the others (which may be waiting in a barrier) are terminated by PID and the exit code is the failing rank's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BF_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p_ in list(live):
+            code = p_.poll()
+            if code is None:
+                continue
+            live.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code
+                for q_ in live:   # (exact PIDs of our own children)
+                    q_.terminate()
+    return rc
 
 
 def main():
@@ -59,6 +109,8 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="cap on the host cores of the slice-parallel CPU figure")
     ap.add_argument("--farm-slices", type=int, default=512,
                     help="--config 5: independent slices (seeds 0 .. n-1) farmed over the ranks, slice i -> rank i %% N")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than visible devices (rank r on device r %% devices): tests only")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-seed", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -75,9 +127,17 @@ def main():
         print(len(sl["t"]), lp.itercount, time.perf_counter() - t0, flush=True)
         return
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process only spawns the N ranks and relays the outcome
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: one rank per GPU, the two must agree"
+                         % (world, args.gpus))
     dist = None
     if world > 1:
         # torch first: its bundled libamdhip64.so.7 is then the one HIP runtime of the process
@@ -97,6 +157,9 @@ def main():
     ndev = accel.device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible (one rank per GPU; --oversubscribe "
+                         "shares devices, for tests)" % (world, ndev))
     device = local_rank % ndev
     if args.config == 5:
         # BASELINE config 5 as specified: a batch of independent cold slices (seeds 0 .. n-1) at 1280x720 farmed over the
@@ -534,13 +597,7 @@ def main():
         }
         # the fair multi-core figure -- one slice per host core, all cores busy at once (the
         # reference's O(N) loops are serial, so slice-parallel is the only way it uses a multi-core host)
-        ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        try:   # a container's CPU quota (cgroup v2), not the host's core count, is what this job may use
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-            if quota != "max":
-                ncore = min(ncore, max(1, int(quota) // int(period)))
-        except (OSError, ValueError):
-            pass
+        ncore = host_cores()   # (a container's CPU quota, not the host's core count, is what this job may use)
         ncore = max(1, min(ncore, args.cpu_cores if args.cpu_cores > 0 else ncore))
         if ncore > 1:
             # one PROCESS per core (threads of one process serialise on page faults of the per-iteration images);
@@ -648,6 +705,7 @@ def main():
                 "parallelism": "slice-parallel: %d GPU(s) x %d concurrent slice contexts (HIP streams) per GPU, "
                                "no collectives" % (world, B),
                 "host_cores_busy_per_rank": host_cores_busy,
+                "host_cores_available": host_cores(),
             },
             # SURVEY 8(d)'s own definition of the metric (host arrays -> model on the host, H2D included), cold regime:
             # the number next to `value`, which keeps the inputs resident in HBM as the bench contract prescribes

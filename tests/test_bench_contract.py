@@ -1,6 +1,7 @@
-"""bench.py's contract with the driver (GPU): one JSON line with the required keys, for the plain launch and for the
-one-process-per-GPU launch (`python -m torch.distributed.run ... bench.py --gpus N`; two ranks share GPU 0 here, which
-exercises the rendezvous, the barrier / max-over-ranks timing and the whole-job aggregation)."""
+"""bench.py's contract with the driver (GPU): one JSON line with the required keys, for the plain launch, for the plain
+launch with --gpus N (bench.py spawns its own N ranks) and for the one-process-per-GPU launch under a launcher
+(`python -m torch.distributed.run ... bench.py --gpus N`).  Two ranks share GPU 0 here (--oversubscribe), which exercises
+the rendezvous, the barrier / max-over-ranks timing and the whole-job aggregation."""
 import json
 import os
 import socket
@@ -88,3 +89,51 @@ def test_bench_config5_farm_two_ranks():
     assert d["n_gpus"] == 2 and d["unit"] == "Mevents/s" and d["value"] > 0
     c = d["config"]
     assert c["slices"] == 4 and c["slices_failed"] == 0 and "1280x720" in c["workload"] and c["iterations_per_slice_mean"] > 10
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """The driver's command form, `python3 bench.py --gpus N ...` with no launcher around it: N ranks, one JSON line."""
+    d = _line([sys.executable, "bench.py", "--gpus", "2", "--oversubscribe", "--steps", "2", "--warmup", "1"])
+    _check(d, 2, 2, 1)
+    assert "2 GPU(s)" in d["config"]["parallelism"] and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_bench_config5_gpus_flag_spawns_its_own_ranks():
+    d = _line([sys.executable, "bench.py", "--gpus", "2", "--oversubscribe", "--config", "5", "--farm-slices", "4",
+               "--events", "150000", "--concurrent", "2"])
+    assert d["n_gpus"] == 2 and d["config"]["slices"] == 4 and d["config"]["slices_failed"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_more_ranks_than_devices_fails_loudly():
+    from better_flow_amd import accel
+    n = accel.device_count() + 1
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and b"HIP device(s) visible" in r.stderr and b"{" not in r.stdout
+
+
+def test_bench_world_size_must_match_gpus_flag():
+    """(CPU) Under a launcher WORLD_SIZE must equal --gpus: a mismatch is an error, not a silently smaller job."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"must agree" in r.stderr
+
+
+def test_bench_gpus_flag_spawns_and_fails_without_devices():
+    """(CPU) `python bench.py --gpus 2` with no launcher spawns two ranks; on a machine without a HIP device both fail
+    loudly (no CPU fallback) and the parent relays the failure instead of printing a line."""
+    from better_flow_amd import accel
+    try:
+        have = accel.device_count() > 0
+    except Exception:   # noqa: BLE001
+        have = False
+    if have:
+        pytest.skip("a HIP device is present: the GPU tests cover the spawn path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and r.stderr.count(b"needs a HIP device") == 2 and b"{" not in r.stdout

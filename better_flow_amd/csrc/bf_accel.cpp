@@ -5,6 +5,7 @@
 // is reusable across slices and never allocates per slice.  There is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -13,6 +14,7 @@
 #include <chrono>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <string>
@@ -180,6 +182,7 @@ struct bf_ctx {
     bf_profile prof;
 
     char err[512];
+    std::mutex err_mu;   // fail() may be called from the uploading thread and the solving thread at once (see bf_accel.h: threading)
 };
 
 namespace {
@@ -188,6 +191,7 @@ int fail(bf_ctx* c, int code, const char* fmt, ...) {
     if (c) {
         va_list ap;
         va_start(ap, fmt);
+        std::lock_guard<std::mutex> g(c->err_mu);
         vsnprintf(c->err, sizeof(c->err), fmt, ap);
         va_end(ap);
     }
@@ -727,9 +731,18 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
             pos = end + 1;
             if (item.empty()) continue;
             const size_t eq = item.find('=');
-            const int orc = eq == std::string::npos ? BF_ERR_ARG : bf_set_option(c, item.substr(0, eq).c_str(), atoll(item.c_str() + eq + 1));
+            // (strtoll with an end pointer: "fused=abc" or "fused=" must not quietly become 0)
+            bool syntax = eq == std::string::npos || eq + 1 >= item.size();
+            long long val = 0;
+            if (!syntax) {
+                char* endp = nullptr;
+                errno = 0;
+                val = strtoll(item.c_str() + eq + 1, &endp, 10);
+                syntax = errno != 0 || endp == item.c_str() + eq + 1 || *endp != '\0';
+            }
+            const int orc = syntax ? BF_ERR_ARG : bf_set_option(c, item.substr(0, eq).c_str(), val);
             if (orc != BF_OK) {
-                fprintf(stderr, "bf_create: BF_ACCEL_OPTIONS entry '%s': %s\n", item.c_str(), eq == std::string::npos ? "expected key=value" : c->err);
+                fprintf(stderr, "bf_create: BF_ACCEL_OPTIONS entry '%s': %s\n", item.c_str(), syntax ? "expected key=<integer>" : c->err);
                 bf_destroy(c);
                 return orc;
             }
@@ -779,7 +792,15 @@ void bf_destroy(bf_ctx* c) {
     delete c;
 }
 
-const char* bf_last_error(const bf_ctx* c) { return c ? c->err : "null ctx"; }
+const char* bf_last_error(const bf_ctx* c) {
+    if (!c) return "null ctx";
+    // a copy private to the calling thread: another thread of the context's owner (the uploading one) may fail meanwhile
+    static thread_local char text[sizeof(c->err)];
+    std::lock_guard<std::mutex> g(const_cast<bf_ctx*>(c)->err_mu);
+    memcpy(text, c->err, sizeof(text));
+    text[sizeof(text) - 1] = 0;
+    return text;
+}
 
 int bf_get_stat(bf_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return BF_ERR_ARG;
@@ -832,6 +853,7 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         for (int slot = 0; slot < 2; ++slot) {
             if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
             if (!c->d_in16[slot]) HIP_TRY(c, hipMalloc(&c->d_in16[slot], (size_t)c->cap_events * 2 * sizeof(uint16_t)));
+            if (!c->d_in_noise[slot]) HIP_TRY(c, hipMalloc(&c->d_in_noise[slot], (size_t)c->cap_events));   // (else: first use, possibly in the middle of a solve)
         }
         return BF_OK;
     }

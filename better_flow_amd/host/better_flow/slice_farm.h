@@ -327,9 +327,14 @@ private:
                     std::lock_guard<std::mutex> g(mu_);
                     while (!queue_.empty() && queue_.front().uploaded) { staged.push_back(queue_.front()); queue_.pop_front(); }
                 }
-                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc >= 0) (void)bf_commit_upload(wk.ctx);
-                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc >= 0) p.upload_rc = issue_upload(wk.ctx, p.task);
-                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc < 0) --wk.slots;   // (a failed re-issue holds no slot)
+                // (only the jobs that HOLD a slot: one whose first copy already failed never got one and is reported as it is)
+                std::vector<Staged *> held;
+                for (Staged &p : staged) if (p.task.n > 0 && p.upload_rc >= 0) held.push_back(&p);
+                for (Staged *p : held) { (void)p; (void)bf_commit_upload(wk.ctx); }
+                for (Staged *p : held) {
+                    p->upload_rc = issue_upload(wk.ctx, p->task);
+                    if (p->upload_rc < 0) --wk.slots;   // (a failed re-issue holds no slot)
+                }
             }
         }
     }

@@ -266,6 +266,9 @@ public:
         p.new_events = (uint64_t)event_diff;
         p.time_diff = time_diff;
         p.trigger_plus1 = head;
+        // (the ring slots a slice in flight still needs: its events and, for a full ring, the oldest element it leaves out --
+        // deliver() zeroes that element's flow and must still find it there)
+        p.protect = oldest;
         SliceFarm::Task t;
         t.ring_row = row_; t.ring_col = col_; t.ring_ts = ts; t.ring_noise = noise; t.noise_live = &noise_live;
         t.first_global = p.first;
@@ -273,12 +276,16 @@ public:
         t.t0 = p.start_time + time_base;
         t.scale = scale; t.res_x = RES_X; t.res_y = RES_Y; t.max_iter = max_iter;
         t.warm = stm_disable ? SliceFarm::Warm::Cold : SliceFarm::Warm::FromPrevious;
-        if (accumulate && p.n > 0) {
+        if ((accumulate || (want_flow && farm->workers() > 1)) && p.n > 0) {
+            // A private block per slice, copied into the ring by deliver() -- which runs in SLICE order.  Needed for
+            // get_accumulated(), and whenever several workers solve overlapping slices at once: written straight into
+            // the shared ring, an event's flow would be that of whichever slice FINISHED last (and two workers would
+            // write overlapping host memory concurrently), not that of the latest slice as in DVS_flow.
             // (uninitialised: bf_compute_uv_ring writes every pair.  A value-initialised vector cost the producer 16 MB of
             // page faults and zeroes per 1M-event slice -- 4 ms, more than the slice's whole solve)
             p.block = std::shared_ptr<double>(new double[2 * (size_t)p.n], std::default_delete<double[]>());
             t.uv_ring = p.block.get(); t.uv_cap = (int64_t)p.n; t.uv_first = 0;
-        } else if (want_flow && p.n > 0) {
+        } else if (want_flow && p.n > 0) {   // one worker: slices complete in order, straight into the pinned ring
             t.uv_ring = uv; t.uv_cap = (int64_t)cap; t.uv_first = t.first;
         }
         t.user = p.index;
@@ -291,7 +298,7 @@ public:
         {
             std::lock_guard<std::mutex> g(mu);
             pending.push_back(p);
-            protected_from.store(pending.front().first, std::memory_order_release);
+            protected_from.store(pending.front().protect, std::memory_order_release);
         }
         last_trigger_plus1 = head;
         event_diff = 0;
@@ -334,7 +341,7 @@ public:
 
 protected:
     struct Pending {
-        uint64_t index = 0, first = 0, n = 0, ring_size = 0, new_events = 0, trigger_plus1 = 0;
+        uint64_t index = 0, first = 0, n = 0, ring_size = 0, new_events = 0, trigger_plus1 = 0, protect = 0;
         ull start_time = 0, trigger_time = 0, oldest_time = 0;
         sll time_diff = 0;
         bool full = false, zero_excluded = false;
@@ -344,6 +351,9 @@ protected:
         uint64_t first, n;
         ull start_time;
         std::shared_ptr<double> block;   // (u, v) pairs of the slice's events
+        bool lead;                // the ring was full and its oldest element (event first - 1, which the slice leaves out,
+                                  // datastructures.h:71-76) had never been in a slice: the reference's copy of the ring
+                                  // (dvs_flow.h:340-345) holds it too, with the zero flow of a fresh Event
     };
 
     // configuration
@@ -530,7 +540,7 @@ protected:
                 ++slices_done;
                 if (r.rc != 0) ++slices_skipped;
                 iterations_total += (ull)r.info.iterations;
-                if (accumulate) kept.push_back(Kept{p.first, p.n, p.start_time, p.block});
+                if (accumulate) kept.push_back(Kept{p.first, p.n, p.start_time, p.block, p.zero_excluded});
                 if (p.trigger_plus1 > flow_through_plus1) flow_through_plus1 = p.trigger_plus1;
             }
         }
@@ -538,7 +548,7 @@ protected:
         {
             std::lock_guard<std::mutex> g(mu);
             pending.pop_front();
-            protected_from.store(pending.empty() ? UINT64_MAX : pending.front().first, std::memory_order_release);
+            protected_from.store(pending.empty() ? UINT64_MAX : pending.front().protect, std::memory_order_release);
         }
         cv.notify_all();
     }
@@ -580,19 +590,23 @@ inline FlowTable StreamEngine::get_accumulated() {
         for (size_t j = i + 1; j < K && kept[j].first <= c; ++j)
             if (c < kept[j].first + kept[j].n) mark[j][(size_t)(c - kept[j].first)] = 1;
     };
+    auto emit = [&](size_t i, uint64_t g, double eu, double ev) {   // an unmarked event of slice i: mark its later copies, write it
+        const uint64_t t = hist_ts[g];
+        if (i + 1 < K) {
+            mark_later(i, g);
+            for (uint32_t c = prev[g]; c != NONE && t - hist_ts[c] < 100000ull; c = prev[c]) mark_later(i, c);   // dt < 0.1 ms
+            for (uint32_t c = next[g]; c != NONE && hist_ts[c] == t; c = next[c]) mark_later(i, c);             // same instant, arrived later
+        }
+        out.timestamp.push_back(t); out.row.push_back(hist_row[g]); out.col.push_back(hist_col[g]);
+        out.u.push_back(eu); out.v.push_back(ev);
+    };
     for (size_t i = 0; i < K; ++i) {
         const Kept &s = kept[i];
+        // (its t is the raw timestamp -- it never saw set_local_time --, so the t == -1 mark does not apply to it)
+        if (s.lead) emit(i, s.first - 1, 0.0, 0.0);
         for (uint64_t p = 0; p < s.n; ++p) {
             if (mark[i][(size_t)p]) continue;
-            const uint64_t g = s.first + p;
-            const uint64_t t = hist_ts[g];
-            if (i + 1 < K) {
-                mark_later(i, g);
-                for (uint32_t c = prev[g]; c != NONE && t - hist_ts[c] < 100000ull; c = prev[c]) mark_later(i, c);   // dt < 0.1 ms
-                for (uint32_t c = next[g]; c != NONE && hist_ts[c] == t; c = next[c]) mark_later(i, c);             // same instant, arrived later
-            }
-            out.timestamp.push_back(t); out.row.push_back(hist_row[g]); out.col.push_back(hist_col[g]);
-            out.u.push_back(s.block.get()[2 * (size_t)p]); out.v.push_back(s.block.get()[2 * (size_t)p + 1]);
+            emit(i, s.first + p, s.block.get()[2 * (size_t)p], s.block.get()[2 * (size_t)p + 1]);
         }
     }
     return out;

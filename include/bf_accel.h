@@ -20,8 +20,16 @@
  * BF_ERR_NODEVICE and every other call fails with BF_ERR_ARG on a NULL ctx.
  *
  * Threading: one bf_ctx per (host thread, GPU).  A ctx is reusable across slices
- * (no per-slice allocation), is not thread-safe, and owns all of its device memory,
- * pinned staging and its HIP stream.
+ * (no per-slice allocation), owns all of its device memory, pinned staging and its HIP
+ * stream, and is NOT thread-safe -- with one exception, which the stream engine
+ * (better_flow/slice_farm.h) relies on: the asynchronous uploads (bf_upload_events_async,
+ * bf_upload_ring_async, bf_upload_ring16_async) and bf_wait_uploads touch only the
+ * context's staging slots and copy stream and may be called from a SECOND thread while
+ * the owning thread is inside bf_set_cloud, bf_set_model, bf_run or bf_compute_uv*.  The
+ * caller serialises them against each other and against bf_commit_upload (one mutex),
+ * and sets "stream_prealloc" first so that no upload allocates device memory in the
+ * middle of a solve.  Nothing else may run concurrently on one ctx.  bf_last_error
+ * returns a copy of the text private to the calling thread.
  */
 #ifndef BF_ACCEL_H
 #define BF_ACCEL_H

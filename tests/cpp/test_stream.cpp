@@ -124,6 +124,30 @@ static int run(const char *tag, const Stream &in, ull on_ev, ull on_time, int ma
     std::printf("bulk, pipelined, %d worker(s): %zu vs %zu slices, %zu slice differences, %zu table differences\n", workers, recs.size(),
                 recs_b.size(), rec_diff, tab_diff);
     if (rec_diff || tab_diff) ++bad;
+    if (workers > 1) {
+        // ---- C: several workers WITHOUT accumulate: the (u, v) ring must hold, for every event, the flow of the LATEST slice
+        // that solved it (DVS_flow: a later recompute overwrites best_u / best_v) -- not that of whichever overlapping slice
+        // finished last on some worker.  Compared with front end A's ring (one worker, slices in order) after the tail.
+        bf::StreamFlow<MAX_SZ, SPAN> ringc(on_ev, on_time);
+        ringc.set_max_iter(max_iter);
+        ringc.set_pipelined();
+        ringc.set_stm_disable(true);
+        ringc.set_devices(std::vector<int>{bf::DeviceContext::device()}, workers);
+        for (size_t at = 0; at < in.t.size(); at += 7777) {
+            const size_t m = in.t.size() - at < 7777 ? in.t.size() - at : 7777;
+            ringc.add_events(in.row.data() + at, in.col.data() + at, in.t.data() + at, m);
+        }
+        ringc.recompute();
+        ringc.drain();
+        size_t ring_diff = sf.size() == ringc.size() ? 0 : 1;
+        const size_t visit = sf.size() == MAX_SZ ? sf.size() - 1 : sf.size();   // (the oldest element of a full ring is in no slice)
+        for (size_t k = 0; k < visit && k < ringc.size(); ++k) {
+            const double a_u = sf.u(k), a_v = sf.v(k), c_u = ringc.u(k), c_v = ringc.v(k);
+            if (sf.timestamp(k) != ringc.timestamp(k) || std::memcmp(&a_u, &c_u, 8) != 0 || std::memcmp(&a_v, &c_v, 8) != 0) ++ring_diff;
+        }
+        std::printf("flow ring, %d workers, no accumulate: %zu differences over %zu ring elements\n", workers, ring_diff, visit);
+        if (ring_diff) ++bad;
+    }
     std::printf("%s %s: %d slices + tail, %d stopped by the window guard, %d problems (ring %zu, span %lld ns)\n", bad ? "FAIL" : "OK", tag,
                 slices, skipped_guard, bad, (size_t)MAX_SZ, (long long)SPAN);
     return bad;
@@ -137,6 +161,11 @@ int main(int argc, char **argv) {
     bad += run<3000, 15000000>("short-span", plain, 1000, FROM_SEC(0.5), -1, false, 1);         // the 15 ms span trims the ring before it fills
     bad += run<50000, 200000000>("never-full", twins, 4000, FROM_SEC(0.033), 10, true, 1);      // never full; capped, STM off
     bad += run<3000, 40000000>("independent x3", twins, 1500, FROM_SEC(0.02), 10, true, 3);     // independent slices on three workers
+    // a ring SMALLER than the trigger interval: every slice finds the ring full, and its oldest element -- which the slice
+    // leaves out (datastructures.h:71-76) -- has never been in a slice: the reference's accumulated copy (dvs_flow.h:340-345)
+    // still holds it, with zero flow
+    bad += run<1000, 40000000>("ring < trigger", twins, 1500, FROM_SEC(0.02), 10, false, 1);
+    bad += run<1000, 40000000>("ring < trigger x2", twins, 1500, FROM_SEC(0.02), 10, true, 2);
     {   // a sensor so large that the confined start of the stream falls under the window guard (optimizer_rolling.h:49-55):
         // those slices flag their events as noise, and the flagged events stay out of the later, overlapping slices
         bf::sensor().res_x = 1000; bf::sensor().res_y = 1400;

@@ -116,4 +116,5 @@ def test_config4_full_size_every_tile_against_its_oracle(oracle_lib, accel_mod):
            int((np.abs(it_g - it_o) == 1).sum()), second_bar, worst))
     assert ran >= 900 and skipped >= 1, (ran, skipped)
     assert it_g.max() > 1000, "the straggler regime (one tile far above the mean) must be part of the test"
-    assert second_bar <= ran // 20, second_bar
+    # (13 of 957 need the second bar today; bounded at 2 %, not at a comfortable multiple)
+    assert second_bar <= ran // 50, second_bar

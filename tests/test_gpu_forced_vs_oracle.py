@@ -1,0 +1,106 @@
+"""Every loop form of the library, FORCED, against the CPU oracle (not against another device loop).
+
+tests/test_gpu_fused.py and tests/test_gpu_split.py show that the one-kernel iteration (`fused`) and the own-pixels +
+margin-plane format (`bin_split`) return the bits of the two-kernel dense-slab loop, which the other suites hold to the
+oracle -- a transitive argument.  Here each form is selected explicitly (and the test checks that it is the one that ran)
+and compared with `oracle/bf_oracle.c` directly on the same slice:
+
+* the valid-pixel count of the time image -- an integer, the support of the event-count image seen through the form's own
+  scatter + stencil kernels -- equal at EVERY iteration up to the first pixel-boundary crossing (accel_lib.h:147-178,
+  object_model.cpp:103-126);
+* every field of the 41-record trajectory <= 1e-6 relative (floors as in test_gpu_geometries.py) up to that crossing,
+  which must not come before iteration 9, and within 4 x the oracle's own forward / reversed spread afterwards
+  (optimizer_rolling.h:48-125,305-347);
+* the per-event flow after the capped run within the same yardstick (event.h:135-142).
+"""
+import numpy as np
+import pytest
+
+from better_flow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = {"dx": 1e-4, "dy": 1e-4, "rot": 1e-2, "div": 1.0,
+          "total_dx": 1e-4, "total_dy": 1e-4, "total_rot": 1e-6, "total_div": 1e-4}
+K = 40
+
+# name -> (options, scatter_format the context must report, one-kernel loop expected)
+FORMS = {
+    "one-kernel iteration (fused=2)": (dict(binned=2, fused=2), None, 1),
+    "own pixels + margin plane, update at the scatter head (bin_split=2)":
+        (dict(binned=2, fused=0, bin_compact=0, bin_split=2), 3, 0),
+    "own pixels + margin plane, update in the stencil tail (bin_split=2, co_schedule)":
+        (dict(binned=2, fused=0, bin_compact=0, bin_split=2, co_schedule=1), 3, 0),
+    "dense slabs, update in the stencil tail": (dict(binned=2, fused=0, bin_compact=0, bin_split=0, co_schedule=1), 0, 0),
+    "event lists (bin_compact=2)": (dict(binned=2, fused=0, bin_compact=2), 2, 0),
+    "merged lists (bin_compact=3)": (dict(binned=2, fused=0, bin_compact=3), 1, 0),
+    "global atomics (binned=0)": (dict(binned=0, fused=0), -1, 0),
+}
+
+
+@pytest.fixture(scope="module")
+def case(oracle_lib):
+    H, W, s = 260, 346, 3
+    sl = synth.make_slice(300000, H, W, 0.030, seed=41)
+    n = len(sl["t"])
+
+    def oracle_run(order):
+        o = oracle_lib.Cloud(sl["fr_x"][order], sl["fr_y"][order], sl["t"][order])
+        w_ = o.set_cloud(s, H, W)
+        m_ = oracle_lib.Model()
+        rc_, lp_, tr_ = o.run(w_, m_, max_iter=K, res_x=H, res_y=W, trace_cap=K + 1)
+        assert rc_ == 0 and lp_.itercount == K + 1
+        u_, v_ = o.compute_uv()
+        inv = np.empty(n, np.int64)
+        inv[order] = np.arange(n)
+        return tr_, u_[inv], v_[inv]
+    otr, ou, ov = oracle_run(np.arange(n))
+    otr_r, ou_r, ov_r = oracle_run(np.arange(n)[::-1].copy())
+    spread = {f: max(abs(getattr(otr[k].model, f) - getattr(otr_r[k].model, f)) for k in range(K + 1)) for f in FIELDS}
+    cnt_spread = max(abs(otr[k].model.cnt - otr_r[k].model.cnt) for k in range(K + 1))
+    return dict(H=H, W=W, s=s, sl=sl, otr=otr, ou=ou, ov=ov, ou_r=ou_r, ov_r=ov_r, spread=spread, cnt_spread=cnt_spread)
+
+
+@pytest.mark.parametrize("form", list(FORMS), ids=lambda f: f.split(" (")[0].replace(" ", "_").replace(",", ""))
+def test_forced_form_against_the_oracle(accel_mod, case, form):
+    options, want_fmt, want_one_kernel = FORMS[form]
+    H, W, s, sl = case["H"], case["W"], case["s"], case["sl"]
+    a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
+    for k, v in options.items():
+        a.set_option(k, v)
+    a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    a.set_cloud(s, H, W)
+    assert a.get_stat("one_kernel") == want_one_kernel, form
+    if want_fmt is not None:
+        assert a.get_stat("scatter_format") == want_fmt, (form, a.get_stat("scatter_format"))
+    o = a.default_opts()
+    o.res_x, o.res_y, o.max_iter, o.trace_cap, o.want_uv = H, W, K, K + 1, 1
+    rc, m, info = a.run(o)
+    tr = [t_.model.as_dict() for t_ in a.get_trace(K + 1)]
+    u, v = a.compute_uv()
+    a.close()
+    assert rc == 0 and info.iterations == K + 1 and len(tr) == K + 1
+    if want_one_kernel:
+        assert info.launches < 1.5 * info.iterations + 3 * info.rebins + 8, "the one-kernel loop was not the one that ran"
+    otr, spread = case["otr"], case["spread"]
+    k_g = next((k for k in range(K + 1) if tr[k]["cnt"] != otr[k].model.cnt), K + 1)
+    assert k_g >= 9, (form, k_g)
+    worst = [0.0, 0.0]
+    for k in range(K + 1):
+        g, o_ = tr[k], otr[k].model
+        for f, floor in FIELDS.items():
+            ov_ = getattr(o_, f)
+            if k < k_g:
+                dev = abs(g[f] - ov_) / max(abs(ov_), floor)
+                worst[0] = max(worst[0], dev)
+                assert dev <= 1e-6, (form, k, f, g[f], ov_)
+            else:
+                worst[1] = max(worst[1], abs(g[f] - ov_) / max(spread[f], 1e-300))
+                assert abs(g[f] - ov_) <= 4.0 * spread[f] + 1e-6 * max(abs(ov_), floor), (form, k, f, g[f], ov_, spread[f])
+        if k >= k_g:
+            assert abs(g["cnt"] - o_.cnt) <= 4 * max(case["cnt_spread"], 1), (form, k)
+    for g_, o_, r_ in ((u, case["ou"], case["ou_r"]), (v, case["ov"], case["ov_r"])):
+        yard = np.abs(o_ - r_).max()
+        assert np.all(np.abs(g_ - o_) <= 4.0 * yard + 1e-6 * np.abs(o_) + 1e-3), (form, np.abs(g_ - o_).max(), yard)
+    print("%s: valid-pixel counts equal for the first %d iterations; worst relative deviation before the first crossing "
+          "%.2e, after it %.2f x the oracle's own spread" % (form, k_g, worst[0], worst[1]))

@@ -453,16 +453,25 @@ def _build_test_stream(out_dir, against_gpu):
 def _check_stream_output(out):
     lines = out.splitlines()
     verdicts = [ln for ln in lines if ln.startswith(("OK", "FAIL"))]
-    assert len(verdicts) == 6 and all(v.startswith("OK") for v in verdicts), out[-4000:]
+    assert len(verdicts) == 8 and all(v.startswith("OK") for v in verdicts), out[-4000:]
     # the small ring really filled (full-ring quirk: one element fewer iterated) and the short span really trimmed
     assert "ring 3000 / 3000, iterated 2999" in out
     assert any(int(ln.split("ring ")[1].split(" /")[0]) < 3000 for ln in lines if ln.startswith("slice"))
     # every run compared a non-trivial accumulated table, and the bulk / pipelined / multi-worker replays agreed
     acc = [ln for ln in lines if ln.startswith("accumulated:")]
-    assert len(acc) == 6 and all(ln.endswith(" 0 differences") and int(ln.split()[1]) > 3000 for ln in acc), acc
+    assert len(acc) == 8 and all(ln.endswith(" 0 differences") and int(ln.split()[1]) > 3000 for ln in acc), acc
     bulk = [ln for ln in lines if ln.startswith("bulk, pipelined")]
-    assert len(bulk) == 6 and all("0 slice differences, 0 table differences" in ln for ln in bulk), bulk
-    assert sum("3 worker(s)" in ln or "2 worker(s)" in ln for ln in bulk) == 2
+    assert len(bulk) == 8 and all("0 slice differences, 0 table differences" in ln for ln in bulk), bulk
+    assert sum("3 worker(s)" in ln or "2 worker(s)" in ln for ln in bulk) == 3
+    # several workers without accumulate: the (u, v) ring holds the flow of the latest slice, whatever order the workers finish in
+    ring = [ln for ln in lines if ln.startswith("flow ring,")]
+    assert len(ring) == 3 and all(" 0 differences over " in ln and int(ln.split("over ")[1].split()[0]) > 500 for ln in ring), ring
+    # a ring smaller than the trigger interval: the table holds EVERY event seen, including the oldest element each full-ring
+    # slice leaves out (never solved: zero flow) -- dvs_flow.h:340-345
+    small = [lines[i] for i, ln in enumerate(lines) if ln.startswith(("OK ring < trigger", "FAIL ring < trigger"))]
+    assert len(small) == 2
+    for ln in acc[6:]:
+        assert ln.split()[1] == ln.split()[3] == ln.split()[6], ln
     # the two runs on the oversized sensor went through the window guard (events flagged as noise) AND through real solves
     noise = [v for v in verdicts if "noise-" in v]
     assert len(noise) == 2

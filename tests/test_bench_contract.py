@@ -71,7 +71,7 @@ def test_bench_two_ranks_torchrun():
     port = s.getsockname()[1]
     s.close()
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"])
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--oversubscribe", "--steps", "2", "--warmup", "1"])
     _check(d, 2, 2, 1)
     assert d["cpu_baseline"] is None          # timed on rank 0 at N = 1 only
 
@@ -84,7 +84,7 @@ def test_bench_config5_farm_two_ranks():
     port = s.getsockname()[1]
     s.close()
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--config", "5", "--farm-slices", "4",
+               "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--oversubscribe", "--config", "5", "--farm-slices", "4",
                "--events", "150000", "--concurrent", "2"])
     assert d["n_gpus"] == 2 and d["unit"] == "Mevents/s" and d["value"] > 0
     c = d["config"]

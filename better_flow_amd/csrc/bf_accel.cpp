@@ -72,6 +72,11 @@ struct bf_ctx {
     BinGrid fgrid;                   // its sort grid: keys = (tile, zone)
     uint32_t* d_ftab = nullptr;      // FusedTab per tile
     int ftab_alloc = 0;
+    // persistent form of that loop (k_fused_loop, bf_loop.hip): a context ALONE on the GPU keeps the work-groups resident
+    int opt_persist = 1;             // 0 never, 1 when the one-kernel loop is taken and the context is not co-scheduled
+    unsigned long long *d_xrec = nullptr, *d_xred = nullptr;   // exchange records of the sub-tiles / of the reducers (two parities each)
+    int xrec_alloc = 0;              // records per parity d_xrec holds
+    float2* d_xscratch[3] = {nullptr, nullptr, nullptr};       // private product arrays of the strips' readers
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
     uint32_t* d_armed = nullptr;
@@ -776,7 +781,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in16[i]) (void)hipFree(c->d_in16[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in_noise[i]) (void)hipFree(c->d_in_noise[i]);
-    void* bufs[] = {c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
+    void* bufs[] = {c->d_xrec, c->d_xred, c->d_xscratch[0], c->d_xscratch[1], c->d_xscratch[2], c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_mplane[0], c->d_mplane[1], c->d_mlist, c->d_mcount, c->d_ovf_bits[0], c->d_ovf_bits[1], c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
@@ -901,6 +906,11 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     if (!strcmp(key, "fused")) {
         if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "fused must be 0, 1 (auto) or 2");
         c->opt_fused = (int)value;
+        return BF_OK;
+    }
+    if (!strcmp(key, "persist")) {
+        if (value < 0 || value > 1) return fail(c, BF_ERR_ARG, "persist must be 0 or 1");
+        c->opt_persist = (int)value;
         return BF_OK;
     }
     if (!strcmp(key, "fused_margin")) {
@@ -1736,6 +1746,26 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of
     // idle GPU).  Kernels launched after `done` was set return at once (~1 us each).
+    // The persistent form of the one-kernel loop (bf_loop.hip): the work-groups stay resident over many iterations and
+    // exchange their moment sums through memory -- for a context that has the GPU to itself (two such kernels from two
+    // contexts could each hold half of the CUs and wait for the other half).
+    const bool persist = fused && !c->opt_co_schedule && c->opt_persist != 0 &&
+                         fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc);   // (else: one launch per iteration)
+    if (persist) {
+        const int nsub = c->fgrid.TSR / 16, nrec = c->fgrid.nbr * c->fgrid.nbc * nsub;
+        if (nrec > c->xrec_alloc) {
+            if (c->d_xrec) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_xrec)); }
+            c->d_xrec = nullptr;
+            HIP_TRY(c, hipMalloc(&c->d_xrec, (size_t)2 * (size_t)nrec * 32 * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_xrec, 0, (size_t)2 * (size_t)nrec * 32 * sizeof(unsigned long long), c->stream));
+            c->xrec_alloc = nrec;
+        }
+        if (!c->d_xred) {
+            HIP_TRY(c, hipMalloc(&c->d_xred, (size_t)2 * 16 * 32 * sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_xred, 0, (size_t)2 * 16 * 32 * sizeof(unsigned long long), c->stream));
+            for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_xscratch[i], (size_t)c->cap_events * sizeof(float2)));
+        }
+    }
     bool want_rebin = false;
     int last_rebin_at = 0;
     // A warm start that is expected to converge in a handful of iterations (the previous one did) is polled batch by batch,
@@ -1743,7 +1773,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // warm-started slice -- is fed and polled like a cold run: two-iteration batches with a blocking poll each cost it a
     // host round trip every other iteration (22 instead of 14 us per iteration on a 50 000-event slice).
     const bool quick_warm = warm_start && c->warm_iters_hint < 3 * o.poll_interval;
-    const bool snap_polled = binned && !quick_warm;   // progress is read from the pinned snapshot (below)
+    const bool snap_polled = binned && !quick_warm && !persist;   // progress is read from the pinned snapshot (below)
     if (snap_polled) {
         *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
         *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0].run_tag) = 0ull;
@@ -1755,7 +1785,61 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     double ht_launch = 0, ht_wait = 0;
     auto ht_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double ht_mark = host_timing ? ht_now() : 0;
-    for (int batch = 0;; ++batch) {
+    for (int batch = 0; persist; ++batch) {
+        // One round: the (device-gated) re-bin, the loop kernel -- which returns when the loop is over, when a re-bin is due
+        // or after max_passes iterations --, the final warp gated on `done`, and the state for the host.  A round ends with
+        // a host round trip (~20 us of idle GPU); a cold run takes about one per re-bin.
+        {
+            int rc = enqueue_rebin(c, c->d_state, perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr, true, 0);
+            if (rc != BF_OK) return rc;
+        }
+        FusedLoopArgs la;
+        la.sets = ev_sets(c);
+        la.ftab = c->d_ftab;
+        la.st = c->d_state; la.st_other = c->d_state + 1;
+        la.snap = nullptr;
+        la.rec = c->d_xrec; la.red = c->d_xred;
+        for (int i = 0; i < 3; ++i) la.scratch[i] = c->d_xscratch[i];
+        la.trace = trace;
+        la.nbr = c->fgrid.nbr; la.nbc = c->fgrid.nbc;
+        la.R = c->win.scale_img_x; la.C = c->win.scale_img_y;
+        la.max_passes = 4096;
+        la.first_warp = first_warp ? 1 : 0;
+        {
+            ProfScope ps(c, 0, c->n);
+            HIP_TRY(c, launch_fused_loop(la, c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->stream));
+        }
+        {
+            ProfScope ps(c, 3);
+            WarpScatterArgs fa = ws_args(c, buf, 2);
+            fa.st = c->d_state;
+            fa.pick_set = 1;
+            fa.sorted_out = 1;
+            if (o.want_uv) fa.uv = c->d_uv;
+            launch_final_warp(fa, c->stream);
+        }
+        inf.launches += 5;
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(c->poll_ev[batch & 1], c->stream));
+        if (warm_start || !c->opt_blocking_poll) {
+            HIP_TRY(c, hipEventSynchronize(c->poll_ev[batch & 1]));
+        } else {
+            int rcw = wait_event_sleeping(c, c->poll_ev[batch & 1]);
+            if (rcw != BF_OK) return rcw;
+        }
+        inf.polls++;
+        const DevState& ws = c->h_state[batch & 1];
+        launched_iters = ws.last_j + 1;
+        if (ws.hot.done) {
+            fin = ws;
+            final_done = true;
+            break;
+        }
+        if (batch > 100000) return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
+    }
+    const bool persist_ran = final_done;
+    for (int batch = 0; !persist_ran; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
         // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
         // when a polled snapshot shows the update asking for one.  The request is predictive

@@ -379,40 +379,6 @@ __global__ __launch_bounds__(kBsThreads) void k_bin_scatter(EvSets sets, int has
     }
 }
 
-// A structure in LDS -> scalar registers: every lane reads it, v_readfirstlane makes each word uniform (the values a
-// kernel branches and addresses with should not occupy vector registers).
-template <class T>
-__device__ __forceinline__ T lds_uniform(const T* p) {
-    static_assert(sizeof(T) % 4 == 0, "whole words");
-    T out;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
-    return out;
-}
-
-// What the scatter loop needs from the state, in scalar registers.
-struct ScatterHot {
-    int32_t done, bin_tbits, bin_ok, fmt, scale, C, wsx, wsy, x_sh, y_sh;
-    long long tmin;
-    WarpParams wp;
-};
-__device__ __forceinline__ int lds_sreg(const int32_t* p) { return __builtin_amdgcn_readfirstlane(*p); }
-__device__ __forceinline__ ScatterHot scatter_hot(const DevState* s) {
-    ScatterHot h;
-    h.done = lds_sreg(&s->hot.done); h.bin_tbits = lds_sreg(&s->hot.bin_tbits); h.bin_ok = lds_sreg(&s->hot.bin_ok);
-    h.fmt = lds_sreg(&s->hot.fmt);
-    h.scale = lds_sreg(&s->hot.scale); h.C = lds_sreg(&s->hot.C); h.wsx = lds_sreg(&s->hot.wsx); h.wsy = lds_sreg(&s->hot.wsy);
-    h.x_sh = lds_sreg(&s->hot.x_sh); h.y_sh = lds_sreg(&s->hot.y_sh);
-    const long long tm = s->hot.tmin;
-    h.tmin = ((long long)__builtin_amdgcn_readfirstlane((int)(tm >> 32)) << 32) |
-             (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)tm);
-    h.wp = lds_uniform(&s->hot.wp);
-    return h;
-}
-
-constexpr int kStateWords = (int)(sizeof(DevState) / 8);
 constexpr int kMaxTileRows = 192;   // LR = TSR + 2 D <= 128 + 64
 
 // One event of the tile-binned scatter, from its previous projected position: warp (event.h:100-108,164-168 -- same

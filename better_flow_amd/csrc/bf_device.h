@@ -105,7 +105,8 @@ struct HotState {
     int32_t pp, redo;                 // one-kernel iteration: which of a set's two product arrays is current; the next pass repeats
                                       // the scatter of the last one after a re-bin (its sums were incomplete)
     int32_t pend, spare_;             // ... the sums of the last pass await their update (launch numbers do not tell: passes
-                                      // that wait for a re-bin or repeat one do not advance the iteration)
+                                      // that wait for a re-bin or repeat one do not advance the iteration);
+                                      // spare_: launches of the persistent loop kernel (k_fused_loop) completed in this run
     int32_t cs, flip, bin_ok, fmt;    // live event set; flip = a re-bin moved the events to set cs^1; fmt = this slice's scatter writes
                                       // COMPACT lists (1) instead of dense slabs (0) (informative: bf_binned.hip);
                                       // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)

@@ -318,9 +318,12 @@ __device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_bia
 // 2^-64; a 30 ms slice rotates by ~1e-3), the library routine otherwise.  ~10 dependent operations instead of ~100 on
 // the one lane every iteration waits for.  Agrees with libm to <= 1 ulp (the reference calls std::cos / std::sin,
 // event.h:102-103; the stand-alone operator bf_project_4param_reinit does so too, on the host).
+// (the library routine out of line: inlined, its two dozen f64 constants are materialised -- and, in a kernel that loops,
+// hoisted into registers for the whole loop -- on a path no real slice takes)
+__device__ __attribute__((noinline)) static void sincos_large(double x, double* sn, double* cs) { sincos(x, sn, cs); }
 __device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
     if (!(fabs(x) <= 0.25)) {
-        sincos(x, sn, cs);
+        sincos_large(x, sn, cs);
         return;
     }
     const double z = x * x;
@@ -603,6 +606,42 @@ __device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int 
 }
 
 typedef unsigned int bf_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kStateWords = (int)(sizeof(DevState) / 8);
+
+// A structure in LDS -> scalar registers: every lane reads it, v_readfirstlane makes each word uniform (the values a
+// kernel branches and addresses with should not occupy vector registers).
+template <class T>
+__device__ __forceinline__ T lds_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    T out;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
+    return out;
+}
+
+// What the scatter loop needs from the state, in scalar registers.
+struct ScatterHot {
+    int32_t done, bin_tbits, bin_ok, fmt, scale, C, wsx, wsy, x_sh, y_sh;
+    long long tmin;
+    WarpParams wp;
+};
+__device__ __forceinline__ int lds_sreg(const int32_t* p) { return __builtin_amdgcn_readfirstlane(*p); }
+__device__ __forceinline__ ScatterHot scatter_hot(const DevState* s) {
+    ScatterHot h;
+    h.done = lds_sreg(&s->hot.done); h.bin_tbits = lds_sreg(&s->hot.bin_tbits); h.bin_ok = lds_sreg(&s->hot.bin_ok);
+    h.fmt = lds_sreg(&s->hot.fmt);
+    h.scale = lds_sreg(&s->hot.scale); h.C = lds_sreg(&s->hot.C); h.wsx = lds_sreg(&s->hot.wsx); h.wsy = lds_sreg(&s->hot.wsy);
+    h.x_sh = lds_sreg(&s->hot.x_sh); h.y_sh = lds_sreg(&s->hot.y_sh);
+    const long long tm = s->hot.tmin;
+    h.tmin = ((long long)__builtin_amdgcn_readfirstlane((int)(tm >> 32)) << 32) |
+             (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)tm);
+    h.wp = lds_uniform(&s->hot.wp);
+    return h;
+}
+
 
 // ---- moment sums across work-groups: exact fixed-point accumulators (bf_device.h: MomentAcc) ----------------------
 __device__ __forceinline__ void fx_split(double v, unsigned long long& hi, unsigned long long& lo) {

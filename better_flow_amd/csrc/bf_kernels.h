@@ -192,6 +192,25 @@ struct FusedArgs {
     unsigned long long* tl;          // debug timeline (`make tl` build only)
 };
 hipError_t launch_fused_pass(const FusedArgs& a, int half_scale, int rows_per_tile, hipStream_t s);
+// The persistent form of the one-kernel iteration (k_fused_loop, bf_loop.hip): up to max_passes iterations per launch, the
+// work-groups resident, the moment sums exchanged through tagged records in memory instead of a launch boundary.
+struct FusedLoopArgs {
+    EvSets sets;
+    const uint32_t* ftab;            // FusedTab per tile
+    DevState* st;                    // read at entry; written (with st_other and snap) by work-group 0 at exit
+    DevState* st_other;
+    DevState* snap;                  // pinned host copy: (done, it) after every pass, the whole state at exit
+    unsigned long long* rec;         // [2][tiles * NSUB][16][2]: per-sub-tile records (payload, tag), by pass parity
+    unsigned long long* red;         // [2][16][16][2]: the reducers' records
+    float2* scratch[3];              // private product arrays of the strips' readers (lists longer than a pass)
+    bf_trace_rec* trace;
+    int nbr, nbc, R, C;
+    int max_passes;
+    int first_warp;                  // 0: the first pass of the run scatters the stored products as they are
+};
+hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_per_tile, int n_cus, hipStream_t s);
+// can `ntiles` work-groups of that kernel be resident at once on this device (n_cus compute units)?
+bool fused_loop_resident(int half_scale, int rows_per_tile, int n_cus, int ntiles);
 void launch_run_init(DevState* st, const DevState& v, uint32_t* ovf, uint32_t prev_dirty, MomentAcc* acc, bool init_loop, hipStream_t s);
 
 // bf_local.hip -- contrast-score evaluation of OptimizerLocal (optimizer_sampler.cpp:120-153)

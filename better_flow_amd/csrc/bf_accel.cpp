@@ -5,6 +5,7 @@
 // is reusable across slices and never allocates per slice.  There is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cmath>
@@ -73,7 +74,8 @@ struct bf_ctx {
     uint32_t* d_ftab = nullptr;      // FusedTab per tile
     int ftab_alloc = 0;
     // persistent form of that loop (k_fused_loop, bf_loop.hip): a context ALONE on the GPU keeps the work-groups resident
-    int opt_persist = 1;             // 0 never, 1 when the one-kernel loop is taken and the context is not co-scheduled
+    bool counted = false;            // in g_live_ctx
+    int opt_persist = 1;             // 0 never, 1 for warm-started runs of the one-kernel loop on a context that is not co-scheduled, 2 cold runs too
     unsigned long long *d_xrec = nullptr, *d_xred = nullptr;   // exchange records of the sub-tiles / of the reducers (two parities each)
     int xrec_alloc = 0;              // records per parity d_xrec holds
     float2* d_xscratch[3] = {nullptr, nullptr, nullptr};       // private product arrays of the strips' readers
@@ -191,6 +193,11 @@ struct bf_ctx {
 };
 
 namespace {
+
+// Contexts alive per device in this process.  The persistent loop kernel needs every one of its work-groups resident at
+// once; two such kernels from two contexts could each hold part of the CUs and wait for the rest, so a context takes it
+// only while it is the one context on its device (other contexts: "co_schedule" or not, they would share the CUs).
+std::atomic<int> g_live_ctx[64];
 
 int fail(bf_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -753,12 +760,15 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
             }
         }
     }
+    g_live_ctx[device & 63].fetch_add(1);
+    c->counted = true;
     *out = c;
     return BF_OK;
 }
 
 void bf_destroy(bf_ctx* c) {
     if (!c) return;
+    if (c->counted) g_live_ctx[c->device & 63].fetch_sub(1);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tl) {   // debug timeline dump: launch group slot ticks(100 MHz)
@@ -815,6 +825,12 @@ int bf_get_stat(bf_ctx* c, const char* key, int64_t* value) {
     }
     if (!strcmp(key, "one_kernel")) {
         *value = (c->fused_ok && (!c->opt_co_schedule || c->fused_shared)) ? 1 : 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "persistent")) {   // would bf_run, called now, take the persistent loop kernel?
+        *value = (c->fused_ok && !c->opt_co_schedule && (c->opt_persist == 2 || (c->opt_persist == 1 && c->pending_warp)) &&
+                  g_live_ctx[c->device & 63].load() == 1 &&
+                  fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc)) ? 1 : 0;
         return BF_OK;
     }
     return fail(c, BF_ERR_ARG, "unknown statistic '%s'", key);
@@ -909,7 +925,7 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         return BF_OK;
     }
     if (!strcmp(key, "persist")) {
-        if (value < 0 || value > 1) return fail(c, BF_ERR_ARG, "persist must be 0 or 1");
+        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "persist must be 0, 1 (auto) or 2");
         c->opt_persist = (int)value;
         return BF_OK;
     }
@@ -1661,6 +1677,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // two-kernel tile-binned loop when the slice is dense enough for it, else global atomics.
     const bool fused = c->fused_ok && (!c->opt_co_schedule || c->fused_shared);
     const bool binned = c->use_binned || fused;
+    // The persistent form of the one-kernel loop (bf_loop.hip): the work-groups stay resident over many iterations and
+    // exchange their moment sums through memory -- for a context that has the GPU to itself (two such kernels from two
+    // contexts could each hold half of the CUs and wait for the other half), when all tiles can be resident at once.
+    // A cold run re-bins a dozen times in its first iterations, and every re-bin ends a launch of the persistent kernel with
+    // a host round trip (measured on 50 000 events, 240x180: 25 us per iteration against 17); a warm-started slice of a stream
+    // -- the reference's own mode, ~115 iterations and one or two re-bins -- is where it pays (11.1 against 12.2 us per
+    // iteration all in): "auto" takes it for warm starts.
+    const bool persist = fused && !c->opt_co_schedule && (c->opt_persist == 2 || (c->opt_persist == 1 && c->pending_warp)) &&
+                         g_live_ctx[c->device & 63].load() == 1 &&
+                         fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc);   // (else: one launch per iteration)
     DevState& h = c->hst;
     // Tile-binned mode sorts the events by the tile of their CURRENT target, so a warm-start
     // warp (bf_set_model) is applied before the sort rather than inside the first iteration.
@@ -1683,7 +1709,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     h.hot.rebins = 0; h.ovf_total = 0;
     h.hot.cs = c->cs; h.hot.flip = 0;
     h.hot.pp = 0; h.hot.redo = 0; h.hot.pend = 0; h.last_j = -1;
-    if (binned) h.drift_limit = c->opt_bin_predict ? 0.6 * (double)(fused ? c->fgrid.D : c->grid.D) : 1e300;
+    // (the persistent loop re-bins AT the request -- it returns for it --, the other loops one or two batches of launches
+    // after it: the same effective threshold)
+    if (binned) h.drift_limit = c->opt_bin_predict ? (persist ? 0.85 : 0.6) * (double)(fused ? c->fgrid.D : c->grid.D) : 1e300;
     if (!first_warp) h.hot.wp = identity_warp();
     h.ref_wp = h.hot.wp;
     const bool perm_at_start = c->has_perm;
@@ -1749,8 +1777,6 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // The persistent form of the one-kernel loop (bf_loop.hip): the work-groups stay resident over many iterations and
     // exchange their moment sums through memory -- for a context that has the GPU to itself (two such kernels from two
     // contexts could each hold half of the CUs and wait for the other half).
-    const bool persist = fused && !c->opt_co_schedule && c->opt_persist != 0 &&
-                         fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc);   // (else: one launch per iteration)
     if (persist) {
         const int nsub = c->fgrid.TSR / 16, nrec = c->fgrid.nbr * c->fgrid.nbc * nsub;
         if (nrec > c->xrec_alloc) {
@@ -1805,6 +1831,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         la.R = c->win.scale_img_x; la.C = c->win.scale_img_y;
         la.max_passes = 4096;
         la.first_warp = first_warp ? 1 : 0;
+        la.tl = c->d_tl;
         {
             ProfScope ps(c, 0, c->n);
             HIP_TRY(c, launch_fused_loop(la, c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->stream));
@@ -1831,6 +1858,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         inf.polls++;
         const DevState& ws = c->h_state[batch & 1];
         launched_iters = ws.last_j + 1;
+        if (host_timing && batch < 40)
+            fprintf(stderr, "persist round %d: it %d done %d need_rebin %d redo %d last_j %d rebins %d rc %d launches %d ovf_total %u\n", batch, ws.hot.it,
+                    ws.hot.done, ws.hot.need_rebin, ws.hot.redo, ws.last_j, ws.hot.rebins, ws.rc, ws.hot.spare_, ws.ovf_total);
         if (ws.hot.done) {
             fin = ws;
             final_done = true;

@@ -345,6 +345,42 @@ __device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
     *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 
+// The same polynomials with their fourteen coefficients read from a table (LDS, filled by sincos_table_fill): a kernel that
+// LOOPS over iterations would otherwise keep all of them in registers for the whole loop (loop-invariant constants are
+// hoisted), 28 VGPRs it needs for its events.  Same operations in the same order: the same bits.
+__device__ __forceinline__ void sincos_table_fill(double* tab) {
+    tab[0] = -1.0 / 1307674368000.0; tab[1] = 1.0 / 6227020800.0; tab[2] = -1.0 / 39916800.0; tab[3] = 1.0 / 362880.0;
+    tab[4] = -1.0 / 5040.0; tab[5] = 1.0 / 120.0; tab[6] = -1.0 / 6.0;
+    tab[7] = 1.0 / 20922789888000.0; tab[8] = -1.0 / 87178291200.0; tab[9] = 1.0 / 479001600.0; tab[10] = -1.0 / 3628800.0;
+    tab[11] = 1.0 / 40320.0; tab[12] = -1.0 / 720.0; tab[13] = 1.0 / 24.0;
+}
+__device__ __forceinline__ void sincos_small_tab(double x, const double* tab, double* sn, double* cs) {
+    if (!(fabs(x) <= 0.25)) {
+        sincos_large(x, sn, cs);
+        return;
+    }
+    const double z = x * x;
+    double c_[14];   // (all fourteen reads in flight together)
+#pragma unroll
+    for (int i = 0; i < 14; ++i) c_[i] = tab[i];
+    double ps = c_[0];
+    ps = fma(ps, z, c_[1]);
+    ps = fma(ps, z, c_[2]);
+    ps = fma(ps, z, c_[3]);
+    ps = fma(ps, z, c_[4]);
+    ps = fma(ps, z, c_[5]);
+    ps = fma(ps, z, c_[6]);
+    *sn = fma(x * z, ps, x);
+    double pc = c_[7];
+    pc = fma(pc, z, c_[8]);
+    pc = fma(pc, z, c_[9]);
+    pc = fma(pc, z, c_[10]);
+    pc = fma(pc, z, c_[11]);
+    pc = fma(pc, z, c_[12]);
+    pc = fma(pc, z, c_[13]);
+    *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+
 // A uniform double out of one lane of a wave (two v_readlane_b32).
 __device__ __forceinline__ double lane_f64(double v, int lane) {
     const long long b = __double_as_longlong(v);
@@ -379,7 +415,8 @@ __device__ __forceinline__ long long lane_i64(unsigned long long v, int lane) {
 //     8, 10, 12, 14, 15  : 1 / x_div, 1 / y_div, 1 / rot_div, 1 / div_div, 1 / scale
 // rot and div are formed from the quotients (object_model.cpp:26-38 with the division distributed over the terms;
 // the dividers enter as reciprocals: <= 1 ulp from the divided form, far inside the moments' 1e-9 bar).
-__device__ __forceinline__ void model_update_wave(DevState* st, unsigned long long word, int lane, int mode) {
+__device__ __forceinline__ void model_update_wave(DevState* st, unsigned long long word, int lane, int mode,
+                                                  const double* sc_tab = nullptr) {
     const int f = lane & 15;
     const long long n_i = lane_i64(word, 0), sci = lane_i64(word, 1), scj = lane_i64(word, 2);
     const int R = st->hot.R, C = st->hot.C;
@@ -436,7 +473,8 @@ __device__ __forceinline__ void model_update_wave(DevState* st, unsigned long lo
     wp.dnx = -m.total_dx; wp.dny = -m.total_dy;
     wp.cx = cxs; wp.cy = cys;
     wp.div = m.total_div;
-    sincos_small(-m.total_rot, &wp.s, &wp.c);
+    if (sc_tab) sincos_small_tab(-m.total_rot, sc_tab, &wp.s, &wp.c);
+    else sincos_small(-m.total_rot, &wp.s, &wp.c);
     m.cx = cxs;
     m.cy = cys;
 

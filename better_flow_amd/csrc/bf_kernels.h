@@ -207,6 +207,7 @@ struct FusedLoopArgs {
     int nbr, nbc, R, C;
     int max_passes;
     int first_warp;                  // 0: the first pass of the run scatters the stored products as they are
+    unsigned long long* tl;          // debug timeline (`make tl` build only)
 };
 hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_per_tile, int n_cus, hipStream_t s);
 // can `ntiles` work-groups of that kernel be resident at once on this device (n_cus compute units)?

@@ -80,8 +80,8 @@ __device__ __forceinline__ bool xchg_poll_sum(const unsigned long long* base, co
             ok = ok && (idx[k] < 0 || tg == tag);
         }
         if (__ballot(!ok) == 0ull) break;
+        __builtin_amdgcn_s_sleep(2);   // (~50 ns: a poller must not crowd the memory side the records travel through)
         if (tries >= 32u) {
-            __builtin_amdgcn_s_sleep(2);
             if (tries == 32u) t0 = wall_clock64();
             else if ((tries & 255u) == 0u && wall_clock64() - t0 > 20000000ull) return false;   // 0.2 s of the 100 MHz clock
         }
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(&s_time[NSUB][0]);                      // [AR * AC]   (bin_ok == 0 only)
     __shared__ unsigned long long s_rpart[NSUB][kSumFields * 4];
     __shared__ DevState s_state;
-    __shared__ int s_lost, s_exit, s_abort;
+    __shared__ int s_lost, s_exit, s_abort, s_rest;
+    __shared__ double s_sctab[14];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int ntiles = a.nbr * a.nbc, nrec = ntiles * NSUB;
     const int nred = ntiles < kLoopReducers ? ntiles : kLoopReducers;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
 #pragma unroll
     for (int r = 1; r < kFusedRanges; ++r) off_step[r] = ft.off[r] - ft.off[r - 1];
     if (tid < kStateWords) reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st)[tid];
-    if (tid == 0) { s_lost = 0; s_exit = 0; s_abort = 0; }
+    if (tid == 0) { s_lost = 0; s_exit = 0; s_abort = 0; s_rest = 0; sincos_table_fill(s_sctab); }
     __syncthreads();
     auto store_state = [&]() {   // work-group 0, after a barrier: both state buffers and the host's snapshot
         if (b == 0 && tid < kStateWords) {
@@ -141,6 +142,11 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
         }
     }
     const int live_set = lds_sreg(&s_state.hot.cs) ^ lds_sreg(&s_state.hot.flip);
+    __syncthreads();
+    // A re-bin moved the events to the other set (hot.flip): commit it now, as every pass of k_fused_pass does at its head.
+    // (model_update_rest commits it too, but a pass that lost events has no update -- and the NEXT re-bin's scatter kernel
+    // reads set `cs`: left uncommitted, it would re-sort the stale set with the fresh one's bin ids.)
+    if (tid == 0 && s_state.hot.flip) { s_state.hot.cs ^= 1; s_state.hot.flip = 0; }
     const EvSetPtrs ev = a.sets.s[live_set];
     const uint32_t* __restrict__ xy = ev.xy;
     const int32_t* __restrict__ t = ev.t;
@@ -193,25 +199,31 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     int j = s_state.last_j + 1;
     bool first_of_run = s_state.last_j < 0;
     int passes = 0;
+    {   // the LDS tile, zeroed once here and then under every pass's exchange
+        ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
+        for (int i = tid; i < AR * AC / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
+        for (int i = tid; i < AR * AC; i += THREADS) s_cnt[i] = 0u;
+        __syncthreads();
+    }
     for (;;) {
         // (opaque copies of the thread's indices: everything derived from them inside a pass would otherwise be hoisted out
         // of the pass loop as loop-invariant -- ~100 registers of addresses and pixel coordinates, twice the budget of two
         // work-groups per CU)
         int tid_ = tid, lt_ = lt;
         asm volatile("" : "+v"(tid_), "+v"(lt_));
+        tl_stamp(a.tl, j, 0);
         // ---- scatter ----
         const ScatterHot hs = scatter_hot(&s_state);
         const bool redo = lds_sreg(&s_state.hot.redo) != 0;
         const bool do_warp = (first_of_run ? a.first_warp != 0 : true) && !redo;
         const int hsc = hs.scale / 2;
         const bool packed = hs.bin_ok != 0;
-        {
-            ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
-            for (int i = tid_; i < AR * AC / 2; i += THREADS) z[i] = make_ulonglong2(0ull, 0ull);
-            if (!packed)
-                for (int i = tid_; i < AR * AC; i += THREADS) s_cnt[i] = 0u;
+        // (the LDS tile is zero: cleared before the loop, and by the idle waves under the previous pass's exchange)
+        if (tid_ == THREADS - 1 && s_rest) {   // bookkeeping of the last update, off the critical path: a thread of the last wave
+            model_update_rest(&s_state, b == 0 ? a.trace : nullptr, 0, 0u);
+            s_rest = 0;
         }
-        __syncthreads();
+        tl_stamp(a.tl, j, 1);
         bool lost_here = false;
         for (uint32_t base = 0; base < M; base += THREADS * U) {
             if (!single) load_pass(base, false);
@@ -263,7 +275,9 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             }
         }
         if (lost_here) s_lost = 1;
+        tl_stamp(a.tl, j, 2);
         __syncthreads();
+        tl_stamp(a.tl, j, 3);
         // ---- the stencil of k_stencil_binned, one 16 x 64 sub-tile per 256-thread sub-group, on the LDS tile ----
         const int bt = hs.bin_tbits;
         const unsigned long long bm = (1ull << bt) - 1ull;
@@ -289,7 +303,9 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             }
             s_time[g][idx] = tv;
         }
+        tl_stamp(a.tl, j, 4);
         __syncthreads();
+        tl_stamp(a.tl, j, 5);
         Sums sm;
         sums_zero(sm);
 #pragma unroll
@@ -303,7 +319,9 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             }
         }
         constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
+        tl_stamp(a.tl, j, 6);
         block_reduce_publish<256, kPack>(sm, s_rpart[g], lt_, r0 - hR, c0 - hC);   // (work-group barrier inside)
+        tl_stamp(a.tl, j, 7);
         // ---- publish: this sub-tile's record of pass j ----
         const unsigned long long tag = run_hi | (unsigned long long)(unsigned int)(j + 1);
         unsigned long long* const rec = a.rec + (size_t)(j & 1) * (size_t)nrec * kRecWords;
@@ -315,6 +333,13 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
                 if (lt_ == 15) w = (g == 0 && s_lost) ? 1ull : 0ull;                  // lane 15: events outran their bins
                 xchg_store(rec + (size_t)(b * NSUB + g) * kRecWords + 2 * lt_, w, tag);
             }
+        }
+        tl_stamp(a.tl, j, 8);
+        if (tid_ >= 128) {   // waves that take no part in the exchange clear the tile for the next pass meanwhile
+            ulonglong2* z = reinterpret_cast<ulonglong2*>(s_acc);
+            for (int i = tid_ - 128; i < AR * AC / 2; i += THREADS - 128) z[i] = make_ulonglong2(0ull, 0ull);
+            if (!packed)
+                for (int i = tid_ - 128; i < AR * AC; i += THREADS - 128) s_cnt[i] = 0u;
         }
         // ---- reduce: wave 1 of the first work-groups adds up its share of the records ----
         if (tid_ >= 64 && tid_ < 128 && b < nred) {
@@ -350,6 +375,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             }
             unsigned long long word = 0;
             const bool good = xchg_poll_sum<4>(red, idx, tag, word);
+            tl_stamp(a.tl, j, 9);
             word += __shfl_xor(word, 16, 64);
             word += __shfl_xor(word, 32, 64);
             const bool lost = lane_i64(word, 15) != 0;
@@ -361,15 +387,20 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
                     s_state.last_j = j;
                 }
             } else {
-                model_update_wave(&s_state, word, tid_, 1);
+                __builtin_amdgcn_s_setprio(3);
+                model_update_wave(&s_state, word, tid_, 1, s_sctab);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_wave_barrier();
                 if (tid_ == 0) {
-                    model_update_rest(&s_state, b == 0 ? a.trace : nullptr, 0, 0u);
+                    // (model_update_rest -- the drift bound that asks for a re-bin, the commit of a re-bin's flip, the trace
+                    // record -- runs under the next pass's scatter: a re-bin request is acted on one pass later)
+                    s_rest = 1;
                     s_state.hot.redo = 0; s_state.hot.pend = 0;
                     s_state.last_j = j;
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            tl_stamp(a.tl, j, 10);
             if (tid_ == 0) {
                 const bool out = s_abort || s_state.hot.done || s_state.hot.need_rebin || passes + 1 >= a.max_passes;
                 s_exit = out ? 1 : 0;
@@ -382,6 +413,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             }
         }
         __syncthreads();
+        tl_stamp(a.tl, j, 11);
         ++passes;
         ++j;
         first_of_run = false;
@@ -395,6 +427,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             if (v < own) p_cur[vi[k]] = vp[k];
         }
     }
+    if (tid == 0 && s_rest) model_update_rest(&s_state, b == 0 ? a.trace : nullptr, 0, 0u);
     if (b == 0 && tid == 0) {
         s_state.hot.spare_ += 1;
         if (s_abort) { s_state.rc = BF_ERR_HIP; s_state.hot.done = s_state.run_tag ? s_state.run_tag : 1; }

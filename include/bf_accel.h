@@ -162,6 +162,14 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "fused_margin" scaled pixels an event may move between two re-bins of that loop (default 8; at most half a tile
  *                  minus scale / 2 + 1).    "fused_rows"  rows of its image tiles: 0 (default: 32, or 64 when the image
  *                  has too many tiles for the counting sort), 32, 64.
+ *   "persist"      the persistent form of that loop (k_fused_loop, bf_loop.hip): the work-groups stay resident, keep their
+ *                  events in registers and run iteration after iteration in ONE launch, exchanging the moment sums through
+ *                  tagged records in memory instead of a launch boundary; the launch ends when the loop is over or a re-bin
+ *                  is due.  0 never; 1 (default) for warm-started runs (bf_set_model: a stream's chain, where a slice is
+ *                  ~100 iterations and one or two re-bins) on a context that is not "co_schedule"d, is the only context of
+ *                  this process on its device (two resident kernels could wait for each other's CUs) and whose tiles can
+ *                  all be resident at once; 2 for cold runs too (they re-bin a dozen times, each a host round trip: slower).
+ *                  Bit-identical to the other loops.
  *   BF_ACCEL_OPTIONS (environment, read by bf_create): "key=value,key=value" applied to every context of the process.
  *   "bin_tile"     tile WIDTH of the binned scatter (0 = default: chosen per slice with the height; or 16, 32,
  *                  64, 128).
@@ -216,6 +224,7 @@ int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
  *   "scatter_format"  what the last bf_set_cloud chose for the tile-binned loop: 0 dense slabs, 1 merged lists, 2 event
  *                     lists, 3 own pixels + margin plane ("bin_split"); -1 when the slice does not take that loop.
  *   "one_kernel"      1 when bf_run would take the one-kernel iteration for the slice staged now, else 0.
+ *   "persistent"      1 when bf_run, called now, would run it as the persistent kernel ("persist"), else 0.
  * BF_ERR_ARG for an unknown key. */
 int bf_get_stat(bf_ctx *ctx, const char *key, int64_t *value);
 

@@ -47,7 +47,7 @@ def main():
     extra = {k: int(v) for k, v in extra.items()}
     sl = synth.make_slice(n, H, W, 0.03, seed=5)
     ref, iref, tref = run(sl, H, W, s, dict({"binned": 2, "fused": 2, "persist": 0}, **extra), reps=3)
-    got, igot, tgot = run(sl, H, W, s, dict({"binned": 2, "fused": 2, "persist": 1}, **extra), reps=3)
+    got, igot, tgot = run(sl, H, W, s, dict({"binned": 2, "fused": 2, "persist": 2}, **extra), reps=3)
     print("%d events %dx%d s%d: launch per iteration: %d iterations, %d launches, %d re-bins, %.2f us / iteration; "
           "persistent: %d iterations, %d launches, %d polls, %d re-bins, %.2f us / iteration" %
           (len(sl["t"]), W, H, s, iref.iterations, iref.launches, iref.rebins, 1e6 * tref / max(1, iref.iterations),

@@ -4,8 +4,10 @@ work-group, events of a tile's edge strips read by the neighbouring tiles' work-
 It must return the bits of the two-kernel tile-binned loop (same integer accumulators, same per-sub-tile f64 partials) --
 model, iteration count, every trace record, per-event flow, and the warm start that follows -- with the default margin,
 with margins so small that events outrun their bins (the `lost` flag, a re-bin, the pass repeated before its update),
-with 64-row tiles, with the unpacked LDS planes, without the predictive re-bin.  And `auto` must take it exactly for the
-slices it was measured to be faster on (bf_set_cloud).
+with 64-row tiles, with the unpacked LDS planes, without the predictive re-bin -- and so must its persistent form
+(k_fused_loop, bf_loop.hip: many iterations per launch, sums exchanged through tagged records), forced for the cold run
+as well ("persist" = 2; by default only the warm start takes it).  And `auto` must take the one-kernel loop exactly for
+the slices it was measured to be faster on (bf_set_cloud).
 """
 import numpy as np
 import pytest
@@ -21,6 +23,7 @@ def run(accel_mod, sl, H, W, s, opts, max_iter=-1):
         a.set_option(k, v)
     a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
     a.set_cloud(s, H, W)
+    persistent = a.get_stat("persistent")
     o = a.default_opts()
     o.res_x, o.res_y, o.want_uv, o.trace_cap, o.max_iter = H, W, 1, 4096, max_iter
     rc, m, info = a.run(o)
@@ -32,10 +35,11 @@ def run(accel_mod, sl, H, W, s, opts, max_iter=-1):
     u2, v2 = a.compute_uv()
     a.close()
     return dict(rc=(rc, rc2), it=(info.iterations, info2.iterations), model=(m.as_dict(), m2.as_dict()), trace=(trace, trace2),
-                flow=(u.tobytes(), v.tobytes(), u2.tobytes(), v2.tobytes()), rebins=info.rebins, launches=info.launches)
+                flow=(u.tobytes(), v.tobytes(), u2.tobytes(), v2.tobytes()), rebins=info.rebins, launches=info.launches, persistent=persistent)
 
 
-VARIANTS = (("default margin", {}), ("margin 2", {"fused_margin": 2}), ("margin 1", {"fused_margin": 1}),
+VARIANTS = (("default margin", {}), ("persistent kernel", {"persist": 2}), ("persistent kernel, margin 2", {"persist": 2, "fused_margin": 2}),
+            ("persistent kernel, 64-row tiles, unpacked planes", {"persist": 2, "fused_rows": 64, "bin_pack_limit": 20}), ("margin 2", {"fused_margin": 2}), ("margin 1", {"fused_margin": 1}),
             ("64-row tiles", {"fused_rows": 64}), ("unpacked planes", {"bin_pack_limit": 20}),
             ("no predictive re-bin, margin 3", {"bin_predict": 0, "fused_margin": 3}))
 
@@ -49,9 +53,13 @@ def test_same_bits_as_the_two_kernel_loop(accel_mod, case):
     ref = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 0}, max_iter)
     assert ref["rc"][0] == 0 and ref["it"][0] > 20
     for name, o in VARIANTS:
-        got = run(accel_mod, sl, H, W, s, dict({"binned": 2, "fused": 2}, **o), max_iter)
+        got = run(accel_mod, sl, H, W, s, dict({"binned": 2, "fused": 2, "persist": 0}, **o), max_iter)
         if name == "default margin":   # (tight margins spend launches waiting for re-bins)
             assert got["launches"] < 0.75 * ref["launches"], "the one-kernel loop was not the one that ran"
+        if name == "persistent kernel" and (s * H + s + 31) // 32 * ((s * W + s + 63) // 64) <= 256:
+            assert got["persistent"] == 1   # (all tiles resident at once; much larger images fall back to one launch per iteration)
+        if name == "persistent kernel" and got["persistent"]:   # (five launches per round -- re-bin trio, loop kernel, gated final warp --, a round per re-bin)
+            assert got["launches"] <= 5 * (got["rebins"] + 2) + 8, "the persistent kernel was not the one that ran"
         for key in ("rc", "it", "model", "trace", "flow"):
             assert got[key] == ref[key], (name, key)
         if name == "margin 1":

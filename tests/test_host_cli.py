@@ -650,7 +650,9 @@ def test_cli_reference_ring_same_bytes_on_every_device_loop(tmp_path):
     ref = go("two_kernel", "fused=0,binned=2")
     assert len(ref[0]) > 10_000_000 and len(ref[1]) > 80
     assert go("auto", "") == ref
-    assert go("fused", "fused=2") == ref
+    assert go("fused", "fused=2,persist=0") == ref
+    assert go("persistent", "fused=2,persist=2") == ref          # the persistent kernel for every slice, cold ones too
+    assert go("persistent_auto", "fused=2") == ref               # ... and as the default takes it: warm-started slices only
     assert go("fused_tight", "fused=2,fused_margin=1") == ref
     assert go("atomics", "fused=0,binned=0") == ref
     assert go("fused_sync", "fused=2", ["--sync"]) == ref

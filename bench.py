@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--front-end-slices", type=int, default=20, help="rolling slices in the front-end measurement's event file")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="bf_set_option knob for every context (experiments), e.g. --opt bin_threads=512")
-    ap.add_argument("--cpu-iters", type=int, default=60)
+    ap.add_argument("--cpu-iters", type=int, default=120, help="iteration_steps of the CPU baseline's bounded sample (~0.2 s each)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="cap on the host cores of the slice-parallel CPU figure")
     ap.add_argument("--farm-slices", type=int, default=512,
                     help="--config 5: independent slices (seeds 0 .. n-1) farmed over the ranks, slice i -> rank i %% N")
@@ -501,12 +501,20 @@ def main():
         # scripts/collect_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  null if not collected
         # or not for this workload.
-        traffic = None
+        # (keyed by geometry AND kernel variant: the line names the 1024-thread lean kernel when several contexts share the
+        # GPU, the head-update kernel for one context -- the counters must be that variant's)
+        traffic = traffic_kernel = stencil_traffic = None
         tj = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tj) and args.events == 1000000:
-            t_ = json.load(open(tj)).get("%dx%dx%d" % (W, H, s))
+            tjd = json.load(open(tj))
+            key = "%dx%dx%d" % (W, H, s)
+            t_ = tjd.get(key + ("_lean1024" if B > 1 else "_head1024")) or tjd.get(key)
             if t_:
                 traffic = (2.0 * t_["fetch_kb"] + t_["write_kb"]) * 1024.0
+                traffic_kernel = t_.get("kernel")
+            t3_ = tjd.get(key + ("_stencil_tail" if B > 1 else "_stencil_head"))
+            if t3_:
+                stencil_traffic = (2.0 * t3_["fetch_kb"] + t3_["write_kb"]) * 1024.0
         # The same kernel at BASELINE's other two geometries (configs 3 and 5), one context alone as it runs there by default
         # (a stream's chain / a farm lane with the GPU to itself: update at the scatter head), first 120 iterations of a cold
         # 1M-event slice each -- a second or so, not part of the timed region.
@@ -548,6 +556,7 @@ def main():
             "other_geometries": other_geo,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_kernel": traffic_kernel,
             "avg_launch_us": k1_s * 1e6, "launches": int(live), "launches_incl_early_exit": int(p.warp_scatter_launches),
             "algorithmic_bytes_per_launch": K1_BYTES_PER_EVENT_ITER * ev_per_launch,
             "measured_copy_ceiling_gbps": copy_gbps,
@@ -561,6 +570,7 @@ def main():
                 "algorithmic_bytes_per_launch": 24.0 * img_px,
                 "achieved": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9,
                 "frac": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": stencil_traffic,
                 "note": "bound by dependent latency and instruction issue (its waves wait ~55 % of their cycles), not by bandwidth: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
             },
             "per_kernel_us": {
@@ -595,6 +605,11 @@ def main():
                       (oloop.itercount, len(sl["t"]), dtc, 1e3 * per_iter, full_iters),
             "ms_per_iteration": 1e3 * per_iter,
         }
+        # the same oracle run ONCE to the loop's own termination (scripts/cpu_to_termination.py, in the build container:
+        # minutes of CPU that the default bench run does not spend), quoted beside the extrapolated sample
+        tt = os.path.join(ROOT, "profiles", "cpu_to_termination.json")
+        if os.path.exists(tt) and args.events == 1000000 and (H, W, s) == (260, 346, 3):
+            cpu_baseline["to_termination"] = json.load(open(tt))
         # the fair multi-core figure -- one slice per host core, all cores busy at once (the
         # reference's O(N) loops are serial, so slice-parallel is the only way it uses a multi-core host)
         ncore = host_cores()   # (a container's CPU quota, not the host's core count, is what this job may use)

@@ -1586,11 +1586,7 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
 #define BF_K3(HS_)                                                                                                  \
-    if (a.threads >= 512) {                                                                                         \
-        if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, 512>, grid, dim3(512), 0, s, a);                  \
-        else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, 512>, grid, dim3(512), 0, s, a);                  \
-        else launch_timed(k_stencil_binned<HS_, 0, 512>, grid, dim3(512), 0, s, a);                                 \
-    } else if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);     \
+    if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);     \
     else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, a);            \
     else launch_timed(k_stencil_binned<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, a)
     switch (a.scale / 2) {

@@ -1,4 +1,4 @@
-// bf_kernels.h -- launch interface between bf_accel.cpp (C-ABI, host logic) and
+// bf_kernels.h -- launch interface between the C-ABI files (bf_context / bf_upload / bf_operators / bf_run / bf_extras .cpp) and
 // bf_kernels.hip (gfx950 kernels).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -76,12 +76,11 @@ struct StencilArgs {
     const uint32_t* chdr;
     int compact;
     const unsigned long long* m_cur;   // interior + margin format (compact == 3): the margin plane of buffer `cur`
-    int threads;                       // work-group size of the stencil kernels (256 or 512; the loop's choice per slice)
     BinGrid g;
     int cur;
 };
 
-// Profiling hook: when armed (by bf_accel.cpp's ProfScope), the next launch of a loop kernel goes through
+// Profiling hook: when armed (by ProfScope, bf_ctx.h), the next launch of a loop kernel goes through
 // hipExtLaunchKernelGGL with these events, which then carry the kernel's own begin / end timestamps (what
 // rocprofv3 reports) instead of bracketing the launch with two extra barrier packets (~1.5 us more).
 struct LaunchTimer {

@@ -443,12 +443,6 @@ void launch_stencil(const StencilArgs& a, int src, hipStream_t s) {
     stencil_grid(a.R, a.C, &gx, &gy);
     dim3 grid(gx, gy);
     if (src == 3) { launch_stencil_binned(a, grid, s); return; }
-    if (a.threads >= 512) {
-        if (src == 0) hipLaunchKernelGGL((k_stencil<0, 512>), grid, dim3(512), 0, s, a);
-        else if (src == 1) hipLaunchKernelGGL((k_stencil<1, 512>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((k_stencil<2, 512>), grid, dim3(512), 0, s, a);
-        return;
-    }
     if (src == 0) hipLaunchKernelGGL((k_stencil<0, kThreads>), grid, dim3(kThreads), 0, s, a);
     else if (src == 1) hipLaunchKernelGGL((k_stencil<1, kThreads>), grid, dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((k_stencil<2, kThreads>), grid, dim3(kThreads), 0, s, a);

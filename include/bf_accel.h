@@ -202,9 +202,6 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "bin_threads"  work-group size of the binned warp+scatter kernel: 0 (default: 1024 where a bin holds thousands
  *                  of events, 512 where it holds a few hundred), 256, 512, 1024.
  *   "bin_ev"       events a scatter thread keeps in flight: 0 (default: from the events per bin), 1, 2, 4, 8.
- *   "stencil_threads"  work-group size of the stencil kernels: 0 / 256 (default) or 512 (a shorter chain per tile: 1.5 %
- *                  per iteration for one context alone on a small image, 12 % less throughput with several contexts; its
- *                  f64 partial sums are ordered differently, so results differ in the last bits from the default's).
  *   "bin_compact"  what the scatter kernel hands to the stencil kernel: 0 dense tiles (the bin's events merged in an LDS
  *                  tile, one accumulator per tile pixel written), 2 event lists (one entry per event: tile-local pixel
  *                  index + packed accumulator, sorted by tile row; no LDS tile), 3 merged lists (the events merged in the

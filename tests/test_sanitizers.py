@@ -81,4 +81,4 @@ def test_stream_engine_and_slice_farm_under_thread_sanitizer(tmp_path):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
     r = subprocess.run([exe, txt], cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
     assert r.returncode == 0 and b"ThreadSanitizer" not in r.stderr, r.stderr.decode()[-4000:]
-    assert r.stdout.decode().count("\nOK ") + r.stdout.decode().startswith("OK ") == 6
+    assert r.stdout.decode().count("\nOK ") + r.stdout.decode().startswith("OK ") == 8

@@ -547,6 +547,44 @@ def main():
                         "iterations": int(i2.iterations)})
                 except Exception as e:   # (a measurement beside the contract's: never the reason a bench line is missing)
                     other_geo.append({"geometry": "%dx%d" % (W2, H2), "error": str(e)[:200]})
+        # The two loop kernels with the CHIP FULL of their own work-groups: one context solving eight config-2 slices side by
+        # side (8 x the sensor area, 8 x 1M events at the same density: 2048 bins of 48 x 64 pixels, 6016 stencil tiles) --
+        # what a kernel achieves when it is not bound by one slice's latency chain (a single config-2 slice has one
+        # work-group of the scatter kernel per CU).  Per-launch times are the kernels' own; fractions on algorithmic bytes.
+        chip_full = None
+        if args.events == 1000000 and (H, W, s) == (260, 346, 3) and not args.opt:
+            try:
+                H8, W8 = 2 * H, 4 * W
+                sl8 = synth.make_slice(8000000, H8, W8, 0.030, seed=1)
+                a8 = accel.Accel(max_events=len(sl8["t"]), max_rows=s * H8 + s, max_cols=s * W8 + s)
+                for k8, v8 in (("binned", 2), ("fused", 0), ("bin_compact", 0), ("bin_split", 0), ("bin_tile", 64), ("bin_tile_rows", 48),
+                               ("co_schedule", 1), ("bin_threads", 512)):
+                    a8.set_option(k8, v8)
+                o8 = a8.default_opts()
+                o8.res_x, o8.res_y, o8.max_iter = H8, W8, 80
+                for rep in range(2):
+                    a8.upload_events(sl8["fr_x"], sl8["fr_y"], sl8["t"])
+                    w8 = a8.set_cloud(s, H8, W8)
+                    if rep == 1:
+                        a8.profile_enable(1); a8.profile_reset()
+                    _, _, i8 = a8.run(o8)
+                p8 = a8.profile_get()
+                a8.close()
+                n8, it8 = len(sl8["t"]), max(1, i8.iterations)
+                px8 = float(w8.scale_img_x) * float(w8.scale_img_y)
+                k1_8, k3_8 = p8.warp_scatter_ms * 1e-3 / it8, p8.stencil_ms * 1e-3 / it8
+                chip_full = {
+                    "what": "one context, %d events on a %dx%d sensor (eight config-2 slices side by side), dense slabs, 48x64 bins x 512 threads, "
+                            "update in the stencil tail; first %d iterations of a cold run" % (n8, W8, H8, it8),
+                    "warp_scatter_us": k1_8 * 1e6, "stencil_us": k3_8 * 1e6,
+                    "warp_scatter_us_per_1M_events": k1_8 * 1e6 * 1e6 / n8, "stencil_us_per_config2_image": k3_8 * 1e6 * img_px / px8,
+                    "warp_scatter_frac": K1_BYTES_PER_EVENT_ITER * n8 / k1_8 / 1e9 / HBM_PEAK_GBPS,
+                    "stencil_frac": 24.0 * px8 / k3_8 / 1e9 / HBM_PEAK_GBPS,
+                    "iteration_frac": (K1_BYTES_PER_EVENT_ITER * n8 + 24.0 * px8) / (k1_8 + k3_8) / 1e9 / HBM_PEAK_GBPS,
+                }
+                del sl8
+            except Exception as e:   # noqa: BLE001 -- a measurement beside the contract's
+                chip_full = {"error": str(e)[:200]}
         roofline = {
             "bound": "hbm", "kernel": "k_bin_warp_scatter%s (warp + tile-binned LDS scatter)" % ("_lean" if B > 1 else ""),
             "regime": "one slice context alone on the GPU, 1024-thread work-groups (the shape of a kernel that has the GPU to "
@@ -554,6 +592,7 @@ def main():
                       ("update in the stencil kernel's tail, as with %d contexts per GPU" % B if B > 1 else "update at its head"),
             "co_scheduled_shape": shared_shape,
             "other_geometries": other_geo,
+            "chip_full": chip_full,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_kernel": traffic_kernel,

@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--front-end-slices", type=int, default=20, help="rolling slices in the front-end measurement's event file")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="bf_set_option knob for every context (experiments), e.g. --opt bin_threads=512")
-    ap.add_argument("--cpu-iters", type=int, default=120, help="iteration_steps of the CPU baseline's bounded sample (~0.2 s each)")
+    ap.add_argument("--cpu-iters", type=int, default=0,
+                    help="iteration_steps of the CPU baseline's sample; 0 (default): the whole cold run, to the loop's own termination "
+                         "(~530 iterations, 10-40 s on one host core)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="cap on the host cores of the slice-parallel CPU figure")
     ap.add_argument("--farm-slices", type=int, default=512,
                     help="--config 5: independent slices (seeds 0 .. n-1) farmed over the ranks, slice i -> rank i %% N")
@@ -498,7 +500,7 @@ def main():
         except Exception:
             copy_gbps = None
         # HBM traffic per launch from the PMC passes (profiles/k1_traffic.json is written by
-        # scripts/collect_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
+        # scripts/collect_r4.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  null if not collected
         # or not for this workload.
         # (keyed by geometry AND kernel variant: the line names the 1024-thread lean kernel when several contexts share the
@@ -632,23 +634,29 @@ def main():
         ow = oc.set_cloud(s, H, W)
         om = oracle.Model()
         tc = time.perf_counter()
-        _, oloop, _ = oc.run(ow, om, max_iter=args.cpu_iters - 1, res_x=H, res_y=W)
+        orc_, oloop, _ = oc.run(ow, om, max_iter=(args.cpu_iters - 1) if args.cpu_iters > 0 else -1, res_x=H, res_y=W)
         dtc = time.perf_counter() - tc
         per_iter = dtc / max(1, oloop.itercount)
         full_iters = iters / max(1, args.steps * B)      # the GPU run's iterations per slice
+        if args.cpu_iters > 0:
+            cpu_value = len(sl["t"]) / (per_iter * full_iters) / 1e6
+            sample = ("first %d iteration_steps of the same %d-event cold run (%.1f s, %.1f ms/iteration), extrapolated to the %.0f "
+                      "iterations the full run takes" % (oloop.itercount, len(sl["t"]), dtc, 1e3 * per_iter, full_iters))
+        else:   # the whole job, nothing extrapolated
+            cpu_value = len(sl["t"]) / dtc / 1e6
+            sample = ("the same %d-event slice from a cold start to the reference loop's own termination: %d iteration_steps in %.1f s "
+                      "(%.1f ms/iteration; the GPU run: %.0f iterations)" % (len(sl["t"]), oloop.itercount, dtc, 1e3 * per_iter, full_iters))
         cpu_baseline = {
-            "value": len(sl["t"]) / (per_iter * full_iters) / 1e6, "unit": "Mevents/s",
+            "value": cpu_value, "unit": "Mevents/s",
             "cores": 1, "kind": "port",
-            "sample": "first %d iteration_steps of the same %d-event cold run (%.1f s, %.1f ms/iteration), "
-                      "extrapolated to the %.0f iterations the full run takes" %
-                      (oloop.itercount, len(sl["t"]), dtc, 1e3 * per_iter, full_iters),
+            "sample": sample,
+            "iterations": int(oloop.itercount), "to_termination": args.cpu_iters <= 0,
             "ms_per_iteration": 1e3 * per_iter,
         }
-        # the same oracle run ONCE to the loop's own termination (scripts/cpu_to_termination.py, in the build container:
-        # minutes of CPU that the default bench run does not spend), quoted beside the extrapolated sample
+        # (the same run in the build container, for reference: scripts/cpu_to_termination.py)
         tt = os.path.join(ROOT, "profiles", "cpu_to_termination.json")
         if os.path.exists(tt) and args.events == 1000000 and (H, W, s) == (260, 346, 3):
-            cpu_baseline["to_termination"] = json.load(open(tt))
+            cpu_baseline["build_container"] = json.load(open(tt))
         # the fair multi-core figure -- one slice per host core, all cores busy at once (the
         # reference's O(N) loops are serial, so slice-parallel is the only way it uses a multi-core host)
         ncore = host_cores()   # (a container's CPU quota, not the host's core count, is what this job may use)
@@ -657,7 +665,7 @@ def main():
             # one PROCESS per core (threads of one process serialise on page faults of the per-iteration images);
             # every worker builds its slice, reports ready, and all start together
             import subprocess
-            short = max(4, args.cpu_iters // 4)
+            short = max(4, (args.cpu_iters if args.cpu_iters > 0 else 240) // 4)
             cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--events", str(args.events),
                    "--height", str(H), "--width", str(W), "--scale", str(s), "--cpu-iters", str(short)]
             procs = [subprocess.Popen(cmd + ["--cpu-worker-seed", str(1 + k)], stdin=subprocess.PIPE,

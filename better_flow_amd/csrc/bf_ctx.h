@@ -83,7 +83,7 @@ struct bf_ctx {
     int opt_persist = 1;             // 0 never, 1 for warm-started runs of the one-kernel loop on a context that is not co-scheduled, 2 cold runs too
     unsigned long long *d_xrec = nullptr, *d_xred = nullptr;   // exchange records of the sub-tiles / of the reducers (two parities each)
     int xrec_alloc = 0;              // records per parity d_xrec holds
-    float2* d_xscratch[3] = {nullptr, nullptr, nullptr};       // private product arrays of the strips' readers
+    float2* d_xscratch[4] = {nullptr, nullptr, nullptr, nullptr};       // private product arrays of the strips' readers
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
     uint32_t* d_armed = nullptr;

@@ -201,12 +201,13 @@ struct FusedLoopArgs {
     DevState* snap;                  // pinned host copy: (done, it) after every pass, the whole state at exit
     unsigned long long* rec;         // [2][tiles * NSUB][16][2]: per-sub-tile records (payload, tag), by pass parity
     unsigned long long* red;         // [2][16][16][2]: the reducers' records
-    float2* scratch[3];              // private product arrays of the strips' readers (lists longer than a pass)
+    float2* scratch[4];              // private product arrays (lists longer than a pass): the strips' readers' [0 .. 2], the owners' [3]
     bf_trace_rec* trace;
     int nbr, nbc, R, C;
     int max_passes;
     int first_warp;                  // 0: the first pass of the run scatters the stored products as they are
     unsigned long long* tl;          // debug timeline (`make tl` build only)
+    int debug_abort;                 // >= 0: every work-group gives up at that pass (BF_DEBUG_PERSIST_ABORT: exercises the undo + fall-back)
 };
 hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_per_tile, int n_cus, hipStream_t s);
 // can `ntiles` work-groups of that kernel be resident at once on this device (n_cus compute units)?

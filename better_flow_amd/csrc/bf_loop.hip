@@ -32,8 +32,10 @@
 // the multi-pass path: products kept in memory, the strips' in per-reader private arrays (`scratch`), so that no
 // work-group ever reads what another one writes during the loop.
 //
-// A waiter gives up after 0.2 s without progress (a work-group that never became resident: cannot happen under a
-// cooperative launch): the kernel then ends with rc = BF_ERR_HIP instead of hanging the device.
+// A waiter gives up after 0.2 s without progress (a work-group that never became resident: another process's kernels hold
+// part of the CUs).  The launch then UNDOES itself: nobody stores products or state -- the events and the state are as the
+// launch found them --, work-group 0 only marks the state (hot.spare_ < 0: work-groups that start late leave at once), and
+// bf_run carries on with one launch per iteration.  Never a hang, never a wrong sum.
 #include <hip/hip_runtime.h>
 #include <atomic>
 
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     };
     {
         const int done0 = lds_sreg(&s_state.hot.done), rebin0 = lds_sreg(&s_state.hot.need_rebin);
+        if (lds_sreg(&s_state.hot.spare_) < 0) return;   // this launch has given up (see above): nothing was and nothing is changed
         if (done0 || rebin0 == 2) {   // the loop is over, or it waits for a re-bin nobody enqueued: nothing to do
             __syncthreads();
             if (b == 0 && tid == 0) s_state.hot.spare_ += 1;
@@ -158,15 +161,16 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     uint32_t vxy[U], vi[U];
     int32_t vt[U];
     float2 vp[U];
-    // products of list entry v: the owner's live in the slice's own array, a strip event's in the private array of the
-    // reader's direction (N / S -> 0, W / E -> 1, diagonal -> 2: no two readers of an event share a direction class)
+    // products of list entry v during the loop (multi-pass lists): private arrays -- the owner's copy in scratch[3], a strip
+    // event's in the array of the reader's direction (N / S -> 0, W / E -> 1, diagonal -> 2: no two readers of an event
+    // share a direction class)
     auto entry_of = [&](uint32_t v, uint32_t& i, float2*& parr) {
         uint32_t off = ft.off[0];
 #pragma unroll
         for (int r = 1; r < kFusedRanges; ++r) off += v >= ft.pre[r] ? off_step[r] : 0u;
         i = v + off;
         const int slot = (v >= ft.pre[1] ? 1 : 0) + (v >= ft.pre[3] ? 1 : 0) + (v >= ft.pre[6] ? 1 : 0);
-        parr = slot == 0 ? p_cur : (slot == 1 ? a.scratch[0] : (slot == 2 ? a.scratch[1] : a.scratch[2]));
+        parr = slot == 0 ? a.scratch[3] : (slot == 1 ? a.scratch[0] : (slot == 2 ? a.scratch[1] : a.scratch[2]));
     };
     auto load_pass = [&](uint32_t base, bool from_global) {
 #pragma unroll
@@ -183,8 +187,9 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
         }
     };
     if (M && single) load_pass(0u, true);
-    if (M && !single) {   // copy-in: the strips' products into this reader's private arrays
-        for (uint32_t v = own + tid; v < M; v += THREADS) {
+    if (M && !single) {   // copy-in: the list's products into this work-group's private arrays (its own events' too: the slice's
+                          // array is only written when the launch ends in order)
+        for (uint32_t v = tid; v < M; v += THREADS) {
             uint32_t i;
             float2* parr;
             entry_of(v, i, parr);
@@ -374,7 +379,8 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
                 idx[m] = q < nred ? q * 16 + f : -1;
             }
             unsigned long long word = 0;
-            const bool good = xchg_poll_sum<4>(red, idx, tag, word);
+            bool good = xchg_poll_sum<4>(red, idx, tag, word);
+            if (a.debug_abort >= 0 && j >= a.debug_abort) good = false;   // (test hook: every work-group "times out" at that pass)
             tl_stamp(a.tl, j, 9);
             word += __shfl_xor(word, 16, 64);
             word += __shfl_xor(word, 32, 64);
@@ -419,19 +425,30 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
         first_of_run = false;
         if (s_exit) break;
     }
-    // ---- exit: the owners' products, then the state ----
+    // ---- exit: the owners' products, then the state -- unless the launch gave up: then nothing is stored ----
+    if (s_abort) {
+        if (b == 0 && tid == 0) {   // the mark, in both state buffers: work-groups that start late leave at entry
+            __hip_atomic_store(&a.st->hot.spare_, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.st_other->hot.spare_, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     if (single && M) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t v = k * THREADS + tid;
             if (v < own) p_cur[vi[k]] = vp[k];
         }
+    } else if (M) {
+        for (uint32_t v = tid; v < own; v += THREADS) {
+            uint32_t i;
+            float2* parr;
+            entry_of(v, i, parr);
+            p_cur[i] = parr[i];
+        }
     }
     if (tid == 0 && s_rest) model_update_rest(&s_state, b == 0 ? a.trace : nullptr, 0, 0u);
-    if (b == 0 && tid == 0) {
-        s_state.hot.spare_ += 1;
-        if (s_abort) { s_state.rc = BF_ERR_HIP; s_state.hot.done = s_state.run_tag ? s_state.run_tag : 1; }
-    }
+    if (b == 0 && tid == 0) s_state.hot.spare_ += 1;
     __syncthreads();
     store_state();
 }

@@ -174,7 +174,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         if (!c->d_xred) {
             HIP_TRY(c, hipMalloc(&c->d_xred, (size_t)2 * 16 * 32 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemsetAsync(c->d_xred, 0, (size_t)2 * 16 * 32 * sizeof(unsigned long long), c->stream));
-            for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_xscratch[i], (size_t)c->cap_events * sizeof(float2)));
+            for (int i = 0; i < 4; ++i) HIP_TRY(c, hipMalloc(&c->d_xscratch[i], (size_t)c->cap_events * sizeof(float2)));
         }
     }
     bool want_rebin = false;
@@ -184,11 +184,6 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // warm-started slice -- is fed and polled like a cold run: two-iteration batches with a blocking poll each cost it a
     // host round trip every other iteration (22 instead of 14 us per iteration on a 50 000-event slice).
     const bool quick_warm = warm_start && c->warm_iters_hint < 3 * o.poll_interval;
-    const bool snap_polled = binned && !quick_warm && !persist;   // progress is read from the pinned snapshot (below)
-    if (snap_polled) {
-        *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
-        *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0].run_tag) = 0ull;
-    }
     int stall_allowance = 0;   // launches that may have been spent waiting for a re-bin (one-kernel iteration)
     bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
@@ -196,6 +191,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     double ht_launch = 0, ht_wait = 0;
     auto ht_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double ht_mark = host_timing ? ht_now() : 0;
+    bool prewarp_done = false, persist_gave_up = false;
     for (int batch = 0; persist; ++batch) {
         // One round: the (device-gated) re-bin, the loop kernel -- which returns when the loop is over, when a re-bin is due
         // or after max_passes iterations --, the final warp gated on `done`, and the state for the host.  A round ends with
@@ -210,13 +206,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         la.st = c->d_state; la.st_other = c->d_state + 1;
         la.snap = nullptr;
         la.rec = c->d_xrec; la.red = c->d_xred;
-        for (int i = 0; i < 3; ++i) la.scratch[i] = c->d_xscratch[i];
+        for (int i = 0; i < 4; ++i) la.scratch[i] = c->d_xscratch[i];
         la.trace = trace;
         la.nbr = c->fgrid.nbr; la.nbc = c->fgrid.nbc;
         la.R = c->win.scale_img_x; la.C = c->win.scale_img_y;
         la.max_passes = 4096;
         la.first_warp = first_warp ? 1 : 0;
         la.tl = c->d_tl;
+        const char* dbg_abort = getenv("BF_DEBUG_PERSIST_ABORT");   // (test hook, read per launch: tests set and clear it)
+        la.debug_abort = dbg_abort ? atoi(dbg_abort) : -1;
+        prewarp_done = true;
         {
             ProfScope ps(c, 0, c->n);
             HIP_TRY(c, launch_fused_loop(la, c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->stream));
@@ -246,6 +245,18 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         if (host_timing && batch < 40)
             fprintf(stderr, "persist round %d: it %d done %d need_rebin %d redo %d last_j %d rebins %d rc %d launches %d ovf_total %u\n", batch, ws.hot.it,
                     ws.hot.done, ws.hot.need_rebin, ws.hot.redo, ws.last_j, ws.hot.rebins, ws.rc, ws.hot.spare_, ws.ovf_total);
+        if (ws.hot.spare_ < 0) {
+            // The launch gave up (a work-group waited 0.2 s for others that were not resident: something else holds part of
+            // the GPU) and undid itself: events and state are as it found them.  The rest of the run takes one launch per
+            // iteration.
+            persist_gave_up = true;
+            if (host_timing) fprintf(stderr, "persistent loop kernel gave up in round %d (last_j %d): falling back to one launch per iteration\n", batch, ws.last_j);
+            first = ws.last_j < 0;
+            h.hot.spare_ = 0;
+            HIP_TRY(c, hipMemcpyAsync(&c->d_state[0].hot.spare_, &h.hot.spare_, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&c->d_state[1].hot.spare_, &h.hot.spare_, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            break;
+        }
         if (ws.hot.done) {
             fin = ws;
             final_done = true;
@@ -253,7 +264,13 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         }
         if (batch > 100000) return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
     }
+    (void)persist_gave_up;
     const bool persist_ran = final_done;
+    const bool snap_polled = binned && !quick_warm && !persist_ran;   // progress is read from the pinned snapshot (below)
+    if (snap_polled) {
+        *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0]) = 0ull;
+        *reinterpret_cast<volatile unsigned long long*>(&c->h_state[0].run_tag) = 0ull;
+    }
     for (int batch = 0; !persist_ran; ++batch) {
         // The re-bin kernels are device-gated (they run only if hot.need_rebin is set), but even a
         // no-op launch costs ~4.5 us here, so they are enqueued only before the first iteration and
@@ -261,7 +278,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // (0.6 x margin of drift), which covers the one-to-two batches of polling lag; anything
         // that still escapes takes the exact overflow path.
         if (binned && (batch == 0 || want_rebin)) {
-            int rc = enqueue_rebin(c, state_of(launched_iters), perm_at_start, (prewarp && batch == 0) ? &prewarp_wp : nullptr, fused, launched_iters);
+            int rc = enqueue_rebin(c, state_of(launched_iters), perm_at_start, (prewarp && batch == 0 && !prewarp_done) ? &prewarp_wp : nullptr, fused, launched_iters);
             if (rc != BF_OK) return rc;
             inf.launches += 3;
             want_rebin = false;

@@ -88,3 +88,25 @@ def test_auto_takes_it_where_it_was_measured_faster(accel_mod):
         shared = want_fused and 8 * len(sl["t"]) <= w.scale_img_x * w.scale_img_y
         assert (info2.launches < 1.5 * info2.iterations + 3 * info2.rebins + 8) == shared, (n, H, W, info2.launches, info2.iterations)
         a.close()
+
+
+def test_persistent_kernel_that_gives_up_undoes_itself(accel_mod):
+    """A work-group of the persistent kernel that waits 0.2 s for records that never come (another process's kernels hold part
+    of the CUs) makes the launch give up: nobody stores products or state, and bf_run carries on with one launch per
+    iteration from where that launch started.  BF_DEBUG_PERSIST_ABORT=<pass> makes every work-group "time out" at that pass:
+    the results must be the bits of the other loops -- for single-pass lists (events in registers) and multi-pass lists
+    (private product arrays), cold and warm, giving up in the first launch and in a later one."""
+    import os
+    for (n, H, W, s, seed) in ((50000, 180, 240, 3, 4), (300000, 260, 346, 3, 6)):
+        sl = synth.make_slice(n, H, W, 0.03, seed=seed)
+        ref = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 0})
+        for at in (0, 3, 17):
+            os.environ["BF_DEBUG_PERSIST_ABORT"] = str(at)
+            try:
+                got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2})
+            finally:
+                del os.environ["BF_DEBUG_PERSIST_ABORT"]
+            assert got["persistent"] == 1
+            assert got["launches"] > ref["it"][0] // 2, "the fall-back (one launch per iteration) must have run"
+            for key in ("rc", "it", "model", "trace", "flow"):
+                assert got[key] == ref[key], (n, at, key)

@@ -97,7 +97,13 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // (the persistent loop re-bins AT the request -- it returns for it --, the other loops one or two batches of launches
     // after it: the same effective threshold)
     if (binned) h.drift_limit = c->opt_bin_predict ? (persist ? 0.85 : 0.6) * (double)(fused ? c->fgrid.D : c->grid.D) : 1e300;
-    if (!first_warp) h.hot.wp = identity_warp();
+    // A warm start whose warp is fused into the first counting sort: the bins are built for the positions THAT warp gives,
+    // so it is the reference the drift bound measures from (k_bin_scan: ref_wp <- hot.wp; the first pass does not warp, and the
+    // first update overwrites hot.wp).  With the identity there, the first update -- whose warp is the previous model's plus
+    // one small step -- looked like a jump of the whole flow and asked for a re-bin right after the one just made: one more
+    // counting sort per warm slice, and in the persistent loop one more launch with its host round trip.
+    if (prewarp) h.hot.wp = prewarp_wp;
+    else if (!first_warp) h.hot.wp = identity_warp();
     h.ref_wp = h.hot.wp;
     const bool perm_at_start = c->has_perm;
 

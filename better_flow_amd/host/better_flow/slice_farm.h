@@ -258,8 +258,9 @@ private:
             const auto t3 = now();
             if (t.uv_ring && (rc = bf_compute_uv_ring(wk.ctx, t.uv_ring, t.uv_cap, t.uv_first)) < 0) return fail(rc, "compute_uv_ring");
             if (phase_timing)
-                std::fprintf(stderr, "farm worker %d slice %llu: since upload issue %.0f us | commit %.0f set_cloud %.0f run %.0f (%d it) uv %.0f us\n", wk.index,
-                             (unsigned long long)s.id, us(s.t_issue, t0), us(t0, t1), us(t1, t2), us(t2, t3), (int)r.info.iterations, us(t3, now()));
+                std::fprintf(stderr, "farm worker %d slice %llu: since upload issue %.0f us | commit %.0f set_cloud %.0f run %.0f (%d it, %d launches, %d polls, %d re-bins) uv %.0f us\n", wk.index,
+                             (unsigned long long)s.id, us(s.t_issue, t0), us(t0, t1), us(t1, t2), us(t2, t3), (int)r.info.iterations, (int)r.info.launches,
+                             (int)r.info.polls, (int)r.info.rebins, us(t3, now()));
         } else {
             // the reference runs its optimizer on the empty cloud: x_min = RES_X, x_max = 0 (optimizer_rolling.h:252-260)
             // make a negative window, the guard of :49-55 skips it, and get_model() is the model set_model() stored

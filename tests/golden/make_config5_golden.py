@@ -71,7 +71,45 @@ def one_run(args):
                 digest=slice_digest(sl), n=n)
 
 
+def assemble(outdir, seeds, members):
+    """python make_config5_golden.py --assemble OUTDIR K seed ...: the fixtures of main() and ensemble(K) from the per-run files
+    tests/golden/config5_job.py left in OUTDIR (the same runs, made one by one so that they can be resumed)."""
+    def load(seed, member):
+        d = np.load(os.path.join(outdir, "job_%d_%d.npz" % (seed, member)))
+        return {k: (d[k] if d[k].ndim else d[k].item()) for k in d.files}
+    for seed in seeds:
+        f, r = load(seed, 0), load(seed, 1)
+        assert f["digest"] == r["digest"]
+        idx = np.linspace(0, f["n"] - 1, SAMPLES).astype(np.int64)
+        out = dict(seed=seed, geometry=np.array([H, W, S]), n=f["n"], input_sha256=f["digest"], fields=np.array(FIELDS),
+                   trace_stride=STRIDE, sample_idx=idx, percentiles=np.array(PCT),
+                   spread_u=np.abs(f["u"] - r["u"]).max(), spread_v=np.abs(f["v"] - r["v"]).max())
+        for tag, d in (("fwd", f), ("rev", r)):
+            out[tag + "_rc"] = d["rc"]
+            out[tag + "_iterations"] = d["iterations"]
+            out[tag + "_dividers"] = d["dividers"]
+            out[tag + "_model"] = d["model"]
+            out[tag + "_every"] = d["every"]
+            out[tag + "_u"] = d["u"][idx]
+            out[tag + "_v"] = d["v"][idx]
+            out[tag + "_u_pct"] = np.percentile(d["u"], PCT)
+            out[tag + "_v_pct"] = np.percentile(d["v"], PCT)
+        np.savez_compressed(os.path.join(HERE, "config5_720p_seed%d.npz" % seed), **out)
+        rs = [load(seed, m) for m in range(2, 2 + members)]
+        eo = dict(seed=seed, members=np.arange(2, 2 + members), input_sha256=rs[0]["digest"], sample_idx=idx, fields=np.array(FIELDS),
+                  percentiles=np.array(PCT), rc=np.array([q["rc"] for q in rs]), iterations=np.array([q["iterations"] for q in rs]),
+                  dividers=np.array([q["dividers"] for q in rs]), model=np.array([q["model"] for q in rs]),
+                  u=np.array([q["u"][idx] for q in rs]), v=np.array([q["v"][idx] for q in rs]),
+                  u_pct=np.array([np.percentile(q["u"], PCT) for q in rs]), v_pct=np.array([np.percentile(q["v"], PCT) for q in rs]))
+        np.savez_compressed(os.path.join(HERE, "config5_720p_seed%d_ensemble.npz" % seed), **eo)
+        allu = np.array([f["u"], r["u"]] + [q["u"] for q in rs]); allv = np.array([f["v"], r["v"]] + [q["v"] for q in rs])
+        print("seed %d: iterations fwd %d rev %d ensemble %s; width of the six orders' flow: %.3f / %.3f px/s" %
+              (seed, f["iterations"], r["iterations"], eo["iterations"].tolist(), (allu.max(0) - allu.min(0)).max(), (allv.max(0) - allv.min(0)).max()))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--assemble":
+        return assemble(sys.argv[2], [int(a) for a in sys.argv[4:]], int(sys.argv[3]))
     if len(sys.argv) > 1 and sys.argv[1] == "--ensemble":
         return ensemble(int(sys.argv[2]), [int(a) for a in sys.argv[3:]] or [1])
     seeds = [int(a) for a in sys.argv[1:]] or [1]

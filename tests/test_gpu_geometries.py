@@ -234,10 +234,11 @@ def test_config5_to_termination_against_golden(accel_mod, seed):
       seed 0: 5389 .. 7355 iterations, and the row flow differs by 590 px/s between members -- on four of the six orders
               the x divider has doubled away before total_dx got anywhere near the injected -600 px/s.  The reference
               loop has no unique answer on this slice; it is kept because config 5's batch contains such slices.
-    The GPU (order-free integer sums) is one more member of that family.  Bars: return code 0; iteration count inside
-    the ensemble's range widened by a quarter of its width (+ 1 %); per-event flow at 4096 sampled events, its
-    percentiles and the model's totals inside the ensemble's envelope widened by its own (largest) width plus north_star's
-    1e-4 relative / 0.02 px/s."""
+    The GPU (order-free integer sums) is one more run of the same loop: it must belong to ONE FAMILY of the oracle's members
+    (seed 0 has two: upload order / reversed, and the four permutations, 590 px/s apart).  Bars, all against that family:
+    return code 0; iteration count inside the family's range widened by a quarter of its width (+ 1 %); per-event flow at
+    4096 sampled events, its percentiles and the model's totals inside the family's envelope widened by the family's own
+    (largest) width plus north_star's 1e-4 relative / 0.02 px/s."""
     import hashlib
     import os
     H, W, s = 720, 1280, 3
@@ -253,33 +254,54 @@ def test_config5_to_termination_against_golden(accel_mod, seed):
     rc, m, info, _, u, v = _gpu_run(accel_mod, sl, H, W, s, -1, 0)
     its = np.array([int(z["fwd_iterations"]), int(z["rev_iterations"])] + e["iterations"].tolist())
     assert rc == 0 and int(z["fwd_rc"]) == int(z["rev_rc"]) == 0 and not e["rc"].any()
-    slack = 0.25 * (its.max() - its.min()) + 0.01 * its.mean()
-    assert its.min() - slack <= info.iterations <= its.max() + slack, (info.iterations, its.tolist())
     idx = z["sample_idx"]
     assert np.array_equal(idx, e["sample_idx"])
-
-    def inside(g, members, what):
-        lo, hi = members.min(axis=0), members.max(axis=0)
-        # (six members under-sample the family: a seventh falls outside their range at every third event; it must stay
-        # within one ensemble width -- the widest over the sampled events -- of it)
-        w = (hi - lo).max() + np.maximum(1e-4 * np.maximum(np.abs(lo), np.abs(hi)), 0.02)
-        bad = (g < lo - w) | (g > hi + w)
-        assert not np.any(bad), (what, int(np.sum(bad)), float(np.max(np.maximum(lo - g, g - hi))), float((hi - lo).max()))
-        return float(np.max(np.maximum(lo - g, g - hi)))   # > 0: that far (px/s) outside the raw envelope
-
-    worst = max(inside(u[idx], np.vstack([z["fwd_u"], z["rev_u"], e["u"]]), "u"),
-                inside(v[idx], np.vstack([z["fwd_v"], z["rev_v"], e["v"]]), "v"))
-    inside(np.percentile(u, z["percentiles"]), np.vstack([z["fwd_u_pct"], z["rev_u_pct"], e["u_pct"]]), "u percentiles")
-    inside(np.percentile(v, z["percentiles"]), np.vstack([z["fwd_v_pct"], z["rev_v_pct"], e["v_pct"]]), "v percentiles")
+    U, V = np.vstack([z["fwd_u"], z["rev_u"], e["u"]]), np.vstack([z["fwd_v"], z["rev_v"], e["v"]])
+    UP, VP = np.vstack([z["fwd_u_pct"], z["rev_u_pct"], e["u_pct"]]), np.vstack([z["fwd_v_pct"], z["rev_v_pct"], e["v_pct"]])
     fields = [str(f) for f in z["fields"]]
     models = np.vstack([z["fwd_model"], z["rev_model"], e["model"]])
-    for f in ("total_dx", "total_dy", "total_rot", "total_div"):
-        k = fields.index(f)
-        lo, hi = models[:, k].min(), models[:, k].max()
-        w = 2.0 * (hi - lo) + 1e-4 * max(abs(lo), abs(hi)) + 1e-9   # (four scalars of six members: two widths)
-        assert lo - w <= getattr(m, f) <= hi + w, (f, getattr(m, f), lo, hi)
-    print("config 5 seed %d to termination: GPU %d iterations, the oracle's six event orders %s; sampled flow %s the ensemble's "
-          "envelope (widest: %.2f px/s in u, %.2f in v)" %
-          (seed, info.iterations, its.tolist(), "inside" if worst <= 0 else "at most %.3f px/s outside" % worst,
-           float((np.vstack([z["fwd_u"], z["rev_u"], e["u"]]).max(0) - np.vstack([z["fwd_u"], z["rev_u"], e["u"]]).min(0)).max()),
-           float((np.vstack([z["fwd_v"], z["rev_v"], e["v"]]).max(0) - np.vstack([z["fwd_v"], z["rev_v"], e["v"]]).min(0)).max())))
+    # The members fall into FAMILIES -- branches of the loop's divider doublings: single-link clusters of the sampled flow
+    # (two members are linked when they differ by less than a tenth of the ensemble's width, or by less than 2 px/s).  Seed
+    # 1: one family, 1.3 px/s wide.  Seed 0: {upload order, reversed} 4.6 px/s wide at u = -600 px/s, and the four
+    # permutations 20 px/s wide at u = -10 .. -29 px/s, 590 px/s away.  The GPU must belong to ONE family: every bar below
+    # is taken against that family's members and widened by that family's own width, not by the ensemble's.
+    nmem = len(U)
+    dist = np.array([[max(np.abs(U[i] - U[j]).max(), np.abs(V[i] - V[j]).max()) for j in range(nmem)] for i in range(nmem)])
+    link = dist < max(2.0, 0.1 * dist.max())
+    fam = list(range(nmem))
+    for i in range(nmem):
+        for j in range(nmem):
+            if link[i, j]:
+                fi, fj = fam[i], fam[j]
+                fam = [fi if f == fj else f for f in fam]
+    families = [np.array([k for k in range(nmem) if fam[k] == f]) for f in sorted(set(fam))]
+
+    def outside(g, members):
+        """How far (px/s) g lies outside the members' envelope widened by their own largest width plus north_star's
+        1e-4 relative / 0.02 px/s (<= 0: inside); and how far outside the raw envelope."""
+        lo, hi = members.min(axis=0), members.max(axis=0)
+        w = (hi - lo).max() + np.maximum(1e-4 * np.maximum(np.abs(lo), np.abs(hi)), 0.02)
+        return float(np.max(np.maximum(lo - w - g, g - hi - w))), float(np.max(np.maximum(lo - g, g - hi)))
+
+    verdicts = []
+    for F in families:
+        fits = its[F]
+        slack = 0.25 * (fits.max() - fits.min()) + 0.01 * fits.mean()
+        ok = fits.min() - slack <= info.iterations <= fits.max() + slack
+        ou_, raw_u = outside(u[idx], U[F])
+        ov_, raw_v = outside(v[idx], V[F])
+        ok = ok and ou_ <= 0 and ov_ <= 0
+        ok = ok and outside(np.percentile(u, z["percentiles"]), UP[F])[0] <= 0 and outside(np.percentile(v, z["percentiles"]), VP[F])[0] <= 0
+        for f in ("total_dx", "total_dy", "total_rot", "total_div"):
+            k = fields.index(f)
+            lo, hi = models[F, k].min(), models[F, k].max()
+            w = 2.0 * (hi - lo) + 1e-4 * max(abs(lo), abs(hi)) + 1e-9   # (four scalars of a few members: two widths)
+            ok = ok and lo - w <= getattr(m, f) <= hi + w
+        width = max(float((U[F].max(0) - U[F].min(0)).max()), float((V[F].max(0) - V[F].min(0)).max()))
+        verdicts.append((bool(ok), F.tolist(), fits.tolist(), width, max(raw_u, raw_v)))
+    assert any(v_[0] for v_ in verdicts), (info.iterations, verdicts)
+    home = next(v_ for v_ in verdicts if v_[0])
+    print("config 5 seed %d to termination: GPU %d iterations; the oracle's six event orders %s form %d famil%s; the GPU belongs to members "
+          "%s (iterations %s, %.2f px/s wide): sampled flow %s that family's raw envelope" %
+          (seed, info.iterations, its.tolist(), len(families), "y" if len(families) == 1 else "ies", home[1], home[2], home[3],
+           "inside" if home[4] <= 0 else "at most %.3f px/s outside" % home[4]))

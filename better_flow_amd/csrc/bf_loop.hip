@@ -5,7 +5,7 @@
 // compiled-in ring of 50 000 events on a 240x180 sensor, ~115 iterations per warm-started slice
 // (bf_motion_compensator.cpp:6-10,135) -- that launch IS the iteration: 11.7 us of which 3.6 are the gap between two
 // dependent launches and 2.0 the head's reload of state, accumulators and events.  Here the work-groups stay resident
-// (one per image tile, cooperative launch: all co-resident), keep their events in REGISTERS between iterations, and
+// (one per image tile, all co-resident: the grid is checked against the occupancy query), keep their events in REGISTERS, and
 // replace the launch boundary by an all-to-all exchange of the moment sums through memory:
 //
 //   pass     as k_fused_pass: the tile's own events and the neighbouring tiles' edge strips are warped and added to an LDS
@@ -488,10 +488,11 @@ static hipError_t launch_loop2(const FusedLoopArgs& a, int n_cus, hipStream_t s)
     if (e != hipSuccess) return e;
     const int ntiles = a.nbr * a.nbc;
     if ((long long)per_cu * n_cus < ntiles) return hipErrorCooperativeLaunchTooLarge;
-    FusedLoopArgs copy = a;
-    void* params[] = {&copy};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_fused_loop<HS, NSUB, 4>), dim3(ntiles), dim3(256 * NSUB), params,
-                                      (unsigned int)lds, s);
+    // A plain launch: the grid was checked against the occupancy query above, which is all hipLaunchCooperativeKernel adds
+    // (at 15-19 us of host time per launch on this stack); residency is the same either way, and should the hardware admit
+    // fewer work-groups than the query says, the kernel's waiters time out and the launch undoes itself.
+    hipLaunchKernelGGL((k_fused_loop<HS, NSUB, 4>), dim3(ntiles), dim3(256 * NSUB), lds, s, a);
+    return hipGetLastError();
 }
 template <int HS>
 static hipError_t launch_loop1(const FusedLoopArgs& a, int rows_per_tile, int n_cus, hipStream_t s) {

@@ -78,8 +78,10 @@ for ci in range(cases):
              ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}), ("merged", {"binned": 2, "bin_compact": 3}), ("merged_co", {"binned": 2, "bin_compact": 3, "co_schedule": 1}),
              ("dense_co", {"binned": 2, "bin_compact": 0, "co_schedule": 1}), ("compact_co", {"binned": 2, "bin_compact": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
              ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))}),
-             ("fused", {"fused": 2}), ("fused_tight", {"fused": 2, "fused_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
-             ("fused64", {"fused": 2, "fused_rows": 64, "fused_margin": int(rng.choice([4, 8, 20]))}), ("fused_unpacked", {"fused": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))})]
+             ("fused", {"fused": 2, "persist": 0}), ("fused_tight", {"fused": 2, "persist": 0, "fused_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
+             ("fused64", {"fused": 2, "fused_rows": 64, "fused_margin": int(rng.choice([4, 8, 20]))}), ("fused_unpacked", {"fused": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
+             ("persist", {"fused": 2, "persist": 2}), ("persist_tight", {"fused": 2, "persist": 2, "fused_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
+             ("persist64_unpacked", {"fused": 2, "persist": 2, "fused_rows": 64, "bin_pack_limit": int(rng.choice([1, 20, 64]))})]
     for name, kv in modes:
         a = accel.Accel(max_events=max(n, 16), max_rows=s * H + s, max_cols=s * W + s)
         for k_, v_ in kv.items():
@@ -166,7 +168,15 @@ for ci in range(cases):
             # a pixel boundary because of it changes the count image discretely: 1e-3-level differences there are the
             # reference's own sensitivity to event order, not a defect (case 73 of seed 102: both scatter modes agree
             # bit for bit with each other and differ from the oracle by 2e-3 in dy at iteration 1).
-            if worst > (3e-4 if k == 0 else 1e-2):
+            # ... and where the mean gradient itself is tiny (a dense slice on a small image: dx = -1.7e-4 in case 14 of seed
+            # 11), ONE such event is several per cent of it: what one pixel can contribute to a mean over cnt pixels -- a
+            # Scharr response of at most 32 x the slice's time span, over cnt, times the lever arm for rot / div -- is the
+            # absolute yardstick there (the oracle's own orders agree to 1e-8 on that case at iteration 0 and the GPU to
+            # 1e-7; at iteration 1 the valid-pixel counts are equal and the centre of mass differs by one pixel-row / cnt).
+            unit = 32.0 * (float(c["t"].max()) - float(c["t"].min())) * 1e-9 / max(1, o_.cnt)
+            crossing = all(abs(g[f] - getattr(o_, f)) <= 2.0 * unit * (max(s * H, s * W) if ("rot" in f or "div" in f) else 1.0)
+                           for f in ("dx", "dy", "rot", "div") if not np.isnan(getattr(o_, f)))
+            if worst > (3e-4 if k == 0 else 1e-2) and not (k >= 1 and crossing):
                 print(tag, "TRACE model at", k, "rel", worst); bad += 1; dump(ci, c, K); break
     if ci % 10 == 9:
         print("... %d cases, %d problems" % (ci + 1, bad), flush=True)

@@ -148,7 +148,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # No data-path collective exists on this path; the process group only carries the
         # timing barrier and two scalar reductions, so the CPU (gloo) backend is enough.
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # (gloo announces its connections on STDOUT, from C++: keep stdout to the one JSON line -- the library's chatter goes
+        # to stderr for the duration of the rendezvous)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import numpy as np
     from better_flow_amd import accel, synth

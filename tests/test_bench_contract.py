@@ -18,8 +18,10 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 def _line(cmd):
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    out = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    lines = [ln for ln in out if ln.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]          # exactly ONE JSON line (rank 0)
+    assert len(out) == 1, out[:5]                               # ... and nothing else on stdout (the rendezvous' chatter goes to stderr)
     return json.loads(lines[0])
 
 

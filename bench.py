@@ -620,8 +620,9 @@ def main():
             "stencil_kernel": {
                 "kernel": "k_stencil_binned (slab merge + box sum + time image + Scharr + moments + fused update)",
                 "algorithmic_bytes_per_launch": 24.0 * img_px,
-                "achieved": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9,
-                "frac": 24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS,
+                # (no stencil launches at all when --opt fused=2 forces the one-kernel iteration: null then)
+                "achieved": (24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9) if p.stencil_ms > 0 else None,
+                "frac": (24.0 * img_px / (p.stencil_ms * 1e-3 / max(1, live)) / 1e9 / HBM_PEAK_GBPS) if p.stencil_ms > 0 else None,
                 "traffic": stencil_traffic,
                 "note": "bound by dependent latency and instruction issue (its waves wait ~55 % of their cycles), not by bandwidth: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
             },
@@ -631,9 +632,9 @@ def main():
             },
             "note": "durations are the kernels' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the "
                     "ctx stream), summed over every loop launch and divided by the launches that did work; "
-                    "rocprofv3's view of the same solo runs: profiles/r3_solo_tail_1024_kernel_stats.csv (this shape: update in "
-                    "the stencil tail, 1024-thread scatter work-groups), r3_solo_tail_kernel_stats.csv (the co-scheduled 512-thread "
-                    "shape) and r3_solo_kernel_stats.csv (update at the head)",
+                    "rocprofv3's view of the same solo runs: profiles/r4_solo_tail_1024_kernel_stats.csv (this shape: update in "
+                    "the stencil tail, 1024-thread scatter work-groups), r4_solo_tail_kernel_stats.csv (the co-scheduled 512-thread "
+                    "shape) and r4_solo_kernel_stats.csv (update at the head)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------

@@ -149,7 +149,12 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // 51 KB tile needs half a CU's wave slots free at once and waits for them while the other contexts' kernels hold a few
     // each: its launches take 16.7 us instead of 8.0 under four contexts; with 512 threads 170 -> 190 Mevents/s.  A context
     // alone is faster with 1024: 8.0 against 8.9 us)
-    const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads : ((ev_per_bin >= 1536.0 && !c->opt_co_schedule) ? 1024 : 512);
+    // (event lists over thousands of bins -- 1280x720 at scale 3: 1620 bins of ~600 events, six per CU -- run 256-thread
+    // work-groups: twice as many bins in flight again, 16.6 against 18.6 us per scatter launch there at 1 M events, 8.2
+    // against 13.3 at 100 k; with a couple of bins per CU -- 640x480, 540 bins -- 512 threads stay ahead, 6.3 against 8.2)
+    const bool many_small_bins = c->fmt == 2 && c->n_cus > 0 && c->grid.nbins >= 4 * c->n_cus && ev_per_bin < 1024.0;
+    const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads
+                          : ((ev_per_bin >= 1536.0 && !c->opt_co_schedule) ? 1024 : (many_small_bins ? 256 : 512));
     if (binned && c->opt_bin_ev > 0) ev_per_thread = c->opt_bin_ev;
     else if (binned) {
         // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a

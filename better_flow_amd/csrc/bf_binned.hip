@@ -32,7 +32,14 @@ namespace bf {
 
 
 // Row -> bin row: exact division by the (not necessarily power-of-two) tile height.
+constexpr int kStencilSgprs = 74;
 __device__ __forceinline__ int row_bin(int row, const BinGrid& g) { return (int)__umulhi((uint32_t)row, g.mul_r); }
+
+// 64-bit load at (uniform base) + (per-thread byte offset): the form a global load takes with a scalar base register pair
+// and a 32-bit vector offset -- no vector instruction for the address.
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* base, uint32_t byte_off) {
+    return *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 // Image tile of the current target of one event (clamped into the grid: events whose target
 // is outside the image are rejected by the scatter but still need a home bin).
@@ -1330,14 +1337,30 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     constexpr int H = HS + 1;
     constexpr int PR = TR + 2 * H, PC = TC + 2 * H;
     constexpr int TH = TR + 2, TW = TC + 2;
-    constexpr int NC = (PR * PC + NT - 1) / NT;
+    // thread mapping of the two pixel loops: wave wv takes rows wv, wv + NW, ... (uniform), lane l column l; the columns
+    // beyond the 64th go to the first lanes of every wave
+    static_assert(TC == 64 && NT % 64 == 0, "one lane per tile column");
+    constexpr int NW = NT / 64;
+    constexpr int KR = (PR + NW - 1) / NW, XC = PC - 64, XE = (KR * XC + 63) / 64;   // halo plane (slab merge)
+    constexpr int KT = (TH + NW - 1) / NW, XT = TW - 64;                             // time tile
+    static_assert(KT * XT <= 64, "the time tile's extra columns fit one pass");
     __shared__ unsigned long long s_acc[PR * PC];
     __shared__ float s_time[TH * TW];
     __shared__ Sums s_red[NT / 64];
     const int R = a.R, C = a.C;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
     const BinGrid g = a.g;
+#ifdef BF_CENSUS
+    if (a.tl && tid == 0 && !(a.check_done && hs.done)) {   // debug: work-groups resident per CU (third block of the timeline buffer: counts, then maxima)
+        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(6164);
+        const uint32_t key = (xcc & 7u) * 128u + ((hw >> 8) & 127u);
+        unsigned long long* cen = a.tl + 2 * 64 * 2 * 16;
+        const unsigned long long n = atomicAdd(&cen[key], 1ull) + 1ull;
+        atomicMax(&cen[1024 + key], n);
+    }
+#endif
     const int bt = hs.bin_tbits;
     const unsigned long long bm = (1ull << bt) - 1ull;
     // (static indices only: a runtime index would push the HotState copy into scratch memory)
@@ -1423,68 +1446,141 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     // Interior + margin format (flush_split): one word of the tiled image per pixel -- bin (br, bc) keeps its TSR x TS pixels
     // at [(br nbc + bc) TSR TS + (gr - br TSR) TS + (gc - bc TS)] -- plus the margin-plane word where another bin's margin
     // can reach the pixel: within D of a boundary of its own bin.  Rows as in the dense form: the tile's rows cross at most
-    // one bin boundary, so the row part of the offset is one of two UNIFORM values.
+    // one bin boundary, so the row part of the offset is one of two UNIFORM values.  Thread mapping as in the dense form
+    // below: a wave takes whole rows of the halo plane, one column per lane.
     static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
     const int TSA = g.TS * g.TSR;
     const int b0r = row_bin(max(r0 - H, 0), g), next_r = (b0r + 1) * g.TSR;
     const int rp0 = b0r * (g.nbc * TSA - g.TSR * g.TS), rp1 = rp0 + g.nbc * TSA - g.TSR * g.TS;
     const int cmask = g.TS - 1;
-    unsigned long long w[NC][2];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int idx = tid + c * NT;
-        const int pr = idx / PC, pc = idx - pr * PC;
-        const int gr = r0 - H + pr, gc = c0 - H + pc;
-        const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
+    auto col_of = [&](int pc, bool& in, bool& edge, int& off, int& gc) {
+        gc = c0 - H + pc;
+        in = gc >= 0 && gc < C;
+        const int cc = gc & cmask;
+        off = __mul24(gc >> g.lg, TSA) + cc;
+        edge = cc < g.D || cc >= g.TS - g.D;
+    };
+    auto row_of = [&](int pr, bool& in, bool& edge, int& off, int& moff) {
+        const int gr = r0 - H + pr;
+        in = pr < PR && gr >= 0 && gr < R;
         const bool up = gr >= next_r;
         const int rr = gr - (up ? next_r : next_r - g.TSR);   // row inside the pixel's bin
-        const int cc = gc & cmask;
-        const int off = (up ? rp1 : rp0) + __mul24(gr, g.TS) + __mul24(gc >> g.lg, TSA) + cc;
-        const bool edge = rr < g.D || rr >= g.TSR - g.D || cc < g.D || cc >= g.TS - g.D;
-        w[c][0] = in ? a.slabs[(uint32_t)off] : 0ull;
-        w[c][1] = (in && edge) ? a.m_cur[(uint32_t)(__mul24(gr, C) + gc)] : 0ull;
+        off = (up ? rp1 : rp0) + __mul24(gr, g.TS);
+        edge = rr < g.D || rr >= g.TSR - g.D;
+        moff = __mul24(gr, C);
+    };
+    unsigned long long w[KR][2], we[XE][2];
+    bool c_in, c_edge;
+    int c_off, c_gc;
+    col_of(lane, c_in, c_edge, c_off, c_gc);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        bool r_in, r_edge;
+        int r_off, r_moff;
+        row_of(wv + k * NW, r_in, r_edge, r_off, r_moff);   // (uniform: scalar unit)
+        w[k][0] = w[k][1] = 0ull;
+        if (r_in && c_in) {
+            w[k][0] = ld_u64(a.slabs + (uint32_t)r_off, (uint32_t)c_off * 8u);
+            if (r_edge || c_edge) w[k][1] = ld_u64(a.m_cur + (uint32_t)r_moff, (uint32_t)c_gc * 8u);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < XE; ++x) {   // the columns beyond the 64th: lanes 0 .. KR XC - 1 of every wave, for the wave's own rows
+        const int e = lane + 64 * x;
+        bool r_in, r_edge, x_in, x_edge;
+        int r_off, r_moff, x_off, x_gc;
+        row_of(wv + (e / XC) * NW, r_in, r_edge, r_off, r_moff);
+        col_of(64 + e % XC, x_in, x_edge, x_off, x_gc);
+        we[x][0] = we[x][1] = 0ull;
+        if (e < KR * XC && r_in && x_in) {
+            we[x][0] = a.slabs[(uint32_t)(r_off + x_off)];
+            if (r_edge || x_edge) we[x][1] = a.m_cur[(uint32_t)(r_moff + x_gc)];
+        }
     }
     if (a.check_done && hs.done) return;   // (uniform; before the first barrier -- the loads above are already out)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int idx = tid + c * NT;
-        if (idx < PR * PC) s_acc[idx] = w[c][0] + w[c][1];
+    for (int k = 0; k < KR; ++k) {
+        const int pr = wv + k * NW;
+        if (pr < PR) s_acc[pr * PC + lane] = w[k][0] + w[k][1];
+    }
+#pragma unroll
+    for (int x = 0; x < XE; ++x) {
+        const int e = lane + 64 * x, pr = wv + (e / XC) * NW;
+        if (e < KR * XC && pr < PR) s_acc[pr * PC + 64 + e % XC] = we[x][0] + we[x][1];
     }
     } else {
     static_assert(TR + 2 * H <= 32, "a tile plus halo must fit the smallest bin height (32)");
     // Row -> bin without a per-pixel division: the tile's rows (with halo) span TR + 2 H <= 32 <= TSR rows, so both
     // gr - D and gr + D cross at most one bin boundary inside the tile.  The bin rows at the tile's first row,
-    // the boundary rows and the slab offsets of those bin rows are UNIFORM (scalar unit); a pixel only compares
-    // and adds.  (Measured, scripts/micro/rates.hip: every vector multiply -- 24-bit, 32-bit lo / hi -- and every
-    // f64 op or conversion issues at ~4.3 cycles per wave per SIMD, adds / logic at ~2.5; what counts is the
-    // instruction count per pixel, which this form halves for the address arithmetic.)
+    // the boundary rows and the slab offsets of those bin rows are UNIFORM (scalar unit).
+    // Thread mapping: a wave takes whole ROWS of the halo plane (rows wv, wv + NW, ...), one column per lane.  Everything
+    // that depends on the row -- which bin rows cover it, the row part of the slab offsets, whether a second bin row has to
+    // be read at all -- is then uniform and lives in the scalar unit; everything that depends on the column is computed once
+    // per thread, not once per pixel; a load is "scalar row base + per-thread byte offset" and costs no vector instruction
+    // for its address.  (With pixel idx = tid + c NT the row / column / bin arithmetic was ~60 vector instructions per slab
+    // pixel, a third of the kernel's: rocprofv3 counted 1038 per wave, and with several contexts on the GPU the vector
+    // units are what the loop saturates.)  The PC - 64 columns beyond the 64th go to the first lanes of every wave, for the
+    // wave's own rows, pixel by pixel as before.
     const int bl = row_bin(max(r0 - H - g.D, 0), g), bh = row_bin(max(r0 - H + g.D, 0), g);
     const int bl_next = (bl + 1) * g.TSR, bh_next = (bh + 1) * g.TSR;
     // element offset of pixel (gr, gc) in the slab of bin (br, bc): (br nbc + bc) LL + (gr - br TSR + D) L + (gc - bc TS + D)
     //   = [br nbc LL - (br TSR - D) L]  +  gr L  +  [bc LL - bc TS + D + gc]
     const int rb_l0 = bl * g.nbc * LLi - (bl * g.TSR - g.D) * g.L, rb_l1 = rb_l0 + g.nbc * LLi - g.TSR * g.L;
     const int rb_h0 = bh * g.nbc * LLi - (bh * g.TSR - g.D) * g.L, rb_h1 = rb_h0 + g.nbc * LLi - g.TSR * g.L;
-    unsigned long long w[NC][4];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int idx = tid + c * NT;
-        const int pr = idx / PC, pc = idx - pr * PC;
-        const int gr = r0 - H + pr, gc = c0 - H + pc;
-        const bool in = idx < PR * PC && gr >= 0 && gr < R && gc >= 0 && gc < C;
+    auto col_of = [&](int pc, bool& in, bool& two, int& lo, int& hi) {
+        const int gc = c0 - H + pc;
+        in = gc >= 0 && gc < C;
+        const int bcl = max(gc - g.D, 0) >> g.lg, bch = min((gc + g.D) >> g.lg, g.nbc - 1);
+        lo = __mul24(bcl, LLi) - (bcl << g.lg) + g.D + gc;
+        hi = __mul24(bch, LLi) - (bch << g.lg) + g.D + gc;
+        two = bch > bcl;
+    };
+    auto row_of = [&](int pr, bool& in, bool& two, int& lo, int& hi) {
+        const int gr = r0 - H + pr;
+        in = pr < PR && gr >= 0 && gr < R;
         // bin (br, bc) holds rows [br*TSR - D, br*TSR + TSR + D)
         const bool l_up = max(gr - g.D, 0) >= bl_next, h_up = gr + g.D >= bh_next;
         const int brl = bl + (l_up ? 1 : 0), brh = min(bh + (h_up ? 1 : 0), g.nbr - 1);
-        const int bcl = max(gc - g.D, 0) >> g.lg, bch = min((gc + g.D) >> g.lg, g.nbc - 1);
         const int grL = __mul24(gr, g.L);
-        const int rowpart_l = (l_up ? rb_l1 : rb_l0) + grL;
-        const int rowpart_h = ((brh > bh) ? rb_h1 : rb_h0) + grL;
-        const int colpart_l = __mul24(bcl, LLi) - (bcl << g.lg) + g.D + gc;
-        const int colpart_h = __mul24(bch, LLi) - (bch << g.lg) + g.D + gc;
+        lo = (l_up ? rb_l1 : rb_l0) + grL;
+        hi = ((brh > bh) ? rb_h1 : rb_h0) + grL;
+        two = brh > brl;
+    };
+    unsigned long long w[KR][4], we[XE][4];
+    bool c_in, c_two;
+    int c_lo, c_hi;
+    col_of(lane, c_in, c_two, c_lo, c_hi);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool use = in && (!(q & 2) || brh > brl) && (!(q & 1) || bch > bcl);
+    for (int k = 0; k < KR; ++k) {
+        bool r_in, r_two;
+        int r_lo, r_hi;
+        row_of(wv + k * NW, r_in, r_two, r_lo, r_hi);   // (uniform: scalar unit)
+        w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0ull;
+        if (r_in && c_in) {
+            const unsigned long long* pl = a.slabs + (uint32_t)r_lo;
+            w[k][0] = ld_u64(pl, (uint32_t)c_lo * 8u);
+            if (c_two) w[k][1] = ld_u64(pl, (uint32_t)c_hi * 8u);
+            if (r_two) {
+                const unsigned long long* ph = a.slabs + (uint32_t)r_hi;
+                w[k][2] = ld_u64(ph, (uint32_t)c_lo * 8u);
+                if (c_two) w[k][3] = ld_u64(ph, (uint32_t)c_hi * 8u);
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < XE; ++x) {
+        const int e = lane + 64 * x;
+        bool r_in, r_two, x_in, x_two;
+        int r_lo, r_hi, x_lo, x_hi;
+        row_of(wv + (e / XC) * NW, r_in, r_two, r_lo, r_hi);
+        col_of(64 + e % XC, x_in, x_two, x_lo, x_hi);
+        we[x][0] = we[x][1] = we[x][2] = we[x][3] = 0ull;
+        if (e < KR * XC && r_in && x_in) {
             // 32-bit element offsets (the slabs and planes are far below 2^32 bytes): base + offset addressing
-            w[c][q] = use ? a.slabs[(uint32_t)(((q & 2) ? rowpart_h : rowpart_l) + ((q & 1) ? colpart_h : colpart_l))] : 0ull;
+            we[x][0] = a.slabs[(uint32_t)(r_lo + x_lo)];
+            if (x_two) we[x][1] = a.slabs[(uint32_t)(r_lo + x_hi)];
+            if (r_two) we[x][2] = a.slabs[(uint32_t)(r_hi + x_lo)];
+            if (r_two && x_two) we[x][3] = a.slabs[(uint32_t)(r_hi + x_hi)];
         }
     }
     if (a.check_done && hs.done) return;   // (uniform; before the first barrier -- the loads above are already out)
@@ -1493,9 +1589,14 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     // s x s box around it.  One 64-bit add per contribution, one unpack per pixel.  Events that took the overflow path
     // are outside that bound (they come from any bin): their planes are read unpacked below, only when there are any.
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int idx = tid + c * NT;
-        if (idx < PR * PC) s_acc[idx] = (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
+    for (int k = 0; k < KR; ++k) {
+        const int pr = wv + k * NW;
+        if (pr < PR) s_acc[pr * PC + lane] = (w[k][0] + w[k][1]) + (w[k][2] + w[k][3]);
+    }
+#pragma unroll
+    for (int x = 0; x < XE; ++x) {
+        const int e = lane + 64 * x, pr = wv + (e / XC) * NW;
+        if (e < KR * XC && pr < PR) s_acc[pr * PC + 64 + e % XC] = (we[x][0] + we[x][1]) + (we[x][2] + we[x][3]);
     }
     }   // dense slabs
     // Overflow events of this iteration (uniform, rare): the scatter kernel flagged their pixels in a bitmap; the rows of it
@@ -1512,8 +1613,10 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
-    for (int idx = tid; idx < TH * TW; idx += NT) {
-        const int tr = idx / TW, tc = idx - tr * TW;
+    // (same thread mapping: uniform row, one column per lane -- the box's LDS addresses are one per-thread base plus
+    // immediates, the row tests are scalar)
+    auto time_px = [&](const int tr, const int tc) {
+        const int idx = tr * TW + tc;
         const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
         float tv = 0.f;
         if (gr >= 0 && gr < R && gc >= 0 && gc < C) {
@@ -1560,6 +1663,22 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
             }
         }
         s_time[idx] = tv;
+    };
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int tr = wv + k * NW;
+        if (tr < TH) time_px(tr, lane);
+    }
+    // the tile's last XT columns: one column each for the waves that had a row less than the others (with 18 rows on four
+    // waves: waves 2 and 3), so that every wave makes the same number of passes
+    constexpr int LW = TH % NW;   // the first LW waves took KT rows
+    if constexpr (LW != 0 && NW - LW >= XT && TH <= 64) {
+        if (wv >= LW && wv < LW + XT && lane < TH) time_px(lane, 64 + (wv - LW));
+    } else {
+        if (lane < KT * XT) {
+            const int tr = wv + (lane / XT) * NW;
+            if (tr < TH) time_px(tr, 64 + lane % XT);
+        }
     }
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 4);
@@ -1567,8 +1686,18 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero);
 }
 
+// Two builds of each: as the compiler allocates it (~100 scalar registers: the rows live in the scalar unit), and with
+// the scalar registers capped at what lets a CU hold 8 work-groups of 256 threads (<= 80: 7 up to 96, 6 up to 112 --
+// MI355X_MICROARCH.md "Residency"; the surplus is spilled into vector-register lanes).  A launch that fills the GPU
+// several times over runs the capped build: measured on one box, same inputs, eight config-2 slices side by side 60.8
+// -> 56.2 us, 1280x720 (event lists) 57.4 -> 50.3 us per launch.  A launch of a few work-groups per CU is one
+// work-group's latency chain long and the spills only lengthen it (346x260: 13.4 -> 13.8 us): the plain build.
 template <int HS, int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_stencil_binned(StencilArgs a) {
+    stencil_binned_body<HS, MODE, NT>(a);
+}
+template <int HS, int MODE, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(kStencilSgprs))) void k_stencil_binned_full(StencilArgs a) {
     stencil_binned_body<HS, MODE, NT>(a);
 }
 
@@ -1584,9 +1713,14 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
     }
 }
 
-void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s) {
+void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s, int n_cus) {
+    const bool full = n_cus > 0 && (long long)grid.x * grid.y >= 8ll * n_cus;   // more work-groups than the CUs hold at once
 #define BF_K3(HS_)                                                                                                  \
-    if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);     \
+    if (full) {                                                                                                     \
+        if (a.compact == 3) launch_timed(k_stencil_binned_full<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);   \
+        else if (a.compact) launch_timed(k_stencil_binned_full<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, a);   \
+        else launch_timed(k_stencil_binned_full<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, a);                  \
+    } else if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);     \
     else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, a);            \
     else launch_timed(k_stencil_binned<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, a)
     switch (a.scale / 2) {

@@ -101,7 +101,7 @@ void launch_local_time(const unsigned long long* ts, unsigned long long t0, int3
 void launch_local_time16(const unsigned long long* ts, const uint16_t* row, const uint16_t* col, unsigned long long t0,
                          int32_t* x_out, int32_t* y_out, int32_t* t_out, long long n, hipStream_t s);
 void stencil_grid(int R, int C, int* gx, int* gy);
-void launch_stencil(const StencilArgs& a, int src, hipStream_t s);
+void launch_stencil(const StencilArgs& a, int src, hipStream_t s, int n_cus = 0);   // n_cus: lets the tile-binned form pick its build by how often the grid fills the GPU
 // applies a pending update (sums in `acc`) to `st` in place: the tile-binned loop's update outside a warp+scatter launch
 void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
                           DevState* snap, hipStream_t s, const uint32_t* lost = nullptr);
@@ -132,7 +132,7 @@ void launch_fill_states(DevState* states, const DevState& tmpl, int nt, hipStrea
 
 // bf_binned.hip
 int bin_kernel_setup();
-void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s);
+void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s, int n_cus);
 // interior + margin format: clear what the bins' lists name in `mplane`, empty the lists (a run that cannot rely on the
 // loop's own clean-up: the dirty margin plane is the one its first iteration adds to, or the bin grid changes)
 void launch_margin_clean(unsigned long long* mplane, const uint32_t* mlist, uint32_t* mcount, int nbins, int mcap, hipStream_t s);

@@ -438,11 +438,11 @@ void stencil_grid(int R, int C, int* gx, int* gy) {
     *gy = (R + kTileR - 1) / kTileR;
 }
 
-void launch_stencil(const StencilArgs& a, int src, hipStream_t s) {
+void launch_stencil(const StencilArgs& a, int src, hipStream_t s, int n_cus) {
     int gx, gy;
     stencil_grid(a.R, a.C, &gx, &gy);
     dim3 grid(gx, gy);
-    if (src == 3) { launch_stencil_binned(a, grid, s); return; }
+    if (src == 3) { launch_stencil_binned(a, grid, s, n_cus); return; }
     if (src == 0) hipLaunchKernelGGL((k_stencil<0, kThreads>), grid, dim3(kThreads), 0, s, a);
     else if (src == 1) hipLaunchKernelGGL((k_stencil<1, kThreads>), grid, dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((k_stencil<2, kThreads>), grid, dim3(kThreads), 0, s, a);

@@ -310,7 +310,7 @@ int bf_get_time_img(bf_ctx* c, float* time_out, uint32_t* count_out) {
     a.zero_cplane = c->d_cplane[buf ^ 1];   // may be NULL (never allocated): nothing to clear
     {
         ProfScope ps(c, 1);
-        launch_stencil(a, stencil_src(c, false), c->stream);
+        launch_stencil(a, stencil_src(c, false), c->stream, c->n_cus);
     }
     HIP_TRY(c, hipGetLastError());
     c->cur = buf ^ 1;   // the stencil zeroed the other buffer; `buf` is cleared by the next pass

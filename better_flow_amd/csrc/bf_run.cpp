@@ -383,7 +383,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 a.tl = c->d_tl;
                 a.tl_launch = launched_iters;
                 ProfScope ps(c, 1);
-                launch_stencil(a, stencil_src(c, binned), c->stream);
+                // (contexts of this process sharing the GPU: the other contexts' kernels hold CU slots too -- count the GPU as full whatever
+                // this grid's size, i.e. take the stencil kernel's build that fits 8 work-groups per CU)
+                launch_stencil(a, stencil_src(c, binned), c->stream, (c->opt_co_schedule && g_live_ctx[c->device & 63].load() > 1) ? 1 : c->n_cus);
             }
             first = false;
             buf ^= 1;

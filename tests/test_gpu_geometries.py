@@ -220,7 +220,7 @@ def test_config2_cold_to_convergence_against_oracle(oracle_lib, accel_mod):
         assert abs(getattr(m, f) - getattr(om, f)) <= 1e-4 * max(abs(getattr(om, f)), 1e-6), f
 
 
-@pytest.mark.parametrize("seed", [1, 0, 2, 4])
+@pytest.mark.parametrize("seed", [1, 0, 2, 4, 3, 5])
 def test_config5_to_termination_against_golden(accel_mod, seed):
     """BASELINE config 5's slice (1M events, 1280x720, scale 3) cold to the loop's OWN termination (optimizer_rolling.h:
     76-101): thousands of iterations, where test_large_geometry_against_oracle compares the first 41.  The oracle needs
@@ -234,6 +234,7 @@ def test_config5_to_termination_against_golden(accel_mod, seed):
       seed 0: 5389 .. 7355 iterations, and the row flow differs by 590 px/s between members -- on four of the six orders
               the x divider has doubled away before total_dx got anywhere near the injected -600 px/s.  The reference
               loop has no unique answer on this slice; it is kept because config 5's batch contains such slices.
+      seeds 2, 4: families 23 and 9 px/s wide;  seeds 3, 5: the six orders scatter into four branches each (see below).
     The GPU (order-free integer sums) is one more run of the same loop: it must belong to ONE FAMILY of the oracle's members
     (seed 0 has two: upload order / reversed, and the four permutations, 590 px/s apart).  Bars, all against that family:
     return code 0; iteration count inside the family's range widened by a quarter of its width (+ 1 %); per-event flow at
@@ -299,6 +300,25 @@ def test_config5_to_termination_against_golden(accel_mod, seed):
             ok = ok and lo - w <= getattr(m, f) <= hi + w
         width = max(float((U[F].max(0) - U[F].min(0)).max()), float((V[F].max(0) - V[F].min(0)).max()))
         verdicts.append((bool(ok), F.tolist(), fits.tolist(), width, max(raw_u, raw_v)))
+    if len(families) >= 4 and not any(v_[0] for v_ in verdicts):
+        # Seeds 3 and 5: the six orders scatter into four branches -- most members are alone in theirs (seed 3: 5203 ..
+        # 22603 iterations, 1672 / 2924 px/s apart; seed 5: 3635 .. 17707 iterations, 44 / 95 px/s apart), so six samples do
+        # not cover the branches the reference loop can take on this slice and "belongs to one family" cannot be asked of a
+        # seventh run.  What can: the GPU run is one more sample of the same scatter -- return code 0, an iteration count
+        # inside the members' range, the sampled flow inside the members' envelope widened by a tenth of its width, and no
+        # further from its nearest member than the members are from theirs.
+        assert its.min() <= info.iterations <= its.max(), (info.iterations, its.tolist())
+        for g_, M in ((u[idx], U), (v[idx], V)):
+            lo, hi = M.min(axis=0), M.max(axis=0)
+            w = 0.1 * (hi - lo).max()
+            assert np.all(g_ >= lo - w) and np.all(g_ <= hi + w), (seed, float(np.max(np.maximum(lo - g_, g_ - hi))))
+        nn = np.sort(dist + np.diag([np.inf] * nmem), axis=1)[:, 0]
+        mine = min(max(np.abs(u[idx] - U[k]).max(), np.abs(v[idx] - V[k]).max()) for k in range(nmem))
+        assert mine <= nn.max(), (mine, nn.tolist())
+        print("config 5 seed %d to termination: GPU %d iterations; the oracle's six event orders %s scatter into %d branches (nearest-"
+              "neighbour distances %s px/s); the GPU run is %.2f px/s from its nearest member and inside the six orders' envelope" %
+              (seed, info.iterations, its.tolist(), len(families), np.round(nn, 2).tolist(), mine))
+        return
     assert any(v_[0] for v_ in verdicts), (info.iterations, verdicts)
     home = next(v_ for v_ in verdicts if v_[0])
     print("config 5 seed %d to termination: GPU %d iterations; the oracle's six event orders %s form %d famil%s; the GPU belongs to members "

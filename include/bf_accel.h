@@ -326,7 +326,13 @@ int bf_run(bf_ctx *ctx, const bf_run_opts *opts, bf_model *model_out, bf_run_inf
  * reference's RES / 15 and 1000 would skip every small tile).  One work-group per tile runs the
  * whole loop on chip.  Needs bf_upload_events first (not bf_set_cloud).  models_out / infos_out
  * hold grid_rows * grid_cols entries (row-major); infos[i].rc is 0, 1 (skipped) or < 0.
- * Afterwards bf_compute_uv / bf_writeout_events return the per-event results of all tiles. */
+ * Afterwards bf_compute_uv / bf_writeout_events return the per-event results of all tiles.
+ * Throughput over many slices: a grid's launch lasts as long as its slowest tile (thousands of
+ * iterations, while the mean is ~90), so a caller keeps several contexts' grids in flight, one host
+ * thread each -- and starts the process with GPU_MAX_HW_QUEUES=16 (the HIP runtime reads it once, at
+ * its first call; default 4): with four hardware queues a fifth grid waits behind another grid's
+ * straggler (measured, 32 x 32 tiles over 1M-event slices: 189 Mevents/s with 4 queues, 510 with 16
+ * queues and 16 grids in flight). */
 typedef struct bf_tile_opts {
     int32_t grid_rows, grid_cols;
     int32_t scale;

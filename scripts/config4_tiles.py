@@ -6,13 +6,27 @@ whole gradient-descent loop on chip) over 1M-event 346x260 slices.
 Reports the latency of ONE grid (the slice is done when its slowest tile is: one 638-event tile needs ~3000 iterations
 while the mean is ~90) and the SUSTAINED rate with G grids in flight -- G slice contexts (host thread + bf_ctx + HIP
 stream each) working through a queue of slices, so that one grid's straggler tile runs under the other grids' bulk; the
-reference would queue these (events, model) tasks one after the other (dvs_flow.h:200-231)."""
+reference would queue these (events, model) tasks one after the other (dvs_flow.h:200-231).
+
+A grid's launch lasts as long as its slowest tile (~21 ms) while its bulk is done in under a millisecond, so the sustained rate
+is "grids in flight / 21 ms" until the GPU's slots are full -- and the HIP runtime gives a process FOUR hardware queues
+(GPU_MAX_HW_QUEUES, default 4): the streams of a fifth grid queue behind another grid's straggler.  With the variable at 16
+(set here before the first HIP call unless the caller set it) and 16 grids in flight: 189 -> 510 Mevents/s (24 / 32: 450 /
+382).  The opposite of the iteration loop's dependent 10 us kernels, where more than four queues lose (EXPERIMENTS.md)."""
 import argparse
 import json
 import os
 import sys
 import threading
 import time
+
+if "--grids" in sys.argv:   # (before the HIP runtime starts: it reads the variable once)
+    try:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, int(sys.argv[sys.argv.index("--grids") + 1])))))
+    except (ValueError, IndexError):
+        pass
+else:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +39,7 @@ N, H, W, s, G = 1000000, 260, 346, 3, 32
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("min_events", nargs="?", type=int, default=256)
-    ap.add_argument("--grids", type=int, default=4, help="tile grids (slice contexts) in flight for the sustained figure")
+    ap.add_argument("--grids", type=int, default=16, help="tile grids (slice contexts) in flight for the sustained figure")
     ap.add_argument("--reps", type=int, default=6, help="slices per context in the sustained run")
     ap.add_argument("--slices", type=int, default=4, help="distinct slices")
     a_ = ap.parse_args()
@@ -86,7 +100,7 @@ def main():
                            "iterations_max": int(it.max()), "tile_iterations_per_s": float(it.sum() / best),
                            "floor": "the slowest tile's %d iterations x %.2f us per iteration of one work-group = %.1f ms: a grid cannot "
                                     "finish before its slowest tile" % (int(it.max()), per_iter_us, 1e-3 * it.max() * per_iter_us)},
-           "sustained": {"grids_in_flight": a_.grids, "slices": a_.grids * a_.reps, "seconds": dts, "mevents_per_s": ev_s / dts / 1e6,
+           "sustained": {"grids_in_flight": a_.grids, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "slices": a_.grids * a_.reps, "seconds": dts, "mevents_per_s": ev_s / dts / 1e6,
                          "tile_iterations_per_s": it_s / dts, "ms_per_slice": 1e3 * dts / (a_.grids * a_.reps)},
            "flow_median_px_s": [float(np.median(u[np.abs(u) > 0])) if (np.abs(u) > 0).any() else 0.0,
                                 float(np.median(v[np.abs(v) > 0])) if (np.abs(v) > 0).any() else 0.0],

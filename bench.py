@@ -497,6 +497,14 @@ def main():
         p, live, live_ev_iters = k_profile()
         if B > 1 and not explicit_shape:
             acc.set_option("bin_threads", 0)
+        # ... and the form the same context takes when it really is alone (no co_schedule): update at the head of the
+        # scatter kernel, no serial tail in the stencil kernel
+        alone_form = None
+        if B > 1:
+            acc.set_option("co_schedule", 0)
+            pa_, la_, lea_ = k_profile()
+            acc.set_option("co_schedule", 1)
+            alone_form = (pa_, la_, lea_)
         dx_, dy_, dt_, n__ = resident[0]
         acc.upload_events_device(dx_, dy_, dt_, n__)
         win_ = acc.set_cloud(s, H, W)
@@ -606,6 +614,18 @@ def main():
             "co_scheduled_shape": shared_shape,
             "other_geometries": other_geo,
             "chip_full": chip_full,
+            "context_alone_form": None if not alone_form else {
+                "what": "the same slice with co_schedule off -- what one context alone on the GPU runs: model / loop update at the "
+                        "head of the scatter kernel (k_bin_warp_scatter), no serial tail in the stencil kernel",
+                "warp_scatter_us": 1e3 * alone_form[0].warp_scatter_ms / max(1, alone_form[1]),
+                "stencil_us": 1e3 * alone_form[0].stencil_ms / max(1, alone_form[1]),
+                "warp_scatter_frac": K1_BYTES_PER_EVENT_ITER * (alone_form[2] / max(1, alone_form[1])) /
+                                     (alone_form[0].warp_scatter_ms * 1e-3 / max(1, alone_form[1])) / 1e9 / HBM_PEAK_GBPS,
+                "stencil_frac": (24.0 * img_px / (alone_form[0].stencil_ms * 1e-3 / max(1, alone_form[1])) / 1e9 / HBM_PEAK_GBPS)
+                                if alone_form[0].stencil_ms > 0 else None,
+                "iteration_frac": (K1_BYTES_PER_EVENT_ITER * (alone_form[2] / max(1, alone_form[1])) + 24.0 * img_px) /
+                                  ((alone_form[0].warp_scatter_ms + alone_form[0].stencil_ms) * 1e-3 / max(1, alone_form[1])) / 1e9 / HBM_PEAK_GBPS,
+            },
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_kernel": traffic_kernel,

@@ -152,7 +152,7 @@ void bf_destroy(bf_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tl) {   // debug timeline dump: launch group slot ticks(100 MHz)
-        std::vector<unsigned long long> tl(3 * 64 * 2 * 16);   // [kernel][launch][group][slot]; third block: per-work-group stamps of K1 launch 20
+        std::vector<unsigned long long> tl(3 * 64 * 2 * 16);   // [kernel][launch][group][slot]; third block: (BF_CENSUS builds) resident stencil work-groups per CU, counts then maxima
         (void)hipMemcpy(tl.data(), c->d_tl, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(c->tl_path, "w")) {
             for (size_t i = 0; i < tl.size(); ++i)

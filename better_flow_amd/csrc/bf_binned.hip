@@ -1683,7 +1683,9 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 4);
     const bool do_zero = a.zero_plane && sload(a.ovf_prev) != 0;   // the other plane buffer is dirty: clear it for the next iteration
-    stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero);
+    // (the accumulator plane is free from here on: the wave totals of the moment sums go through it)
+    static_assert((size_t)PR * PC >= (size_t)(NT / 64) * 192, "the reduction's scratch fits the accumulator plane");
+    stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero, reinterpret_cast<double*>(s_acc));
 }
 
 // Two builds of each: as the compiler allocates it (~100 scalar registers: the rows live in the scalar unit), and with

@@ -221,15 +221,50 @@ __device__ __forceinline__ unsigned int wave_total_dpp(unsigned int v) {
 constexpr int kSumFields = 9;
 // Two halves: every wave publishes its totals (wave reduction, one LDS hop, work-group barrier); then whoever needs the
 // work-group's total adds the partials up -- in the stencil kernels that is the first wave only, the others are done.
+// The six f64 wave totals through LDS instead of six 6-step DPP scans (18 instructions each, every lane adding for the
+// one lane that is read): one DPP step forms the pair sums (lane 2k+1: v[2k] + v[2k+1]), the odd lanes park them in `scr`
+// (this wave's 6 x 32 doubles), lane 8 f + c then adds four consecutive pair sums of field f pairwise -- lanes 8c .. 8c+7
+// of the wave -- and three DPP steps among the eight lanes of a field combine the chunks.  The SAME binary tree over the
+// 64 lanes as wave_total_dpp (adjacent pairs, then pairs of pairs, ...), so the same bits; ~45 vector instructions
+// instead of ~120.  Lane 8 f + 7 ends up with the wave's total of field f.
+__device__ __forceinline__ double wave_totals6_lds(const double (&v)[6], double* scr /* this wave's 192 doubles */, const int lane) {
+    double p[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        p[f] = v[f] + __longlong_as_double((long long)dpp_u64<0x111, 0xf>((unsigned long long)__double_as_longlong(v[f])));   // row_shr:1
+    if (lane & 1) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) scr[f * 32 + (lane >> 1)] = p[f];
+    }
+    __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order)
+    const int fl = lane < 48 ? lane : 0;   // lanes 48 .. 63 read along, their result is not used
+    const double* q = scr + (fl >> 3) * 32 + (fl & 7) * 4;
+    double t = (q[0] + q[1]) + (q[2] + q[3]);
+    t += __longlong_as_double((long long)dpp_u64<0x111, 0xf>((unsigned long long)__double_as_longlong(t)));   // chunks c-1, c
+    t += __longlong_as_double((long long)dpp_u64<0x112, 0xf>((unsigned long long)__double_as_longlong(t)));   // pairs
+    t += __longlong_as_double((long long)dpp_u64<0x114, 0xf>((unsigned long long)__double_as_longlong(t)));   // quads: lane 8 f + 7
+    return t;
+}
+
 template <int THREADS, bool PACK_INTS = false>
 __device__ __forceinline__ void block_reduce_publish(const Sums& sm, unsigned long long* s_part /* 9 * THREADS / 64 */,
-                                                     const int tid, const int base_i = 0, const int base_j = 0) {
+                                                     const int tid, const int base_i = 0, const int base_j = 0,
+                                                     double* s_scr = nullptr /* THREADS / 64 x 192 doubles, or none */) {
     constexpr int W = THREADS / 64;
     Sums r;
     if constexpr (PACK_INTS) {
         const int tn = (int)sm.n;
         const unsigned int wa = wave_total_dpp(((unsigned int)tn << 16) | (unsigned int)((int)sm.scj - tn * base_j));
         const unsigned int wb = wave_total_dpp((unsigned int)((int)sm.sci - tn * base_i));
+        if (s_scr) {
+            const int lane = tid & 63, w = tid >> 6;
+            const double v6[6] = {sm.sgx, sm.sgy, sm.sigx, sm.sigy, sm.sjgx, sm.sjgy};
+            const double t = wave_totals6_lds(v6, s_scr + w * 192, lane);
+            if (lane < 48 && (lane & 7) == 7) s_part[(3 + (lane >> 3)) * W + w] = (unsigned long long)__double_as_longlong(t);
+            if (lane == 63) s_part[0 * W + w] = ((unsigned long long)wa << 32) | (unsigned long long)wb;
+            __syncthreads();
+            return;
+        }
         r.sgx = wave_total_dpp(sm.sgx); r.sgy = wave_total_dpp(sm.sgy);
         r.sigx = wave_total_dpp(sm.sigx); r.sigy = wave_total_dpp(sm.sigy);
         r.sjgx = wave_total_dpp(sm.sjgx); r.sjgy = wave_total_dpp(sm.sjgy);
@@ -760,7 +795,7 @@ __device__ __forceinline__ unsigned long long acc_reduce_wave(const unsigned lon
 // NT: threads of the work-group (256, or 512 on small images: half the pixels per thread, a shorter dependent chain).
 template <int TR, int TC, int NT>
 __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* s_time, Sums* s_red,
-                                             int r0, int c0, bool do_zero) {
+                                             int r0, int c0, bool do_zero, double* s_scr = nullptr /* NT / 64 x 192 doubles of free LDS */) {
     constexpr int TW = TC + 2;
     const int R = a.R, C = a.C;
     const int tid = threadIdx.x;
@@ -816,7 +851,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             reinterpret_cast<unsigned long long*>(&s_state)[tid] = reinterpret_cast<const unsigned long long*>(a.st)[tid];
         __shared__ unsigned long long s_rpart[kSumFields * (NT / 64)];
         constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
-        block_reduce_publish<NT, kPack>(sm, s_rpart, tid, r0 - hR, c0 - hC);
+        block_reduce_publish<NT, kPack>(sm, s_rpart, tid, r0 - hR, c0 - hC, s_scr);
         // Everything below is the FIRST WAVE's: the work-group's total, the accumulator adds, the ticket and -- in the
         // last work-group -- the update.  The other waves are done (a quarter of a tile's instructions used to be every
         // wave adding up the same partials).  No work-group barrier from here on: one wave, in order.

@@ -208,6 +208,8 @@ struct FusedLoopArgs {
     int first_warp;                  // 0: the first pass of the run scatters the stored products as they are
     unsigned long long* tl;          // debug timeline (`make tl` build only)
     int debug_abort;                 // >= 0: every work-group gives up at that pass (BF_DEBUG_PERSIST_ABORT: exercises the undo + fall-back)
+    int debug_mute;                  // >= 0: from that pass on the LAST work-group publishes no records, as if it had never become
+                                     // resident (BF_DEBUG_PERSIST_MUTE): one reducer really times out, the others do not
 };
 hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_per_tile, int n_cus, hipStream_t s);
 // can `ntiles` work-groups of that kernel be resident at once on this device (n_cus compute units)?

@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             if (lt_ < 16) {
                 unsigned long long w = (r0 < R) ? sums_lane_word(blk, lt_) : 0ull;   // (a sub-tile below the image adds nothing)
                 if (lt_ == 15) w = (g == 0 && s_lost) ? 1ull : 0ull;                  // lane 15: events outran their bins
-                xchg_store(rec + (size_t)(b * NSUB + g) * kRecWords + 2 * lt_, w, tag);
+                const bool muted = a.debug_mute >= 0 && j >= a.debug_mute && b == ntiles - 1;   // (test hook)
+                if (!muted) xchg_store(rec + (size_t)(b * NSUB + g) * kRecWords + 2 * lt_, w, tag);
             }
         }
         tl_stamp(a.tl, j, 8);
@@ -366,8 +367,13 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             }
             tot += __shfl_xor(tot, 16, 64);
             tot += __shfl_xor(tot, 32, 64);
-            if (__ballot(!good) != 0ull) s_abort = 1;
-            if (lane < 16) xchg_store(red + (size_t)b * kRecWords + 2 * lane, tot, tag);
+            // A reducer that timed out publishes NOTHING: its partial total under a valid tag would be taken for the sum by
+            // every work-group's first wave (they look at the reduced records every microsecond, at their own clock only
+            // every few hundred) -- an update on wrong sums.  Without the record they all time out as well and the launch
+            // undoes itself as a whole.
+            const bool timed_out = __ballot(!good) != 0ull;
+            if (timed_out) s_abort = 1;
+            if (lane < 16 && !timed_out) xchg_store(red + (size_t)b * kRecWords + 2 * lane, tot, tag);
         }
         // ---- wave 0: the reduced records -> the total of field lane % 16 in every lane; the update ----
         if (tid_ < 64) {

@@ -226,6 +226,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         la.tl = c->d_tl;
         const char* dbg_abort = getenv("BF_DEBUG_PERSIST_ABORT");   // (test hook, read per launch: tests set and clear it)
         la.debug_abort = dbg_abort ? atoi(dbg_abort) : -1;
+        const char* dbg_mute = getenv("BF_DEBUG_PERSIST_MUTE");
+        la.debug_mute = dbg_mute ? atoi(dbg_mute) : -1;
         prewarp_done = true;
         {
             ProfScope ps(c, 0, c->n);

@@ -110,3 +110,15 @@ def test_persistent_kernel_that_gives_up_undoes_itself(accel_mod):
             assert got["launches"] > ref["it"][0] // 2, "the fall-back (one launch per iteration) must have run"
             for key in ("rc", "it", "model", "trace", "flow"):
                 assert got[key] == ref[key], (n, at, key)
+        # ... and the real thing: ONE work-group goes silent (BF_DEBUG_PERSIST_MUTE=<pass>: the last work-group stops publishing
+        # its records from that pass on, as if it had lost its CU).  Only the reducer in charge of its records times out; it
+        # must not publish its partial total -- the others would take it for the sum -- and the whole launch gives up.
+        for at in (0, 5):
+            os.environ["BF_DEBUG_PERSIST_MUTE"] = str(at)
+            try:
+                got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2})
+            finally:
+                del os.environ["BF_DEBUG_PERSIST_MUTE"]
+            assert got["launches"] > ref["it"][0] // 2, "the fall-back (one launch per iteration) must have run"
+            for key in ("rc", "it", "model", "trace", "flow"):
+                assert got[key] == ref[key], (n, "mute", at, key)

@@ -100,14 +100,19 @@ def test_large_geometry_against_oracle(oracle_lib, accel_mod, H, W, K):
     for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("auto", dict()),
                        ("compact", dict(binned=2, bin_compact=2)), ("dense", dict(binned=2, bin_compact=0)),
                        ("merged", dict(binned=2, bin_compact=3)),
-                       ("tail_update", dict(binned=2, co_schedule=1))):
+                       ("tail_update", dict(binned=2, co_schedule=1)),
+                       ("no_predict", dict(binned=2, bin_margin=4, bin_predict=0))):
         runs[name] = _gpu_run(accel_mod, sl, H, W, s, K, K + 1, **opts)
     b = runs["binned"]
     assert b[0] == 0 and b[2].iterations == K + 1
     assert b[2].rebins >= 1, "the binned path must be the one that ran"
-    assert b[2].overflow_events > 0, "overflow path + the stencil's overflow branch must be live at this geometry"
+    # The overflow path + the stencil's overflow branch must be live at this geometry.  With the drift prediction on, how many
+    # events take it depends on how far the host's re-bin lags the device's request -- usually 299 here, NONE when a slow
+    # host (a cold box) lets the queue run dry and re-bins exactly at the request: seen once in ~20 suite runs.  Without the
+    # prediction a re-bin is only asked for once events HAVE overflowed: live whatever the timing.
+    assert runs["no_predict"][2].overflow_events > 0, "overflow path + the stencil's overflow branch must be live at this geometry"
     assert runs["auto"][2].rebins >= 1, "1M events at this geometry are dense enough for the binned path by default"
-    for name in ("atomics", "auto", "compact", "dense", "merged", "tail_update"):   # integer accumulators: every scatter mode gives the same bits
+    for name in ("atomics", "auto", "compact", "dense", "merged", "tail_update", "no_predict"):   # integer accumulators: every scatter mode gives the same bits
         r = runs[name]
         assert (r[0], r[2].iterations, r[1].as_dict(), r[3]) == (b[0], b[2].iterations, b[1].as_dict(), b[3]), name
         assert np.array_equal(r[4], b[4]) and np.array_equal(r[5], b[5]), name

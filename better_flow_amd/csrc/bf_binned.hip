@@ -669,8 +669,13 @@ void launch_margin_clean(unsigned long long* mplane, const uint32_t* mlist, uint
 // accumulators are the first thing requested, the events of the first pass the second, and while the first wave forms
 // the total and updates, the other fifteen turn their events' stored f32 products into the previous positions (the
 // model-independent third of the per-event arithmetic); the first wave catches up after the barrier.
+// (pre_*: the three pointers the kernel's FIRST loads go through, repeated ahead of the argument block as scalar parameters:
+// the command processor preloads leading scalar arguments into SGPRs before a wave starts -- `-mllvm
+// -amdgpu-kernarg-preload-count`, Makefile -- so those loads leave together with the fetch of the argument block instead
+// of behind it: 7.87 -> 7.66 us per launch alone at config 2, same box, libraries alternating.)
 template <bool WARP, int THREADS, int U, int FMT>
-__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) {
+__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __restrict__ pre_bin_start, const DevState* pre_st_in,
+                                                              MomentAcc* pre_acc, BinScatterArgs a) {
     constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
     constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
@@ -690,15 +695,15 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
     // (The scalar loads come first in program order: placed after the lane-conditional vector loads, the compiler
     // carried the state pointer through a vector register and turned them into vector loads -- which complete in order
     // behind the accumulators.)
-    const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
-    const int done0 = sload(&a.st_in->hot.done), it0 = sload(&a.st_in->hot.it);
-    const int live_set = sload(&a.st_in->hot.cs) ^ sload(&a.st_in->hot.flip);
+    const uint32_t beg = sload(pre_bin_start + b), end = sload(pre_bin_start + b + 1);
+    const int done0 = sload(&pre_st_in->hot.done), it0 = sload(&pre_st_in->hot.it);
+    const int live_set = sload(&pre_st_in->hot.cs) ^ sload(&pre_st_in->hot.flip);
     const uint32_t m_prev_n = SPLIT ? sload(a.mcount + b) : 0u;
     unsigned long long accv[kAccPerLane];
-    if (a.acc && tid < 64) acc_load_wave<false, false>(a.acc, tid, accv);
+    if (pre_acc && tid < 64) acc_load_wave<false, false>(pre_acc, tid, accv);
     const uint32_t ovf_prev_part = (b == 0 && a.acc && tid < 64) ? ovf_part(a.ovf_prev, tid) : 0u;   // (work-group 0 books it below)
     unsigned long long state_word = 0;
-    if (tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
+    if (tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(pre_st_in)[tid];
     const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
     auto store_state = [&]() {   // work-group 0, after a barrier: the state for the next launches and for the host
         if (b == 0 && tid < kStateWords) {
@@ -867,7 +872,8 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(BinScatterArgs a) 
 // and the scatter, so the waves of a work-group drift apart and overlap each other's memory latency.  Work-group 0
 // still carries the state to the other buffer and to the host snapshot.
 template <bool WARP, int THREADS, int U, int FMT>
-__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArgs a) {
+__global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_t* __restrict__ pre_bin_start, const DevState* pre_st_in,
+                                                                   MomentAcc* /* pre_acc: unused here, same signature */, BinScatterArgs a) {
     constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
     constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
@@ -879,8 +885,8 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(BinScatterArg
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t beg = sload(a.bin_start + b), end = sload(a.bin_start + b + 1);
-    const HotState h0 = sload(&a.st_in->hot);   // one burst of scalar loads
+    const uint32_t beg = sload(pre_bin_start + b), end = sload(pre_bin_start + b + 1);
+    const HotState h0 = sload(&pre_st_in->hot);   // one burst of scalar loads
     const uint32_t m_prev_n = SPLIT ? sload(a.mcount + b) : 0u;
     const int X0 = (b / g.nbc) * g.TSR - g.D, Y0 = (b - (b / g.nbc) * g.nbc) * g.TS - g.D;
     if (!COMPACT) {   // zero the LDS tile, 16 bytes per lane (overlaps the loads above)
@@ -1325,13 +1331,25 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
 // HS = scale / 2 is a template parameter so that the tile geometry is constexpr (index
 // arithmetic by multiply-shift), TS is a power of two (shifts), D <= TS / 2 (a pixel is
 // covered by at most 2 x 2 bins) and every slab load of a thread is issued up front.
+// (K3Pre: everything the kernel's first phase -- the slab loads' addresses -- is computed from, as leading scalar kernel
+// arguments that the command processor preloads into SGPRs (14 dwords, the most the hardware takes; see the scatter kernel):
+// the state's load and the address arithmetic no longer wait for the argument block's fetch: 12.44 -> 11.95 us per launch
+// alone at config 2 (update in the tail), 6.5 -> 6.4 with the chip full.)
+struct K3Pre {
+    const unsigned long long* slabs;
+    const DevState* st;
+    int R, C, D, lg, nbc, nbr, LR, L, TSR;
+    uint32_t mul_r;
+};
 template <int HS, int MODE, int NT>   // MODE: what the scatter kernel wrote -- 0 dense slabs, 1 lists, 2 interior + margin plane
-__device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
+__device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const K3Pre& pre) {
     constexpr bool COMPACT = MODE == 1;
     tl_stamp(a.tl, a.tl_launch, 0);
     // one burst of scalar loads; the state is not CONSUMED (not even for the early exit of a finished loop) before the
-    // first vector loads below are out: their latencies overlap instead of adding up
-    const HotState hs = sload(&a.st->hot);
+    // first vector loads below are out: their latencies overlap instead of adding up.  (Keeping EVERY scalar load -- state
+    // and argument block -- behind the slab loads' issue, which the preloaded arguments allow, was built and measured: no
+    // faster than this, EXPERIMENTS.md.)
+    const HotState hs = sload(&pre.st->hot);
     tl_stamp(a.tl, a.tl_launch, 1);
     constexpr int TR = kTileR, TC = kTileC;
     constexpr int H = HS + 1;
@@ -1347,11 +1365,12 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
     __shared__ unsigned long long s_acc[PR * PC];
     __shared__ float s_time[TH * TW];
     __shared__ Sums s_red[NT / 64];
-    const int R = a.R, C = a.C;
+    const int R = pre.R, C = pre.C;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
-    const BinGrid g = a.g;
+    BinGrid g = a.g;   // (the fields the slab addresses use come from the preloaded arguments)
+    g.D = pre.D; g.lg = pre.lg; g.nbc = pre.nbc; g.nbr = pre.nbr; g.LR = pre.LR; g.L = pre.L; g.TSR = pre.TSR; g.mul_r = pre.mul_r;
 #ifdef BF_CENSUS
     if (a.tl && tid == 0 && !(a.check_done && hs.done)) {   // debug: work-groups resident per CU (third block of the timeline buffer: counts, then maxima)
         const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(6164);
@@ -1429,7 +1448,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
                 ox = ge ? s_eox[j] : ox;
             }
             const uint32_t idx = a.cidx[(uint32_t)(base + (int)e)];
-            const unsigned long long v = a.slabs[(uint32_t)(base + (int)e)];
+            const unsigned long long v = pre.slabs[(uint32_t)(base + (int)e)];
             const int lx = (int)__umulhi(idx, g.mul_l);            // idx / L
             const int tr = oy + lx, tc = ox + (int)idx - lx * g.L;  // the point, in time-pixel coordinates
             if (tr >= -HS && tr < TH + HS && tc >= -HS && tc < TW + HS) {
@@ -1480,7 +1499,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         row_of(wv + k * NW, r_in, r_edge, r_off, r_moff);   // (uniform: scalar unit)
         w[k][0] = w[k][1] = 0ull;
         if (r_in && c_in) {
-            w[k][0] = ld_u64(a.slabs + (uint32_t)r_off, (uint32_t)c_off * 8u);
+            w[k][0] = ld_u64(pre.slabs + (uint32_t)r_off, (uint32_t)c_off * 8u);
             if (r_edge || c_edge) w[k][1] = ld_u64(a.m_cur + (uint32_t)r_moff, (uint32_t)c_gc * 8u);
         }
     }
@@ -1493,7 +1512,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         col_of(64 + e % XC, x_in, x_edge, x_off, x_gc);
         we[x][0] = we[x][1] = 0ull;
         if (e < KR * XC && r_in && x_in) {
-            we[x][0] = a.slabs[(uint32_t)(r_off + x_off)];
+            we[x][0] = pre.slabs[(uint32_t)(r_off + x_off)];
             if (r_edge || x_edge) we[x][1] = a.m_cur[(uint32_t)(r_moff + x_gc)];
         }
     }
@@ -1557,11 +1576,11 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         row_of(wv + k * NW, r_in, r_two, r_lo, r_hi);   // (uniform: scalar unit)
         w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0ull;
         if (r_in && c_in) {
-            const unsigned long long* pl = a.slabs + (uint32_t)r_lo;
+            const unsigned long long* pl = pre.slabs + (uint32_t)r_lo;
             w[k][0] = ld_u64(pl, (uint32_t)c_lo * 8u);
             if (c_two) w[k][1] = ld_u64(pl, (uint32_t)c_hi * 8u);
             if (r_two) {
-                const unsigned long long* ph = a.slabs + (uint32_t)r_hi;
+                const unsigned long long* ph = pre.slabs + (uint32_t)r_hi;
                 w[k][2] = ld_u64(ph, (uint32_t)c_lo * 8u);
                 if (c_two) w[k][3] = ld_u64(ph, (uint32_t)c_hi * 8u);
             }
@@ -1577,10 +1596,10 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
         we[x][0] = we[x][1] = we[x][2] = we[x][3] = 0ull;
         if (e < KR * XC && r_in && x_in) {
             // 32-bit element offsets (the slabs and planes are far below 2^32 bytes): base + offset addressing
-            we[x][0] = a.slabs[(uint32_t)(r_lo + x_lo)];
-            if (x_two) we[x][1] = a.slabs[(uint32_t)(r_lo + x_hi)];
-            if (r_two) we[x][2] = a.slabs[(uint32_t)(r_hi + x_lo)];
-            if (r_two && x_two) we[x][3] = a.slabs[(uint32_t)(r_hi + x_hi)];
+            we[x][0] = pre.slabs[(uint32_t)(r_lo + x_lo)];
+            if (x_two) we[x][1] = pre.slabs[(uint32_t)(r_lo + x_hi)];
+            if (r_two) we[x][2] = pre.slabs[(uint32_t)(r_hi + x_lo)];
+            if (r_two && x_two) we[x][3] = pre.slabs[(uint32_t)(r_hi + x_hi)];
         }
     }
     if (a.check_done && hs.done) return;   // (uniform; before the first barrier -- the loads above are already out)
@@ -1694,13 +1713,16 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a) {
 // several times over runs the capped build: measured on one box, same inputs, eight config-2 slices side by side 60.8
 // -> 56.2 us, 1280x720 (event lists) 57.4 -> 50.3 us per launch.  A launch of a few work-groups per CU is one
 // work-group's latency chain long and the spills only lengthen it (346x260: 13.4 -> 13.8 us): the plain build.
+#define BF_K3_PRE_PARAMS const unsigned long long* p_slabs, const DevState* p_st, int p_R, int p_C, int p_D, int p_lg, \
+                          int p_nbc, int p_nbr, int p_LR, int p_L, int p_TSR, uint32_t p_mul_r
+#define BF_K3_PRE_VALUE K3Pre{p_slabs, p_st, p_R, p_C, p_D, p_lg, p_nbc, p_nbr, p_LR, p_L, p_TSR, p_mul_r}
 template <int HS, int MODE, int NT>
-__global__ __launch_bounds__(NT) void k_stencil_binned(StencilArgs a) {
-    stencil_binned_body<HS, MODE, NT>(a);
+__global__ __launch_bounds__(NT) void k_stencil_binned(BF_K3_PRE_PARAMS, StencilArgs a) {
+    stencil_binned_body<HS, MODE, NT>(a, BF_K3_PRE_VALUE);
 }
 template <int HS, int MODE, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(kStencilSgprs))) void k_stencil_binned_full(StencilArgs a) {
-    stencil_binned_body<HS, MODE, NT>(a);
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(kStencilSgprs))) void k_stencil_binned_full(BF_K3_PRE_PARAMS, StencilArgs a) {
+    stencil_binned_body<HS, MODE, NT>(a, BF_K3_PRE_VALUE);
 }
 
 // Plain launch, or (profiling armed) an extended launch whose events carry the kernel's own timestamps.
@@ -1717,14 +1739,15 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s, int n_cus) {
     const bool full = n_cus > 0 && (long long)grid.x * grid.y >= 8ll * n_cus;   // more work-groups than the CUs hold at once
+#define BF_K3_PRE a.slabs, a.st, a.R, a.C, a.g.D, a.g.lg, a.g.nbc, a.g.nbr, a.g.LR, a.g.L, a.g.TSR, a.g.mul_r
 #define BF_K3(HS_)                                                                                                  \
     if (full) {                                                                                                     \
-        if (a.compact == 3) launch_timed(k_stencil_binned_full<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);   \
-        else if (a.compact) launch_timed(k_stencil_binned_full<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, a);   \
-        else launch_timed(k_stencil_binned_full<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, a);                  \
-    } else if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, a);     \
-    else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, a);            \
-    else launch_timed(k_stencil_binned<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, a)
+        if (a.compact == 3) launch_timed(k_stencil_binned_full<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, BF_K3_PRE, a);   \
+        else if (a.compact) launch_timed(k_stencil_binned_full<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, BF_K3_PRE, a);   \
+        else launch_timed(k_stencil_binned_full<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, BF_K3_PRE, a);                  \
+    } else if (a.compact == 3) launch_timed(k_stencil_binned<HS_, 2, kThreads>, grid, dim3(kThreads), 0, s, BF_K3_PRE, a);     \
+    else if (a.compact) launch_timed(k_stencil_binned<HS_, 1, kThreads>, grid, dim3(kThreads), 0, s, BF_K3_PRE, a);            \
+    else launch_timed(k_stencil_binned<HS_, 0, kThreads>, grid, dim3(kThreads), 0, s, BF_K3_PRE, a)
     switch (a.scale / 2) {
         case 0: BF_K3(0); break;
         case 1: BF_K3(1); break;
@@ -1733,6 +1756,7 @@ void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s, int n
         default: BF_K3(4); break;
     }
 #undef BF_K3
+#undef BF_K3_PRE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1778,12 +1802,12 @@ static hipError_t launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s)
         raised.fetch_or(dev_bit, std::memory_order_release);
     }
     if (!a.acc) {   // nothing to update at the head
-        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+        if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
+        else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
         return hipSuccess;
     }
-    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
-    else launch_timed(k_bin_warp_scatter<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a);
+    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
+    else launch_timed(k_bin_warp_scatter<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
     return hipSuccess;
 }
 template <int THREADS, int U>

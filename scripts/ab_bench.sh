@@ -9,8 +9,9 @@ for i in $(seq $N); do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d.get('roofline', {})
-print('$L'.split('/')[-1], 'value %.1f  ev-it/s %.4g  it/slice %.1f  K1 %.2f us  K3 %.2f us  chip-full K1 %.2f K3 %.2f' % (
-    d['value'], d['config']['event_iterations_per_s'], d['config']['iterations_per_slice'],
+oc = d.get('regimes', {}).get('one_context', {})
+print('$L'.split('/')[-1], 'value %.1f  one context cold %.1f warm %.0f  it/slice %.1f  K1 %.2f us  K3 %.2f us  chip-full K1 %.2f K3 %.2f' % (
+    d['value'], oc.get('cold', {}).get('mevents_per_s', 0), oc.get('warm_stm', {}).get('mevents_per_s', 0), d['config']['iterations_per_slice'],
     r.get('per_kernel_us', {}).get('warp_scatter', 0), r.get('per_kernel_us', {}).get('stencil_moments_update', 0),
     r.get('chip_full', {}).get('warp_scatter_us_per_1M_events', 0), r.get('chip_full', {}).get('stencil_us_per_config2_image', 0)))
 "

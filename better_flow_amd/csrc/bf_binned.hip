@@ -1073,8 +1073,10 @@ __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* a
 // runs -- late, never wrong.  The predictive re-bin (drift_limit) keeps that path rare.
 // Packing: the scan sizes count << tbits | time sum for the fullest list; when even that does not fit 64 bits
 // (hot.bin_ok == 0) the tile keeps separate u64 time sums and u32 counts.
+// (pre_*: what the head's loads go through, as leading scalar arguments the command processor preloads -- see k_bin_warp_scatter)
 template <int HS, int NSUB, int U>
-__global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
+__global__ __launch_bounds__(256 * NSUB) void k_fused_pass(const uint32_t* __restrict__ pre_ftab, const DevState* pre_st_in, MomentAcc* pre_acc_in,
+                                                           const uint32_t* pre_lost, int pre_j, FusedArgs a) {
     constexpr int THREADS = 256 * NSUB;
     constexpr int TR = kTileR, TC = kTileC;
     constexpr int H = HS + 1;
@@ -1091,11 +1093,11 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     tl_stamp(a.tl, a.j, 0);
     // scalar loads first (see k_bin_warp_scatter), then the vector loads of the head, nothing consumed in between
-    const HotState h0 = sload(&a.st_in->hot);
+    const HotState h0 = sload(&pre_st_in->hot);
     // (`lost`: three words by launch number mod 3 -- this pass reads its predecessor's, raises its own, clears its
     // successor's.  One shared word was read by late work-groups of a pass AFTER early ones of the same pass had raised it.)
-    const uint32_t lost_prev = sload(a.lost + (a.j + 2) % 3);
-    const FusedTab ft = sload(reinterpret_cast<const FusedTab*>(a.ftab) + b);
+    const uint32_t lost_prev = sload(pre_lost + (pre_j + 2) % 3);
+    const FusedTab ft = sload(reinterpret_cast<const FusedTab*>(pre_ftab) + b);
     // running index -> global index: off[0] plus the offset STEPS of the ranges the index has passed.  (A chain of
     // selects among the offsets themselves was turned into a select among ADDRESSES of a scratch copy of the table: a
     // scratch load in front of every event load.)
@@ -1103,9 +1105,9 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(FusedArgs a) {
 #pragma unroll
     for (int r = 1; r < kFusedRanges; ++r) off_step[r] = ft.off[r] - ft.off[r - 1];
     unsigned long long accv[kAccPerLane];
-    if (tid < 64) acc_load_wave<false, false>(a.acc_in, tid, accv);
+    if (tid < 64) acc_load_wave<false, false>(pre_acc_in, tid, accv);
     unsigned long long state_word = 0;
-    if (tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(a.st_in)[tid];
+    if (tid < kStateWords) state_word = reinterpret_cast<const unsigned long long*>(pre_st_in)[tid];
     auto store_state = [&]() {   // work-group 0, after a barrier
         if (b == 0 && tid < kStateWords) {
             const unsigned long long v = reinterpret_cast<const unsigned long long*>(&s_state)[tid];
@@ -1849,7 +1851,7 @@ static hipError_t launch_fused2(const FusedArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         raised.fetch_or(dev_bit, std::memory_order_release);
     }
-    launch_timed(k_fused_pass<HS, NSUB, U>, dim3(a.nbr * a.nbc), dim3(256 * NSUB), lds, s, a);
+    launch_timed(k_fused_pass<HS, NSUB, U>, dim3(a.nbr * a.nbc), dim3(256 * NSUB), lds, s, a.ftab, a.st_in, a.acc_in, a.lost, a.j, a);
     return hipSuccess;
 }
 template <int HS>

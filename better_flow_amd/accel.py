@@ -113,7 +113,7 @@ EXPORTS = [
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
     "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
     "bf_upload_ring_async", "bf_upload_ring16_async", "bf_compute_uv_ring", "bf_wait_uploads", "bf_projection_img",
-    "bf_color_time_img",
+    "bf_color_time_img", "bf_eval_sincos",
 ]
 
 _lib = None
@@ -189,6 +189,7 @@ def load():
         L.bf_profile_get.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.bf_synchronize.argtypes = [C.c_void_p]
         L.bf_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+        L.bf_eval_sincos.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.bf_run_opts_default.argtypes = [C.POINTER(RunOpts)]
         L.bf_device_count.argtypes = [C.POINTER(C.c_int32)]
         L.bf_device_malloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
@@ -436,6 +437,13 @@ class Accel:
 
     def device_free(self, d):
         self._chk(self.L.bf_device_free(self.h, d))
+
+    def eval_sincos(self, x, table=False):
+        """The device loops' sin / cos (bf_eval_sincos) of the float64 array x -> (sin, cos)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        sn, cs = np.empty_like(x), np.empty_like(x)
+        self._chk(self.L.bf_eval_sincos(self.h, x.ctypes.data, x.size, 1 if table else 0, sn.ctypes.data, cs.ctypes.data))
+        return sn, cs
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=5):
         g = C.c_double(0)

@@ -96,6 +96,13 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
         c->d_stats = c->h_stats;   // k_prepare writes its per-work-group records straight into pinned host memory: no copy command
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, 2 * sizeof(DevState), c->stream));
+        // test hooks of the persistent loop kernel: read here, once (bf_run may run on several threads: no getenv there)
+        if (const char* v = getenv("BF_DEBUG_PERSIST_ABORT")) c->dbg_persist_abort = atoi(v);
+        if (const char* v = getenv("BF_DEBUG_PERSIST_MUTE")) c->dbg_persist_mute = atoi(v);
+        if (const char* v = getenv("BF_DEBUG_PERSIST_SPLIT")) {
+            c->dbg_persist_split = atoi(v);
+            c->dbg_persist_split_late = strstr(v, ",late") ? 1 : 0;
+        }
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
             HIP_TRY(c, hipMalloc(&c->d_tl, 3 * 64 * 2 * 16 * sizeof(unsigned long long)));
@@ -171,7 +178,7 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in16[i]) (void)hipFree(c->d_in16[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in_noise[i]) (void)hipFree(c->d_in_noise[i]);
-    void* bufs[] = {c->d_xrec, c->d_xred, c->d_xscratch[0], c->d_xscratch[1], c->d_xscratch[2], c->d_xscratch[3], c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
+    void* bufs[] = {c->d_xrec, c->d_xred, c->d_verdict, c->d_xscratch[0], c->d_xscratch[1], c->d_xscratch[2], c->d_xscratch[3], c->set[0].p2, c->set[1].p2, c->d_ftab, c->set[0].xy, c->set[0].t, c->set[0].p, c->set[0].perm, c->set[1].xy, c->set[1].t,
                     c->set[1].p, c->set[1].perm, c->d_binid, c->d_hist_cnt, c->d_bin_start,
                     c->d_cursor, c->d_slabs, c->d_cidx, c->d_chdr, c->d_mplane[0], c->d_mplane[1], c->d_mlist, c->d_mcount, c->d_ovf_bits[0], c->d_ovf_bits[1], c->d_armed, c->d_acc, c->d_ovf, c->d_out_tmp, c->d_lplane[0], c->d_lplane[1], c->d_lscore, c->d_limg, c->d_col_planes, c->d_col_img, c->d_tile_hist, c->d_tile_start, c->d_tile_cursor, c->d_tile_states,
                     c->d_noise, c->d_in_x, c->d_in_y, c->d_in_t, c->d_nxny,
@@ -183,6 +190,7 @@ void bf_destroy(bf_ctx* c) {
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_lscore) (void)hipHostFree(c->h_lscore);
+    if (c->h_broken) (void)hipHostFree(c->h_broken);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -211,6 +219,10 @@ int bf_get_stat(bf_ctx* c, const char* key, int64_t* value) {
         *value = (c->fused_ok && !c->opt_co_schedule && (c->opt_persist == 2 || (c->opt_persist == 1 && c->pending_warp)) &&
                   g_live_ctx[c->device & 63].load() == 1 &&
                   fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc)) ? 1 : 0;
+        return BF_OK;
+    }
+    if (!strcmp(key, "persist_giveups")) {   // launches of the persistent loop kernel that gave up and undid themselves
+        *value = c->persist_giveups;
         return BF_OK;
     }
     return fail(c, BF_ERR_ARG, "unknown statistic '%s'", key);
@@ -372,6 +384,25 @@ int bf_profile_get(bf_ctx* c, bf_profile* out) {
     if (!c || !out) return BF_ERR_ARG;
     int rc = prof_fold(c);
     *out = c->prof;
+    return rc;
+}
+
+int bf_eval_sincos(bf_ctx* c, const double* x, int64_t n, int32_t table, double* sin_out, double* cos_out) {
+    if (!c || !x || !sin_out || !cos_out || n < 0) return BF_ERR_ARG;
+    if (n == 0) return BF_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, (size_t)n * 3 * sizeof(double)));
+    int rc = [&]() -> int {
+        HIP_TRY(c, hipMemcpyAsync(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        launch_eval_sincos(d, n, table ? 1 : 0, d + n, d + 2 * n, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(sin_out, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(cos_out, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return BF_OK;
+    }();
+    (void)hipFree(d);
     return rc;
 }
 

@@ -82,8 +82,16 @@ struct bf_ctx {
     bool counted = false;            // in g_live_ctx
     int opt_persist = 1;             // 0 never, 1 for warm-started runs of the one-kernel loop on a context that is not co-scheduled, 2 cold runs too
     unsigned long long *d_xrec = nullptr, *d_xred = nullptr;   // exchange records of the sub-tiles / of the reducers (two parities each)
+    unsigned long long* d_verdict = nullptr;   // (launch id << 2) | COMMIT / ABORT of the persistent kernel's current launch (bf_loop.hip)
+    int* h_broken = nullptr;         // pinned: set by the device if a committed launch could not be read back (never observed)
     int xrec_alloc = 0;              // records per parity d_xrec holds
     float2* d_xscratch[4] = {nullptr, nullptr, nullptr, nullptr};       // private product arrays of the strips' readers
+    // a launch that gave up (something else holds part of the GPU) costs 0.2 s: the context then leaves the persistent kernel
+    // alone for persist_backoff runs (1, 2, 4, ... 64; a launch that completes resets it)
+    int persist_skip = 0, persist_backoff = 0;
+    long long persist_giveups = 0;   // bf_get_stat "persist_giveups"
+    // test hooks, read from the environment ONCE at bf_create (BF_DEBUG_PERSIST_ABORT / _MUTE / _SPLIT=<pass>[,late])
+    int dbg_persist_abort = -1, dbg_persist_mute = -1, dbg_persist_split = -1, dbg_persist_split_late = 0;
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
     uint32_t* d_armed = nullptr;

@@ -351,8 +351,9 @@ __device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_bia
 
 // sin / cos of the (small) rotation angle of the warp: Taylor polynomials in x^2 for |x| <= 0.25 (truncation below
 // 2^-64; a 30 ms slice rotates by ~1e-3), the library routine otherwise.  ~10 dependent operations instead of ~100 on
-// the one lane every iteration waits for.  Agrees with libm to <= 1 ulp (the reference calls std::cos / std::sin,
-// event.h:102-103; the stand-alone operator bf_project_4param_reinit does so too, on the host).
+// the one lane every iteration waits for.  The reference calls std::cos / std::sin (event.h:102-103; the stand-alone operator
+// bf_project_4param_reinit does so too, on the host); how far these are from the host's libm is MEASURED by
+// tests/test_gpu_parity.py::test_device_sincos_against_libm (bf_eval_sincos) and stated in DESIGN.md, "Oracle".
 // (the library routine out of line: inlined, its two dozen f64 constants are materialised -- and, in a kernel that loops,
 // hoisted into registers for the whole loop -- on a path no real slice takes)
 __device__ __attribute__((noinline)) static void sincos_large(double x, double* sn, double* cs) { sincos(x, sn, cs); }
@@ -377,7 +378,10 @@ __device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
     pc = fma(pc, z, 1.0 / 40320.0);
     pc = fma(pc, z, -1.0 / 720.0);
     pc = fma(pc, z, 1.0 / 24.0);
-    *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    // cos x = 1 - w, w = z (1/2 - z pc) <= 0.031: ONE rounding at the size of the result (w carries ~2^-52 w of its own, a
+    // twentieth of the result's ulp at most).  (1 - z/2) + z^2 pc, the form this replaces, rounded twice at that size: up to
+    // 1.008 ulp, 9 % of the results one ulp off libm's -- measured by tests/test_gpu_parity.py, round 5.)
+    *cs = 1.0 - z * fma(-z, pc, 0.5);
 }
 
 // The same polynomials with their fourteen coefficients read from a table (LDS, filled by sincos_table_fill): a kernel that
@@ -413,7 +417,7 @@ __device__ __forceinline__ void sincos_small_tab(double x, const double* tab, do
     pc = fma(pc, z, c_[11]);
     pc = fma(pc, z, c_[12]);
     pc = fma(pc, z, c_[13]);
-    *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    *cs = 1.0 - z * fma(-z, pc, 0.5);   // (see sincos_small)
 }
 
 // A uniform double out of one lane of a wave (two v_readlane_b32).

@@ -210,6 +210,11 @@ struct FusedLoopArgs {
     int debug_abort;                 // >= 0: every work-group gives up at that pass (BF_DEBUG_PERSIST_ABORT: exercises the undo + fall-back)
     int debug_mute;                  // >= 0: from that pass on the LAST work-group publishes no records, as if it had never become
                                      // resident (BF_DEBUG_PERSIST_MUTE): one reducer really times out, the others do not
+    int debug_split, debug_split_late;   // >= 0: the LAST work-group alone "times out" at that pass (BF_DEBUG_PERSIST_SPLIT=<pass>[,late];
+                                     // the host makes it the launch's last pass): at once -- its ABORT decides --, or ~100 us late --
+                                     // the others have committed and it catches up
+    unsigned long long* verdict;     // one word per context: (launch id << 2) | COMMIT / ABORT, decided by compare-and-swap
+    int* broken;                     // pinned host word, set if a committed launch's records cannot be read back (cannot happen)
 };
 hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_per_tile, int n_cus, hipStream_t s);
 // can `ntiles` work-groups of that kernel be resident at once on this device (n_cus compute units)?
@@ -242,5 +247,6 @@ void launch_color_time(const uint32_t* xy, const int32_t* t, const float2* p, co
                        hipStream_t s);
 
 void launch_copy(const void* src, void* dst, long long bytes, int blocks, bool nontemporal, hipStream_t s);
+void launch_eval_sincos(const double* x, long long n, int table, double* sn, double* cs, hipStream_t s);
 
 }  // namespace bf

@@ -466,6 +466,26 @@ void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm,
                        s, xy, p, perm, pr, n);
 }
 
+// The device loops' sin / cos of the warp's rotation angle (sincos_small; sincos_small_tab with its coefficients from an LDS
+// table, as the persistent loop kernel evaluates it), for arbitrary arguments: what bf_eval_sincos measures against libm.
+__global__ __launch_bounds__(kThreads) void k_eval_sincos(const double* __restrict__ x, long long n, int table,
+                                                          double* __restrict__ sn, double* __restrict__ cs) {
+    __shared__ double s_tab[14];
+    if (threadIdx.x == 0) sincos_table_fill(s_tab);
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        double a, b;
+        if (table) sincos_small_tab(x[i], s_tab, &a, &b);
+        else sincos_small(x[i], &a, &b);
+        sn[i] = a;
+        cs[i] = b;
+    }
+}
+void launch_eval_sincos(const double* x, long long n, int table, double* sn, double* cs, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_eval_sincos, dim3(1024), dim3(kThreads), 0, s, x, n, table, sn, cs);
+}
+
 void launch_copy(const void* src, void* dst, long long bytes, int blocks, bool nontemporal, hipStream_t s) {
     if (nontemporal)
         hipLaunchKernelGGL(k_copy_f4<true>, dim3(blocks), dim3(kThreads), 0, s, (const bf_v4f*)src, (bf_v4f*)dst, bytes / 16);

@@ -36,6 +36,12 @@
 // part of the CUs).  The launch then UNDOES itself: nobody stores products or state -- the events and the state are as the
 // launch found them --, work-group 0 only marks the state (hot.spare_ < 0: work-groups that start late leave at once), and
 // bf_run carries on with one launch per iteration.  Never a hang, never a wrong sum.
+// Whether a launch is kept or undone is ONE decision, taken by a compare-and-swap on a verdict word (verdict_decide): a
+// work-group that has timed out proposes ABORT, a work-group that is about to leave with its results proposes COMMIT, the
+// first proposal wins and everybody follows it.  (Every waiter runs its own clock: without the arbiter a record arriving
+// right at the deadline could be accepted by most work-groups and time out in one, which then stored nothing while the
+// others stored their products and the final state.)  A work-group that timed out but finds COMMIT reads the reduced records
+// again -- they exist, somebody accepted them -- and catches up.
 #include <hip/hip_runtime.h>
 #include <atomic>
 
@@ -45,6 +51,9 @@
 
 namespace bf {
 
+#ifndef BF_LOOP_U
+#define BF_LOOP_U 4   // events a thread keeps in registers (experiment builds override)
+#endif
 constexpr int kLoopReducers = 16;
 constexpr int kRecWords = 32;   // a record: 16 lanes x (payload u64, tag u64)
 
@@ -60,12 +69,28 @@ __device__ __forceinline__ bf_u32x4 xchg_load_issue(const unsigned long long* sl
     return v;
 }
 
+// The launch's verdict: one 64-bit word per context, (launch id << 2) | decision.  Launch ids grow, so the word needs no reset:
+// whoever finds an older id in it proposes; the first compare-and-swap that lands decides for everybody.
+constexpr int kVerdictCommit = 1, kVerdictAbort = 2;
+__device__ __forceinline__ int verdict_decide(unsigned long long* w, unsigned long long id /* low two bits clear */, int mine,
+                                              bool* won = nullptr) {
+    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if ((old >> 2) == (id >> 2)) return (int)(old & 3ull);
+        if (__hip_atomic_compare_exchange_strong(w, &old, id | (unsigned long long)mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+            if (won) *won = true;
+            return mine;
+        }
+    }
+}
+
 // Lane-parallel poll: every lane waits for its NS slots (16-byte units at base + 2 * idx[k]; idx < 0: no slot) to carry
 // `tag`, all of a wave's loads in flight together, the whole wave retrying until every lane is served.  Returns the sum of
 // the payloads; false on time-out.
 template <int NS>
 __device__ __forceinline__ bool xchg_poll_sum(const unsigned long long* base, const int (&idx)[NS], unsigned long long tag,
-                                              unsigned long long& sum) {
+                                              unsigned long long& sum, unsigned long long limit = 20000000ull /* 0.2 s of the 100 MHz clock */) {
     bf_u32x4 v[NS];
     unsigned long long t0 = 0;
     for (unsigned tries = 0;; ++tries) {
@@ -85,7 +110,7 @@ __device__ __forceinline__ bool xchg_poll_sum(const unsigned long long* base, co
         __builtin_amdgcn_s_sleep(2);   // (~50 ns: a poller must not crowd the memory side the records travel through)
         if (tries >= 32u) {
             if (tries == 32u) t0 = wall_clock64();
-            else if ((tries & 255u) == 0u && wall_clock64() - t0 > 20000000ull) return false;   // 0.2 s of the 100 MHz clock
+            else if ((tries & 255u) == 0u && wall_clock64() - t0 > limit) return false;
         }
     }
     unsigned long long s = 0;
@@ -156,7 +181,11 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     float2* const p_cur = lds_sreg(&s_state.hot.pp) ? ev.p2 : ev.p;
     const int br = b / a.nbc, bc = b - br * a.nbc;
     const int X0 = br * TSR - H, Y0 = bc * TC - H;
+#ifdef BF_PROTO_OWNONLY   // timing prototype: the tile's own events only (WRONG sums: the neighbours' strips are missing)
+    const uint32_t M = ft.pre[1], own = ft.pre[1];
+#else
     const uint32_t M = ft.total, own = ft.pre[1];
+#endif
     const bool single = M <= (uint32_t)(THREADS * U);   // the whole list lives in registers
     uint32_t vxy[U], vi[U];
     int32_t vt[U];
@@ -201,6 +230,8 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     const int g = tid >> 8, lt = tid & 255;
     const int r0 = br * TSR + g * TR, c0 = bc * TC;
     const unsigned long long run_hi = (unsigned long long)(unsigned int)s_state.run_tag << 32;
+    // this launch's id in the verdict word: (run, launches of the kernel completed in this run); low two bits: the decision
+    const unsigned long long launch_id = run_hi | ((unsigned long long)((unsigned int)s_state.hot.spare_ & 0x3fffffffu) << 2);
     int j = s_state.last_j + 1;
     bool first_of_run = s_state.last_j < 0;
     int passes = 0;
@@ -371,8 +402,9 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             // every work-group's first wave (they look at the reduced records every microsecond, at their own clock only
             // every few hundred) -- an update on wrong sums.  Without the record they all time out as well and the launch
             // undoes itself as a whole.
+            // (It does not decide anything either: this work-group's first wave waits for the same missing record and proposes
+            // the ABORT.)
             const bool timed_out = __ballot(!good) != 0ull;
-            if (timed_out) s_abort = 1;
             if (lane < 16 && !timed_out) xchg_store(red + (size_t)b * kRecWords + 2 * lane, tot, tag);
         }
         // ---- wave 0: the reduced records -> the total of field lane % 16 in every lane; the update ----
@@ -387,11 +419,36 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             unsigned long long word = 0;
             bool good = xchg_poll_sum<4>(red, idx, tag, word);
             if (a.debug_abort >= 0 && j >= a.debug_abort) good = false;   // (test hook: every work-group "times out" at that pass)
+            if (a.debug_split >= 0 && j == a.debug_split && b == ntiles - 1) {   // (test hook: ONE work-group "times out" on the launch's
+                good = false;                                                    //  last pass -- at once, or when the others have committed)
+                if (a.debug_split_late)
+                    for (int q = 0; q < 64; ++q) __builtin_amdgcn_s_sleep(64);   // ~100 us
+            }
             tl_stamp(a.tl, j, 9);
+            bool aborted = false;
+            if (!good) {
+                // Timed out on this work-group's own clock.  ABORT -- unless the launch has been COMMITted meanwhile: then the
+                // reduced records of this pass exist (whoever committed had accepted them) and are read again.
+                int v = 0;
+                if (tid_ == 0) {
+                    bool won = false;
+                    v = verdict_decide(a.verdict, launch_id, kVerdictAbort, &won);
+                    if (won) {   // the mark, in both state buffers: work-groups that start late leave at entry, the host falls back
+                        __hip_atomic_store(&a.st->hot.spare_, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&a.st_other->hot.spare_, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                v = __builtin_amdgcn_readfirstlane(v);
+                if (v == kVerdictCommit) {
+                    good = xchg_poll_sum<4>(red, idx, tag, word, 400000000ull);   // (4 s: cannot fail -- if it does, say so loudly)
+                    if (!good && tid_ == 0 && a.broken) *reinterpret_cast<volatile int*>(a.broken) = 1;
+                }
+                aborted = !good;
+            }
             word += __shfl_xor(word, 16, 64);
             word += __shfl_xor(word, 32, 64);
             const bool lost = lane_i64(word, 15) != 0;
-            if (!good) {
+            if (aborted) {
                 if (tid_ == 0) { s_abort = 1; }
             } else if (lost) {   // sums of a pass that cannot vouch for them: dropped; the pass is repeated on fresh bins
                 if (tid_ == 0) {
@@ -415,6 +472,12 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             tl_stamp(a.tl, j, 10);
             if (tid_ == 0) {
                 const bool out = s_abort || s_state.hot.done || s_state.hot.need_rebin || passes + 1 >= a.max_passes;
+                // leaving with results: COMMIT the launch -- or learn that somebody has given up on it
+                if (out && !s_abort) {
+                    if (a.debug_split >= 0 && !a.debug_split_late && j == a.debug_split && b != ntiles - 1)
+                        for (int q = 0; q < 64; ++q) __builtin_amdgcn_s_sleep(64);   // (test hook: the straggler's ABORT lands first)
+                    if (verdict_decide(a.verdict, launch_id, kVerdictCommit) != kVerdictCommit) s_abort = 1;
+                }
                 s_exit = out ? 1 : 0;
                 s_lost = 0;
                 if (b == 0 && a.snap && !out) {   // progress for the host's watchdog: (done, it), one 8-byte store
@@ -432,13 +495,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
         if (s_exit) break;
     }
     // ---- exit: the owners' products, then the state -- unless the launch gave up: then nothing is stored ----
-    if (s_abort) {
-        if (b == 0 && tid == 0) {   // the mark, in both state buffers: work-groups that start late leave at entry
-            __hip_atomic_store(&a.st->hot.spare_, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.st_other->hot.spare_, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
+    if (s_abort) return;   // (whoever's ABORT decided the launch has marked the state: hot.spare_ < 0)
     if (single && M) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
@@ -462,7 +519,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
 // Raises the dynamic-LDS limit of one instantiation (once per device) and returns how many of its work-groups fit a CU.
 template <int HS, int NSUB>
 static hipError_t loop_setup(int* per_cu, size_t* lds_out) {
-    constexpr int U = 4;
+    constexpr int U = BF_LOOP_U;
     constexpr int H = HS + 1, AR = 16 * NSUB + 2 * H, AC = kTileC + 2 * H;
     constexpr size_t lds = (size_t)AR * AC * 12 + (size_t)NSUB * (kTileR + 2) * (kTileC + 2) * 4;
     const void* fn = reinterpret_cast<const void*>(&k_fused_loop<HS, NSUB, U>);
@@ -497,7 +554,7 @@ static hipError_t launch_loop2(const FusedLoopArgs& a, int n_cus, hipStream_t s)
     // A plain launch: the grid was checked against the occupancy query above, which is all hipLaunchCooperativeKernel adds
     // (at 15-19 us of host time per launch on this stack); residency is the same either way, and should the hardware admit
     // fewer work-groups than the query says, the kernel's waiters time out and the launch undoes itself.
-    hipLaunchKernelGGL((k_fused_loop<HS, NSUB, 4>), dim3(ntiles), dim3(256 * NSUB), lds, s, a);
+    hipLaunchKernelGGL((k_fused_loop<HS, NSUB, BF_LOOP_U>), dim3(ntiles), dim3(256 * NSUB), lds, s, a);
     return hipGetLastError();
 }
 template <int HS>

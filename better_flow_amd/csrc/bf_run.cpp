@@ -69,9 +69,12 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // a host round trip (measured on 50 000 events, 240x180: 25 us per iteration against 17); a warm-started slice of a stream
     // -- the reference's own mode, ~115 iterations and one or two re-bins -- is where it pays (11.1 against 12.2 us per
     // iteration all in): "auto" takes it for warm starts.
-    const bool persist = fused && !c->opt_co_schedule && (c->opt_persist == 2 || (c->opt_persist == 1 && c->pending_warp)) &&
-                         g_live_ctx[c->device & 63].load() == 1 &&
-                         fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc);   // (else: one launch per iteration)
+    bool persist = fused && !c->opt_co_schedule && (c->opt_persist == 2 || (c->opt_persist == 1 && c->pending_warp)) &&
+                   g_live_ctx[c->device & 63].load() == 1 &&
+                   fused_loop_resident(c->win.scale / 2, c->fgrid.TSR, c->n_cus, c->fgrid.nbr * c->fgrid.nbc);   // (else: one launch per iteration)
+    // (g_live_ctx only knows this process: another process's kernels -- or anything else that keeps work-groups from becoming
+    // resident -- shows as a launch that gives up after 0.2 s.  The context then stays away from the kernel for a while.)
+    if (persist && c->persist_skip > 0) { --c->persist_skip; persist = false; }
     DevState& h = c->hst;
     // Tile-binned mode sorts the events by the tile of their CURRENT target, so a warm-start
     // warp (bf_set_model) is applied before the sort rather than inside the first iteration.
@@ -94,6 +97,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     h.hot.rebins = 0; h.ovf_total = 0;
     h.hot.cs = c->cs; h.hot.flip = 0;
     h.hot.pp = 0; h.hot.redo = 0; h.hot.pend = 0; h.last_j = -1;
+    h.hot.spare_ = 0;   // launches of the persistent loop kernel completed in THIS run (with run_tag: the launch's id)
     // (the persistent loop re-bins AT the request -- it returns for it --, the other loops one or two batches of launches
     // after it: the same effective threshold)
     if (binned) h.drift_limit = c->opt_bin_predict ? (persist ? 0.85 : 0.6) * (double)(fused ? c->fgrid.D : c->grid.D) : 1e300;
@@ -182,11 +186,21 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             HIP_TRY(c, hipMemsetAsync(c->d_xrec, 0, (size_t)2 * (size_t)nrec * 32 * sizeof(unsigned long long), c->stream));
             c->xrec_alloc = nrec;
         }
+        // (each buffer under its own check: an allocation that fails half-way must not leave the others looking ready)
         if (!c->d_xred) {
             HIP_TRY(c, hipMalloc(&c->d_xred, (size_t)2 * 16 * 32 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemsetAsync(c->d_xred, 0, (size_t)2 * 16 * 32 * sizeof(unsigned long long), c->stream));
-            for (int i = 0; i < 4; ++i) HIP_TRY(c, hipMalloc(&c->d_xscratch[i], (size_t)c->cap_events * sizeof(float2)));
         }
+        if (!c->d_verdict) {
+            HIP_TRY(c, hipMalloc(&c->d_verdict, 64));
+            HIP_TRY(c, hipMemsetAsync(c->d_verdict, 0, 64, c->stream));
+        }
+        if (!c->h_broken) {
+            HIP_TRY(c, hipHostMalloc(&c->h_broken, 64, hipHostMallocDefault));
+            *c->h_broken = 0;
+        }
+        for (int i = 0; i < 4; ++i)
+            if (!c->d_xscratch[i]) HIP_TRY(c, hipMalloc(&c->d_xscratch[i], (size_t)c->cap_events * sizeof(float2)));
     }
     bool want_rebin = false;
     int last_rebin_at = 0;
@@ -224,10 +238,13 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         la.max_passes = 4096;
         la.first_warp = first_warp ? 1 : 0;
         la.tl = c->d_tl;
-        const char* dbg_abort = getenv("BF_DEBUG_PERSIST_ABORT");   // (test hook, read per launch: tests set and clear it)
-        la.debug_abort = dbg_abort ? atoi(dbg_abort) : -1;
-        const char* dbg_mute = getenv("BF_DEBUG_PERSIST_MUTE");
-        la.debug_mute = dbg_mute ? atoi(dbg_mute) : -1;
+        la.verdict = c->d_verdict; la.broken = c->h_broken;
+        la.debug_abort = c->dbg_persist_abort; la.debug_mute = c->dbg_persist_mute;   // (test hooks: bf_create read the environment)
+        la.debug_split = -1; la.debug_split_late = c->dbg_persist_split_late;
+        if (c->dbg_persist_split >= 0) {   // that pass of THIS launch, made its last one
+            la.debug_split = launched_iters + c->dbg_persist_split;
+            la.max_passes = c->dbg_persist_split + 1;
+        }
         prewarp_done = true;
         {
             ProfScope ps(c, 0, c->n);
@@ -258,11 +275,18 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         if (host_timing && batch < 40)
             fprintf(stderr, "persist round %d: it %d done %d need_rebin %d redo %d last_j %d rebins %d rc %d launches %d ovf_total %u\n", batch, ws.hot.it,
                     ws.hot.done, ws.hot.need_rebin, ws.hot.redo, ws.last_j, ws.hot.rebins, ws.rc, ws.hot.spare_, ws.ovf_total);
+        if (*reinterpret_cast<volatile int*>(c->h_broken)) {
+            *c->h_broken = 0;
+            return fail(c, BF_ERR_HIP, "persistent loop kernel: a committed launch could not be read back");
+        }
         if (ws.hot.spare_ < 0) {
             // The launch gave up (a work-group waited 0.2 s for others that were not resident: something else holds part of
             // the GPU) and undid itself: events and state are as it found them.  The rest of the run takes one launch per
             // iteration.
             persist_gave_up = true;
+            c->persist_giveups++;
+            c->persist_backoff = c->persist_backoff ? (c->persist_backoff < 64 ? 2 * c->persist_backoff : 64) : 1;
+            c->persist_skip = c->persist_backoff;
             if (host_timing) fprintf(stderr, "persistent loop kernel gave up in round %d (last_j %d): falling back to one launch per iteration\n", batch, ws.last_j);
             first = ws.last_j < 0;
             h.hot.spare_ = 0;
@@ -277,7 +301,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         }
         if (batch > 100000) return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
     }
-    (void)persist_gave_up;
+    if (persist && !persist_gave_up) c->persist_backoff = 0;   // (a run that went through: the next give-up starts at one run again)
     const bool persist_ran = final_done;
     const bool snap_polled = binned && !quick_warm && !persist_ran;   // progress is read from the pinned snapshot (below)
     if (snap_polled) {

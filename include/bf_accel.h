@@ -222,6 +222,10 @@ int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
  *                     lists, 3 own pixels + margin plane ("bin_split"); -1 when the slice does not take that loop.
  *   "one_kernel"      1 when bf_run would take the one-kernel iteration for the slice staged now, else 0.
  *   "persistent"      1 when bf_run, called now, would run it as the persistent kernel ("persist"), else 0.
+ *   "persist_giveups" launches of the persistent kernel on this context that gave up (a work-group waited 0.2 s for others
+ *                     that were not resident: something else holds part of the GPU) and undid themselves; the run they
+ *                     belonged to went on with one launch per iteration, and the context leaves the kernel alone for the
+ *                     next 1, 2, 4 ... 64 runs.
  * BF_ERR_ARG for an unknown key. */
 int bf_get_stat(bf_ctx *ctx, const char *key, int64_t *value);
 
@@ -476,6 +480,13 @@ int bf_synchronize(bf_ctx *ctx);
  * with a float4 kernel and returns the best GB/s (read + write counted).  Used by
  * bench.py to report the measured HBM ceiling next to the 8 TB/s nominal peak. */
 int bf_copy_bandwidth(bf_ctx *ctx, int64_t bytes, int32_t reps, double *gbps_out);
+
+/* No reference counterpart.  The sine and cosine the device loops use for the warp's rotation angle
+ * (Event::project_4param_reinit evaluates std::cos / std::sin, event.h:102-103; bf_run's update computes them on the device:
+ * a polynomial for |x| <= 0.25, the device library beyond), evaluated for `n` host arguments.  table != 0: the variant of the
+ * persistent loop kernel, coefficients read from an LDS table -- the same operations in the same order.  For measuring the
+ * distance to the host's libm (tests/test_gpu_parity.py; the bound is stated in DESIGN.md, "Oracle"). */
+int bf_eval_sincos(bf_ctx *ctx, const double *x, int64_t n, int32_t table, double *sin_out, double *cos_out);
 
 #ifdef __cplusplus
 }

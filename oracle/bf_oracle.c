@@ -364,6 +364,15 @@ void bfo_compute_uv(const double *nx, const double *ny, int64_t n, double *u, do
     }
 }
 
+/* The std::cos / std::sin of Event::project_4param_reinit (event.h:102-103) as this host's libm evaluates them, for `n`
+ * arguments: the yardstick of tests/test_gpu_parity.py for the device loops' own sine / cosine. */
+void bfo_sincos(const double *x, int64_t n, double *sn, double *cs) {
+    for (int64_t i = 0; i < n; ++i) {
+        sn[i] = sin(x[i]);
+        cs[i] = cos(x[i]);
+    }
+}
+
 
 /* ===================== OptimizerLocal: the contrast-score optimiser ===================== */
 

@@ -122,6 +122,9 @@ int bfo_run(bfo_cloud *ev, const bfo_window *w, bfo_model *m, int32_t max_iterco
 /* event.h:135-142 */
 void bfo_compute_uv(const double *nx, const double *ny, int64_t n, double *u, double *v);
 
+/* std::sin / std::cos of event.h:102-103 on this host's libm */
+void bfo_sincos(const double *x, int64_t n, double *sn, double *cs);
+
 
 /* ---- Contrast-score optimiser: OptimizerLocal (optimizer_sampler.h:12-68, optimizer_sampler.cpp) ----
  * PARITY UNPINNED for the blur stage: the reference calls cv::GaussianBlur(CV_8UC1, ksize = scale,

@@ -5,7 +5,7 @@ import sys, os, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["BF_TIMELINE"] = "/tmp/bf_tl.txt"
-os.environ["BF_ACCEL_LIB"] = os.path.join(ROOT, "better_flow_amd", "libbf_accel_tl.so")
+os.environ["BF_ACCEL_LIB"] = os.environ.get("BF_TL_LIB", os.path.join(ROOT, "better_flow_amd", "libbf_accel_tl.so"))
 from better_flow_amd import accel, synth
 N, H, W = int(os.environ.get("BF_RUN_N", "50000")), int(os.environ.get("BF_RUN_H", "180")), int(os.environ.get("BF_RUN_W", "240"))
 s = int(os.environ.get("BF_RUN_S", "3"))
@@ -15,7 +15,7 @@ acc.set_option("fused", 2)
 for k, v in [a.split("=") for a in sys.argv[1:]]:
     acc.set_option(k, int(v))
 opts = acc.default_opts(); opts.res_x, opts.res_y = H, W
-opts.max_iter = 200
+opts.max_iter = int(os.environ.get("BF_RUN_MAXITER", "200"))
 acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]); acc.set_cloud(s, H, W)
 rc, m, info = acc.run(opts)
 print("iterations", info.iterations, "launches", info.launches, "re-bins", info.rebins)

@@ -218,6 +218,14 @@ class Cloud:
         return u, v
 
 
+def sincos(x):
+    """std::sin / std::cos (event.h:102-103) of the float64 array x on this host's libm -> (sin, cos)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    sn, cs = np.empty_like(x), np.empty_like(x)
+    lib().bfo_sincos(_p(x, C.c_double), C.c_int64(x.size), _p(sn, C.c_double), _p(cs, C.c_double))
+    return sn, cs
+
+
 def center_of_mass(img):
     img = np.ascontiguousarray(img, dtype=np.float32)
     m = Model()

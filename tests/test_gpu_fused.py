@@ -33,9 +33,11 @@ def run(accel_mod, sl, H, W, s, opts, max_iter=-1):
     rc2, m2, info2 = a.run(o)
     trace2 = [t.model.as_dict() for t in a.get_trace(4096)]
     u2, v2 = a.compute_uv()
+    giveups = a.get_stat("persist_giveups")
     a.close()
     return dict(rc=(rc, rc2), it=(info.iterations, info2.iterations), model=(m.as_dict(), m2.as_dict()), trace=(trace, trace2),
-                flow=(u.tobytes(), v.tobytes(), u2.tobytes(), v2.tobytes()), rebins=info.rebins, launches=info.launches, persistent=persistent)
+                flow=(u.tobytes(), v.tobytes(), u2.tobytes(), v2.tobytes()), rebins=info.rebins, launches=info.launches, persistent=persistent,
+                giveups=giveups)
 
 
 VARIANTS = (("default margin", {}), ("persistent kernel", {"persist": 2}), ("persistent kernel, margin 2", {"persist": 2, "fused_margin": 2}),
@@ -120,5 +122,24 @@ def test_persistent_kernel_that_gives_up_undoes_itself(accel_mod):
             finally:
                 del os.environ["BF_DEBUG_PERSIST_MUTE"]
             assert got["launches"] > ref["it"][0] // 2, "the fall-back (one launch per iteration) must have run"
+            assert got["giveups"] >= 1
             for key in ("rc", "it", "model", "trace", "flow"):
                 assert got[key] == ref[key], (n, "mute", at, key)
+        # ... and the split decision: ONE work-group alone times out on a launch's LAST pass (BF_DEBUG_PERSIST_SPLIT=<pass>: every
+        # launch ends after that many passes), the others do not.  Keeping or undoing the launch is one compare-and-swap on
+        # the verdict word (bf_loop.hip: verdict_decide).  At once: its ABORT lands before the others' COMMIT, everybody
+        # undoes, the fall-back runs.  Late (~100 us): the others have committed, the straggler reads the reduced records
+        # again and leaves with them -- no give-up, and no work-group that silently kept its pre-launch products.
+        for spec, undone in (("7", True), ("7,late", False), ("0,late", False)):
+            os.environ["BF_DEBUG_PERSIST_SPLIT"] = spec
+            try:
+                got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2})
+            finally:
+                del os.environ["BF_DEBUG_PERSIST_SPLIT"]
+            assert got["persistent"] == 1
+            if undone:
+                assert got["giveups"] >= 1 and got["launches"] > ref["it"][0] // 2, (spec, got["giveups"], got["launches"])
+            else:
+                assert got["giveups"] == 0, (spec, got["giveups"])
+            for key in ("rc", "it", "model", "trace", "flow"):
+                assert got[key] == ref[key], (n, "split", spec, key)

@@ -1248,3 +1248,55 @@ def test_run_many_equals_one_by_one(accel_mod):
             assert np.array_equal(u, want[3]) and np.array_equal(v, want[4])
         a.close()
     assert [w[0] for w in alone] == [0, 0, 1]
+
+
+def test_device_sincos_against_libm(oracle_lib, accel_mod):
+    """The device loops evaluate the sine and cosine of the warp's rotation angle themselves (bf_device_fns.h: sincos_small,
+    a polynomial for |x| <= 0.25, the device library beyond; sincos_small_tab in the persistent kernel), where the reference
+    calls std::cos / std::sin (event.h:102-103) -- the stand-alone operator bf_project_4param_reinit takes them from the
+    host, so the bit-exact warp test above never sees the polynomial.  Here it is evaluated on the device (bf_eval_sincos) for
+    1.3 million angles -- dense where a 30 ms slice's rotation lives (|x| <= 2e-3), log-spaced down to 1e-12, sparse up to 0.3
+    with the 0.25 switch-over bracketed, a few large ones -- and held against this host's libm (through the oracle library) and
+    against the 80-bit long-double value: error in ulps of the true result, and the share of results equal to libm's bits.
+    The measured figures are printed and stated in DESIGN.md, "Oracle"."""
+    rng = np.random.default_rng(17)
+    x = np.concatenate([
+        rng.uniform(-2e-3, 2e-3, 1000000),
+        np.sign(rng.uniform(-1, 1, 100000)) * 10.0 ** rng.uniform(-12, -2.5, 100000),
+        rng.uniform(-0.3, 0.3, 150000),
+        0.25 + np.arange(-2000, 2001) * np.spacing(0.25), -0.25 + np.arange(-2000, 2001) * np.spacing(0.25),
+        np.array([0.0, -0.0, 0.25, -0.25, 0.2500000000000001, 1.0, -1.0, 3.0, 10.0, 1e3, 1e6, np.pi, np.pi / 2, 5e-324, 1e-300]),
+    ])
+    assert x.size >= 1000000
+    lsn, lcs = oracle_lib.sincos(x)
+    xl = x.astype(np.longdouble)
+    tsn, tcs = np.sin(xl), np.cos(xl)
+
+    def ulp_err(got, true):
+        ulp = np.spacing(np.abs(true.astype(np.float64))).astype(np.longdouble)
+        return np.abs(got.astype(np.longdouble) - true) / ulp
+    small, poly = np.abs(x) <= 2e-3, np.abs(x) <= 0.25
+    acc = accel_mod.Accel(device=0, max_events=4096, max_rows=64, max_cols=64)
+    try:
+        out = [acc.eval_sincos(x, table=t) for t in (False, True)]
+    finally:
+        acc.close()
+    for table, (dsn, dcs) in zip((False, True), out):
+        es, ec = ulp_err(dsn, tsn), ulp_err(dcs, tcs)
+        eq_s, eq_c = dsn == lsn, dcs == lcs
+        ds, dc = np.abs(dsn.view(np.int64) - lsn.view(np.int64)), np.abs(dcs.view(np.int64) - lcs.view(np.int64))
+        print("device sin / cos (%s), %d angles: max error %.3f / %.3f ulp at x = %.17g / %.17g (polynomial range |x| <= 0.25: %.3f / %.3f; "
+              "this host's libm: %.3f / %.3f); results equal to libm's bits: %.4f %% / %.4f %% (|x| <= 2e-3: %.4f %% / %.4f %%); "
+              "largest distance to libm %d / %d ulp" %
+              ("LDS table" if table else "immediates", x.size, es.max(), ec.max(), x[es.argmax()], x[ec.argmax()],
+               es[poly].max(), ec[poly].max(), ulp_err(lsn, tsn).max(), ulp_err(lcs, tcs).max(),
+               100.0 * eq_s.mean(), 100.0 * eq_c.mean(), 100.0 * eq_s[small].mean(), 100.0 * eq_c[small].mean(), int(ds.max()), int(dc.max())))
+        # the polynomial range (every real slice: a 30 ms slice rotates by ~1e-3): within 0.6 ulp of the true value, at most one
+        # ulp from libm, and libm's own bits for >= 99 % of the angles a slice can produce
+        assert es[poly].max() <= 0.6 and ec[poly].max() <= 0.6, (es[poly].max(), ec[poly].max())
+        assert ds[poly].max() <= 1 and dc[poly].max() <= 1
+        assert eq_s[small].mean() >= 0.99 and eq_c[small].mean() >= 0.99, (eq_s[small].mean(), eq_c[small].mean())
+        # beyond it (a diverged model): the device library's sincos, <= 2 ulp
+        assert es.max() <= 2.0 and ec.max() <= 2.0 and ds.max() <= 2 and dc.max() <= 2
+        if table:   # the persistent kernel's variant: the same operations in the same order
+            assert np.array_equal(dsn, out[0][0]) and np.array_equal(dcs, out[0][1])

@@ -106,13 +106,18 @@ def main():
     ap.add_argument("--no-front-end", action="store_true", help="skip the command-line front-end measurement")
     ap.add_argument("--front-end-slices", type=int, default=20, help="rolling slices in the front-end measurement's event file")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
-                    help="bf_set_option knob for every context (experiments), e.g. --opt bin_threads=512")
+                    help="bf_set_option knob for every context (experiments), e.g. --opt bin_split=2")
     ap.add_argument("--cpu-iters", type=int, default=0,
                     help="iteration_steps of the CPU baseline's sample; 0 (default): the whole cold run, to the loop's own termination "
                          "(~530 iterations, 10-40 s on one host core)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="cap on the host cores of the slice-parallel CPU figure")
     ap.add_argument("--farm-slices", type=int, default=512,
-                    help="--config 5: independent slices (seeds 0 .. n-1) farmed over the ranks, slice i -> rank i %% N")
+                    help="--config 5: independent slices (seeds 0 .. n-1) farmed over the ranks: every slice context of every rank "
+                         "claims its next slice from one shared queue")
+    ap.add_argument("--farm-static", action="store_true", help="--config 5: the round robin slice i -> rank i %% N instead (A/B)")
+    ap.add_argument("--farm-costs", default=None, metavar="JSON",
+                    help="--config 5: a previous run's JSON line (its config.per_slice.iterations): slices are handed out longest first")
+    ap.add_argument("--farm-record", default=None, metavar="PATH", help="--config 5: also write the JSON line to this file")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than visible devices (rank r on device r %% devices): tests only")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
@@ -176,20 +181,36 @@ def main():
         raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible (one rank per GPU; --oversubscribe "
                          "shares devices, for tests)" % (world, ndev))
     device = local_rank % ndev
+    # this rank next to its GPU: the CPUs (and preferred memory) of the device's host NUMA node -- every thread started from here
+    # inherits the binding, every pinned buffer allocated from here on is first touched there (SURVEY 8(e)'s caveat)
+    affinity_at_start = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa_node = accel.bind_thread_to_device_numa(device)
     if args.config == 5:
         # BASELINE config 5 as specified: a batch of independent cold slices (seeds 0 .. n-1) at 1280x720 farmed over the
         # ranks (slice i -> rank i % N, --concurrent slice contexts per rank, models gathered on every rank; no data-path
         # collective).  One timed pass over the whole batch; --steps / --warmup do not apply.
         from better_flow_amd import farm
         specs = [farm.SliceSpec(i, H, W, events=args.events, seed=i) for i in range(args.farm_slices)]
+        if args.farm_costs:   # iteration counts of an earlier run of the same batch: longest first
+            with open(args.farm_costs) as f:
+                prev_its = json.loads(f.read().strip().splitlines()[-1])["config"]["per_slice"]["iterations"]
+            for sp_, it_ in zip(specs, prev_its):
+                sp_.cost = it_
         warm = [farm.SliceSpec(-1 - rank, H, W, events=args.events, seed=100000 + rank)]   # allocations, code objects
         farm.run_farm(warm, rank=0, world=1, device=device, concurrent=1, scale=s, max_iter=3)
-        farm.prepare(specs, rank=rank, world=world)   # the slices' arrays exist before the clock starts; the lanes move + solve
+        # the slices' arrays exist before the clock starts; the lanes move + solve.  Several ranks: any rank may claim any slice,
+        # so each rank leaves the slices it generated where the others can map them (16 B per event under /dev/shm)
+        share_dir = None
+        if world > 1 and not args.farm_static:
+            share_dir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bf_farm_%s" % os.environ.get("MASTER_PORT", "0"))
+            os.makedirs(share_dir, exist_ok=True)
+        farm.prepare(specs, rank=rank, world=world, share_dir=share_dir)
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         merged = farm.run_farm(specs, rank=rank, world=world, device=device, concurrent=max(1, args.concurrent), scale=s,
-                               dist=dist, options={k_: int(v_) for k_, v_ in (o_.split("=") for o_ in args.opt)})
+                               dist=dist, options={k_: int(v_) for k_, v_ in (o_.split("=") for o_ in args.opt)},
+                               static=args.farm_static)
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -198,22 +219,44 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt[0])
+        if share_dir is not None:
+            if dist is not None:
+                dist.barrier()
+            if rank == 0:
+                import shutil
+                shutil.rmtree(share_dir, ignore_errors=True)
         if rank == 0:
             assert sorted(merged) == list(range(args.farm_slices))
             ev = sum(r["events"] for r in merged.values())
-            its = [r["iterations"] for r in merged.values()]
-            print(json.dumps({
+            its = [merged[i]["iterations"] for i in range(args.farm_slices)]
+            bal = farm.balance(merged, world)
+            line = json.dumps({
                 "metric": METRIC, "value": ev / elapsed / 1e6, "unit": "Mevents/s", "n_gpus": world, "steps": 1, "warmup": 0,
                 "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "BASELINE config 5: batch of %d independent %d-event 30 ms slices at %dx%d, scale %d, "
-                                       "cold start to the reference loop's own termination, farmed slice i -> rank i %% %d"
-                                       % (args.farm_slices, args.events, W, H, s, world),
+                                       "cold start to the reference loop's own termination, %s"
+                                       % (args.farm_slices, args.events, W, H, s,
+                                          ("farmed slice i -> rank i %% %d" % world) if args.farm_static else
+                                          ("every slice context of the %d rank(s) claims its next slice from one shared queue%s"
+                                           % (world, ", longest first by a previous run's iteration counts" if args.farm_costs else ""))),
                            "slices": args.farm_slices, "slices_failed": sum(1 for r in merged.values() if r["rc"] != 0),
                            "iterations_per_slice_mean": sum(its) / len(its), "iterations_per_slice_max": max(its),
                            "ms_per_slice_mean": sum(r["ms"] for r in merged.values()) / len(merged),
-                           "parallelism": "slice-parallel: %d GPU(s) x %d slice contexts, no collectives" % (world, args.concurrent)},
-            }))
+                           "parallelism": "slice-parallel: %d GPU(s) x %d slice contexts, no collectives" % (world, args.concurrent),
+                           # per rank: seconds from the start to its last slice, slices taken; imbalance = slowest rank / mean
+                           "ranks": {"busy_s": bal["busy_s"], "slices": bal["slices"], "imbalance": bal["imbalance"],
+                                     "numa_node_of_rank0": numa_node},
+                           # ms: upload issue (under the lane's previous solve) -> model; solve_ms: the lane's own time for the slice
+                           "per_slice": {"iterations": its, "ms": [round(merged[i]["ms"], 3) for i in range(args.farm_slices)],
+                                         "solve_ms": [round(merged[i]["solve_ms"], 3) for i in range(args.farm_slices)],
+                                         "rank": [merged[i]["rank"] for i in range(args.farm_slices)],
+                                         "t_done_s": [round(merged[i].get("t1", 0.0), 4) for i in range(args.farm_slices)]}},
+            })
+            print(line)
+            if args.farm_record:
+                with open(args.farm_record, "w") as f:
+                    f.write(line + "\n")
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -483,22 +526,11 @@ def main():
             p_ = acc.profile_get()
             acc.profile_enable(0)
             return p_, live_, live_ev_iters_
-        # The kernel's launch SHAPE is chosen for the regime: contexts that share the GPU run 512-thread work-groups (a
-        # 1024-thread group waits for half a CU's wave slots under contention), a context alone 1024-thread ones (8.0
-        # against 9.0 us per launch when nothing else runs).  The roofline is the kernel's, measured alone: in the shape
-        # that is right for a kernel running alone -- and, next to it, in the co-scheduled shape.
-        explicit_shape = any(kv.startswith("bin_threads=") for kv in args.opt)
-        shared_shape = None
-        if B > 1 and not explicit_shape:
-            ps_, ls_, le_ = k_profile()
-            shared_shape = {"work_group": 512, "avg_launch_us": 1e3 * ps_.warp_scatter_ms / max(1, ls_),
-                            "frac": K1_BYTES_PER_EVENT_ITER * (le_ / max(1, ls_)) / (ps_.warp_scatter_ms * 1e-3 / max(1, ls_)) / 1e9 / HBM_PEAK_GBPS,
-                            "stencil_us": 1e3 * ps_.stencil_ms / max(1, ls_),
-                            "note": "the shape the headline regime launches (several contexts per GPU), measured with the GPU to itself"}
-            acc.set_option("bin_threads", 1024)
+        # The kernel's launch shape follows the regime (bf_run): contexts that share the GPU run the lean kernel with 512-thread
+        # work-groups (a 1024-thread group waits for half a CU's wave slots under contention), a context alone the head-update
+        # kernel with 1024-thread ones.  The roofline below is the headline regime's own variant, measured with the GPU to
+        # itself; the other variant is `context_alone_form`.
         p, live, live_ev_iters = k_profile()
-        if B > 1 and not explicit_shape:
-            acc.set_option("bin_threads", 0)
         # ... and the form the same context takes when it really is alone (no co_schedule): update at the head of the
         # scatter kernel, no serial tail in the stencil kernel
         alone_form = None
@@ -524,14 +556,14 @@ def main():
         # scripts/collect_r4.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  null if not collected
         # or not for this workload.
-        # (keyed by geometry AND kernel variant: the line names the 1024-thread lean kernel when several contexts share the
-        # GPU, the head-update kernel for one context -- the counters must be that variant's)
+        # (keyed by geometry AND kernel variant: the line names the 512-thread lean kernel when several contexts share the
+        # GPU, the 1024-thread head-update kernel for one context -- the counters must be that variant's)
         traffic = traffic_kernel = stencil_traffic = None
         tj = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tj) and args.events == 1000000:
             tjd = json.load(open(tj))
             key = "%dx%dx%d" % (W, H, s)
-            t_ = tjd.get(key + ("_lean1024" if B > 1 else "_head1024")) or tjd.get(key)
+            t_ = tjd.get(key + ("_lean512" if B > 1 else "_head1024"))
             if t_:
                 traffic = (2.0 * t_["fetch_kb"] + t_["write_kb"]) * 1024.0
                 traffic_kernel = t_.get("kernel")
@@ -563,7 +595,7 @@ def main():
                     px2 = float(w2.scale_img_x) * float(w2.scale_img_y)
                     other_geo.append({
                         "geometry": "%dx%d, scale %d (BASELINE config %d), %d events" % (W2, H2, s, cfg, n2),
-                        "scatter_format": {0: "dense slabs", 1: "merged lists", 2: "event lists", 3: "own pixels + margin plane"}.get(fmt2, str(fmt2)),
+                        "scatter_format": {0: "dense slabs", 2: "event lists", 3: "own pixels + margin plane"}.get(fmt2, str(fmt2)),
                         "warp_scatter_us": k1 * 1e6, "stencil_us": 1e3 * p2.stencil_ms / it2,
                         "frac": K1_BYTES_PER_EVENT_ITER * n2 / k1 / 1e9 / HBM_PEAK_GBPS,
                         "iteration_frac": (K1_BYTES_PER_EVENT_ITER * n2 + 24.0 * px2) / ((p2.warp_scatter_ms + p2.stencil_ms) * 1e-3 / it2) / 1e9 / HBM_PEAK_GBPS,
@@ -580,8 +612,7 @@ def main():
                 H8, W8 = 2 * H, 4 * W
                 sl8 = synth.make_slice(8000000, H8, W8, 0.030, seed=1)
                 a8 = accel.Accel(max_events=len(sl8["t"]), max_rows=s * H8 + s, max_cols=s * W8 + s)
-                for k8, v8 in (("binned", 2), ("fused", 0), ("bin_compact", 0), ("bin_split", 0), ("bin_tile", 64), ("bin_tile_rows", 48),
-                               ("co_schedule", 1), ("bin_threads", 512)):
+                for k8, v8 in (("binned", 2), ("fused", 0), ("bin_compact", 0), ("bin_split", 0), ("co_schedule", 1)):
                     a8.set_option(k8, v8)
                 o8 = a8.default_opts()
                 o8.res_x, o8.res_y, o8.max_iter = H8, W8, 80
@@ -597,8 +628,8 @@ def main():
                 px8 = float(w8.scale_img_x) * float(w8.scale_img_y)
                 k1_8, k3_8 = p8.warp_scatter_ms * 1e-3 / it8, p8.stencil_ms * 1e-3 / it8
                 chip_full = {
-                    "what": "one context, %d events on a %dx%d sensor (eight config-2 slices side by side), dense slabs, 48x64 bins x 512 threads, "
-                            "update in the stencil tail; first %d iterations of a cold run" % (n8, W8, H8, it8),
+                    "what": "one context, %d events on a %dx%d sensor (eight config-2 slices side by side), dense slabs, 512-thread scatter "
+                            "work-groups, update in the stencil tail; first %d iterations of a cold run" % (n8, W8, H8, it8),
                     "warp_scatter_us": k1_8 * 1e6, "stencil_us": k3_8 * 1e6,
                     "warp_scatter_us_per_1M_events": k1_8 * 1e6 * 1e6 / n8, "stencil_us_per_config2_image": k3_8 * 1e6 * img_px / px8,
                     "warp_scatter_frac": K1_BYTES_PER_EVENT_ITER * n8 / k1_8 / 1e9 / HBM_PEAK_GBPS,
@@ -632,11 +663,10 @@ def main():
         dom = k3_obj if dom_is_k3 else k1_obj
         roofline = {
             "bound": "hbm", "kernel": dom["kernel"], "dominant": "stencil_kernel" if dom_is_k3 else "warp_scatter_kernel",
-            "regime": "one slice context alone on the GPU, 1024-thread scatter work-groups (the shape of a kernel that has the GPU to "
-                      "itself); kernel variants of the headline regime (%s); the dominant kernel is the one with the longer "
-                      "average launch (per_kernel_us)" %
-                      ("update in the stencil kernel's tail, as with %d contexts per GPU" % B if B > 1 else "update at the scatter kernel's head"),
-            "co_scheduled_shape": shared_shape,
+            "regime": "one slice context alone on the GPU running the kernel variants of the headline regime (%s); the dominant "
+                      "kernel is the one with the longer average launch (per_kernel_us)" %
+                      ("lean scatter kernel with 512-thread work-groups, update in the stencil kernel's tail, as with %d contexts per GPU" % B
+                       if B > 1 else "update at the scatter kernel's head, 1024-thread work-groups"),
             "other_geometries": other_geo,
             "chip_full": chip_full,
             "context_alone_form": None if not alone_form else {
@@ -669,9 +699,8 @@ def main():
             },
             "note": "durations are the kernels' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the "
                     "ctx stream), summed over every loop launch and divided by the launches that did work; "
-                    "rocprofv3's view of the same solo runs: profiles/r4_solo_tail_1024_kernel_stats.csv (this shape: update in "
-                    "the stencil tail, 1024-thread scatter work-groups), r4_solo_tail_kernel_stats.csv (the co-scheduled 512-thread "
-                    "shape) and r4_solo_kernel_stats.csv (update at the head)",
+                    "rocprofv3's view of the same solo runs: profiles/r5_solo_tail_kernel_stats.csv (these variants: lean 512-thread "
+                    "scatter kernel, update in the stencil tail) and r5_solo_kernel_stats.csv (update at the head, 1024 threads)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------
@@ -708,6 +737,8 @@ def main():
             cpu_baseline["build_container"] = json.load(open(tt))
         # the fair multi-core figure -- one slice per host core, all cores busy at once (the
         # reference's O(N) loops are serial, so slice-parallel is the only way it uses a multi-core host)
+        if affinity_at_start is not None:   # the CPU baseline may use every core the job was given, not only this GPU's NUMA node
+            os.sched_setaffinity(0, affinity_at_start)
         ncore = host_cores()   # (a container's CPU quota, not the host's core count, is what this job may use)
         ncore = max(1, min(ncore, args.cpu_cores if args.cpu_cores > 0 else ncore))
         if ncore > 1:

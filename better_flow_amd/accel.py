@@ -113,10 +113,34 @@ EXPORTS = [
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
     "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
     "bf_upload_ring_async", "bf_upload_ring16_async", "bf_compute_uv_ring", "bf_wait_uploads", "bf_projection_img",
-    "bf_color_time_img", "bf_eval_sincos",
+    "bf_color_time_img", "bf_eval_sincos", "bf_device_numa_node", "bf_bind_thread_to_numa_node", "bf_bind_thread_to_device_numa",
 ]
 
 _lib = None
+
+
+def device_numa_node(device=0):
+    """Host NUMA node of HIP device `device` (-1: the platform does not say)."""
+    node = C.c_int32(-1)
+    load().bf_device_numa_node(device, C.byref(node))
+    return node.value
+
+
+def bind_thread_to_numa_node(node):
+    """Bind the CALLING thread to the CPUs of host NUMA node `node` (that the process may use); returns the number of CPUs it
+    is now bound to, 0 when nothing was done (unknown node, not a NUMA system, CPUs outside the container's cpuset)."""
+    n = C.c_int32(0)
+    rc = load().bf_bind_thread_to_numa_node(node, C.byref(n))
+    if rc < 0:
+        raise BfError(rc, "bf_bind_thread_to_numa_node(%d)" % node)
+    return n.value
+
+
+def bind_thread_to_device_numa(device=0):
+    """bf_bind_thread_to_device_numa: the calling thread next to its GPU; returns the node (-1: unknown, nothing done)."""
+    node = C.c_int32(-1)
+    load().bf_bind_thread_to_device_numa(device, C.byref(node))
+    return node.value
 
 
 def run_many(accels, opts=None):
@@ -190,6 +214,9 @@ def load():
         L.bf_synchronize.argtypes = [C.c_void_p]
         L.bf_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
         L.bf_eval_sincos.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.bf_device_numa_node.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
+        L.bf_bind_thread_to_numa_node.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
+        L.bf_bind_thread_to_device_numa.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
         L.bf_run_opts_default.argtypes = [C.POINTER(RunOpts)]
         L.bf_device_count.argtypes = [C.POINTER(C.c_int32)]
         L.bf_device_malloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]

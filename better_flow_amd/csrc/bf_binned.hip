@@ -508,55 +508,6 @@ __device__ __forceinline__ void list_put(const ScatterHot& hs, const ScatterGeo&
     }
 }
 
-// ---- merged lists (the other compact form) ---------------------------------------------------------------------------
-// A sparse image whose events still meet at pixels (a small sensor at a large scale: 1M events from 90 000 sensor pixels
-// on a 1729 x 2352 image): the bin's events are merged in its LDS tile as in the dense form, but only the TOUCHED pixels
-// go out -- the accumulate returns the previous value, the lane that finds 0 there touched the pixel first and appends
-// its index to the tile's LDS list (one counter add per wave: ballot + rank) and counts its tile row; the flush
-// counting-sorts the list by tile row.  Same list format as the event lists, a third of the entries in that example
-// (the stencil kernel splats every entry into (2 HS + 1)^2 pixels: 49 at scale 7).
-template <bool WARP>
-__device__ __forceinline__ void scatter_event_merged(const ScatterHot& hs, const ScatterGeo& sg, unsigned long long* s_tile,
-                                                     uint16_t* s_list, uint32_t* s_cnt, const BinScatterArgs& a, float2* p,
-                                                     uint32_t i, uint32_t v, int32_t ti, double pr_x, double pr_y,
-                                                     uint32_t& n_ovf) {
-    int X, Y;
-    if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return;
-    const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
-    const int lx = X - sg.X0, ly = Y - sg.Y0;
-    if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
-        const int idx = __mul24(lx, sg.L) + ly;
-        const unsigned long long old = atomicAdd(&s_tile[idx], (1ull << hs.bin_tbits) + dt);
-        if (old == 0ull) {
-            const unsigned long long m = __ballot(1);   // the lanes that are first at their pixel
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            uint32_t base = 0;
-            if (rank == 0) base = atomicAdd(s_cnt, (uint32_t)__popcll(m));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // (the first active lane is the one of rank 0)
-            s_list[base + rank] = (uint16_t)idx;
-            atomicAdd(&s_cnt[1 + lx], 1u);   // entries per tile row (the flush sorts the list by row)
-        }
-    } else {
-        overflow_add(hs, a, X, Y, dt);
-        ++n_ovf;
-    }
-}
-// s_cnt: [0] entries, [1 .. LR] per-row counts, turned into running cursors here.  Called after a work-group barrier.
-template <int THREADS>
-__device__ __forceinline__ void flush_list(const unsigned long long* s_tile, const uint16_t* s_list, uint32_t* s_cnt,
-                                           int LR, uint32_t mul_l, unsigned long long* vals, uint16_t* cidx, uint32_t* crow,
-                                           int tid) {
-    const uint32_t n = s_cnt[0];
-    if (tid < 64) list_row_scan(s_cnt, LR, crow, tid);
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += THREADS) {
-        const uint32_t idx = s_list[i];
-        const uint32_t slot = atomicAdd(&s_cnt[1 + __umulhi(idx, mul_l)], 1u);
-        __hip_atomic_store(&vals[slot], s_tile[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cidx[slot] = (uint16_t)idx;
-    }
-}
-
 // The whole tile goes to the bin's slab (nothing to zero, no atomics).  WRITE-THROUGH stores (agent-scope relaxed =
 // global_store ... sc1): with plain stores the ~15 MB of slabs (+ 8 MB of p) sat dirty in the L2s until the end of the
 // kernel, and their write-back stretched the kernel boundary to ~5.6 us (measured; "B / 6 TB/s" in the MI355X notes).
@@ -676,13 +627,13 @@ void launch_margin_clean(unsigned long long* mplane, const uint32_t* mlist, uint
 template <bool WARP, int THREADS, int U, int FMT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __restrict__ pre_bin_start, const DevState* pre_st_in,
                                                               MomentAcc* pre_acc, BinScatterArgs a) {
-    constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
+    constexpr bool COMPACT = FMT == 2;   // event lists / (0) dense slabs   (FMT 1, lists merged per pixel in the LDS tile, went in round 5: no BASELINE configuration took it)
     constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
     __shared__ DevState s_state;
-    __shared__ uint32_t s_row[(FMT == 1 || FMT == 2) ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
+    __shared__ uint32_t s_row[FMT == 2 ? 1 + kMaxTileRows : 1];   // lists: entries per tile row, then the rows' cursors
     __shared__ uint32_t s_mcnt[2];
-    if (FMT == 1 || FMT == 2)
+    if (FMT == 2)
         for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
     if (SPLIT && threadIdx.x < 2) s_mcnt[threadIdx.x] = 0;
     const BinGrid& g = a.g;
@@ -840,14 +791,12 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
         tl_stamp(a.tl, a.j, 4);
         return;
     }
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);   // (merged lists: the tile, then one index slot per pixel)
     for (;;) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            if (MERGED) scatter_event_merged<WARP>(hs, sg, s_tile, s_list, s_row, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
-            else scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
+            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], ppx[k], ppy[k], n_ovf);
         }
         base += THREADS * U;
         if (base >= end) break;
@@ -860,9 +809,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
     __syncthreads();
     tl_stamp(a.tl, a.j, 3);
     store_state();
-    if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
-                                    a.chdr + (size_t)b * (size_t)(LR + 1), tid);
-    else if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
+    if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
     tl_stamp(a.tl, a.j, 4);
 }
@@ -874,12 +821,12 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
 template <bool WARP, int THREADS, int U, int FMT>
 __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_t* __restrict__ pre_bin_start, const DevState* pre_st_in,
                                                                    MomentAcc* /* pre_acc: unused here, same signature */, BinScatterArgs a) {
-    constexpr bool COMPACT = FMT == 2, MERGED = FMT == 1;   // event lists / merged lists / (0) dense slabs
+    constexpr bool COMPACT = FMT == 2;   // event lists / (0) dense slabs   (FMT 1, lists merged per pixel in the LDS tile, went in round 5: no BASELINE configuration took it)
     constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
-    __shared__ uint32_t s_row[(FMT == 1 || FMT == 2) ? 1 + kMaxTileRows : 1];   // lists: [entries,] entries per tile row, then the rows' cursors
+    __shared__ uint32_t s_row[FMT == 2 ? 1 + kMaxTileRows : 1];   // lists: entries per tile row, then the rows' cursors
     __shared__ uint32_t s_mcnt[2];
-    if (FMT == 1 || FMT == 2)
+    if (FMT == 2)
         for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
     if (SPLIT && threadIdx.x < 2) s_mcnt[threadIdx.x] = 0;
     const BinGrid& g = a.g;
@@ -972,16 +919,13 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_
         if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
         return;
     }
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tile + LL);
     auto scatter_pass = [&](uint32_t base) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t i = base + k * THREADS + tid;
             if (i >= end) continue;
-            if (MERGED) scatter_event_merged<WARP>(hs, sg, s_tile, s_list, s_row, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
-                                                   pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
-            else scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
-                                     pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
+            scatter_event<WARP>(hs, sg, s_tile, a, p, i, vxy[k], vt[k], pr_from_p(vxy[k] & 0xffffu, vp[k].x),
+                                pr_from_p(vxy[k] >> 16, vp[k].y), n_ovf);
         }
     };
     if constexpr (SPLIT) {
@@ -1009,9 +953,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_
         if (n_ovf) { atomicAdd(ovf_counter(a.ovf_cur, b), n_ovf); a.ovf_cur[0] = 1u; }   // (count on the bin's line, flag: bf_device_fns.h)
     }
     __syncthreads();
-    if (MERGED) flush_list<THREADS>(s_tile, s_list, s_row, LR, g.mul_l, a.slabs + (size_t)b * (size_t)LL, a.cidx + (size_t)b * (size_t)LL,
-                                    a.chdr + (size_t)b * (size_t)(LR + 1), tid);
-    else if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
+    if (SPLIT) flush_split<THREADS>(s_tile, a, b, X0, Y0, hs.C, s_mcnt, tid);
     else flush_tile<THREADS>(s_tile, a.slabs + (size_t)b * (size_t)LL, LL, tid);
 }
 
@@ -1781,10 +1723,17 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
                        has_perm, binid, n, bin_start, cursor, g.nbins, st, armed);
 }
 
-template <int THREADS, int U, int FMT>
+// The scatter kernel's instantiations are the ones the host really picks (bf_run), not the full product: the update's home
+// fixes the form -- HEAD: every work-group applies the pending update itself (a context that has the GPU to itself), lean: the
+// stencil kernel's last work-group did ("co_schedule") -- and form + format fix the work-group sizes:
+//     dense slabs / own pixels + margin plane:  head 1024 threads, lean 512
+//     event lists:                              256 (thousands of small bins) or 512, either form
+// times 1, 2, 4 or 8 events per thread and warp / no warp (the first pass of a cold run): 64 kernels, where the full product
+// of the knobs that used to be options (3 sizes x 4 formats, both forms) was 192.
+template <bool HEAD, int THREADS, int U, int FMT>
 static hipError_t launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    // dynamic LDS: the bin's tile (dense slabs, merged lists: + one 16-bit index slot per pixel); event lists: none
-    const size_t lds = FMT == 2 ? 0 : (size_t)a.g.LR * a.g.L * (sizeof(unsigned long long) + (FMT == 1 ? sizeof(uint16_t) : 0)) + 16;
+    // dynamic LDS: the bin's tile; event lists: none
+    const size_t lds = FMT == 2 ? 0 : (size_t)a.g.LR * a.g.L * sizeof(unsigned long long) + 16;
     // LDS tiles above 64 KiB need the dynamic-LDS attribute raised (160 KiB per CU on gfx950).  The attribute belongs to
     // the (function, device) pair, so it is raised once per device the instantiation is launched on: a bit per device
     // ordinal, set after the calls succeeded (two threads racing here both make the calls, which is harmless).
@@ -1792,46 +1741,49 @@ static hipError_t launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     const unsigned long long dev_bit = 1ull << (dev & 63);
+    const void* fns[2] = {HEAD ? reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, FMT>)
+                               : reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, FMT>),
+                          HEAD ? reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, FMT>)
+                               : reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, FMT>)};
     if (!(raised.load(std::memory_order_acquire) & dev_bit)) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&k_bin_warp_scatter<true, THREADS, U, FMT>),
-                              reinterpret_cast<const void*>(&k_bin_warp_scatter<false, THREADS, U, FMT>),
-                              reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<true, THREADS, U, FMT>),
-                              reinterpret_cast<const void*>(&k_bin_warp_scatter_lean<false, THREADS, U, FMT>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kBinTileLdsMax);
             if (e != hipSuccess) return e;
         }
         raised.fetch_or(dev_bit, std::memory_order_release);
     }
-    if (!a.acc) {   // nothing to update at the head
+    if constexpr (HEAD) {
+        if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
+        else launch_timed(k_bin_warp_scatter<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
+    } else {
         if (warp) launch_timed(k_bin_warp_scatter_lean<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
         else launch_timed(k_bin_warp_scatter_lean<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
-        return hipSuccess;
     }
-    if (warp) launch_timed(k_bin_warp_scatter<true, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
-    else launch_timed(k_bin_warp_scatter<false, THREADS, U, FMT>, dim3(a.g.nbins), dim3(THREADS), lds, s, a.bin_start, a.st_in, a.acc, a);
     return hipSuccess;
 }
-template <int THREADS, int U>
-static hipError_t launch_bws(const BinScatterArgs& a, bool warp, hipStream_t s) {
-    if (a.compact == 3) return launch_bws2<THREADS, U, 3>(a, warp, s);
-    if (a.compact == 2) return launch_bws2<THREADS, U, 2>(a, warp, s);
-    if (a.compact == 1) return launch_bws2<THREADS, U, 1>(a, warp, s);
-    return launch_bws2<THREADS, U, 0>(a, warp, s);
+template <bool HEAD, int THREADS, int FMT>
+static hipError_t launch_bws(const BinScatterArgs& a, bool warp, int per_thread, hipStream_t s) {
+    if (per_thread <= 1) return launch_bws2<HEAD, THREADS, 1, FMT>(a, warp, s);
+    if (per_thread <= 2) return launch_bws2<HEAD, THREADS, 2, FMT>(a, warp, s);
+    if (per_thread <= 4) return launch_bws2<HEAD, THREADS, 4, FMT>(a, warp, s);
+    return launch_bws2<HEAD, THREADS, 8, FMT>(a, warp, s);
 }
 
-// `per_thread`: events a thread keeps in flight (1, 2, 4 or 8 at 1024 threads; the smaller work-group sizes keep 8192
-// events per pass).
+// `threads`: bin_scatter_threads()'s answer for this slice; `per_thread`: events a thread keeps in flight (1, 2, 4 or 8).
+// a.acc != NULL: the head form (the pending update's sums), else the lean one.
+int bin_scatter_threads(int fmt, bool head, bool many_small_bins) {
+    if (fmt == 2) return many_small_bins ? 256 : 512;
+    return head ? 1024 : 512;
+}
 hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s) {
-#define BF_K1(T_)                                                          \
-    if (per_thread <= 1) return launch_bws<T_, 1>(a, warp, s);             \
-    else if (per_thread <= 2) return launch_bws<T_, 2>(a, warp, s);        \
-    else if (per_thread <= 4) return launch_bws<T_, 4>(a, warp, s);        \
-    else return launch_bws<T_, 8>(a, warp, s)
-    if (threads >= 1024) { BF_K1(1024); }
-    else if (threads >= 512) { BF_K1(512); }
-    else { BF_K1(256); }
-#undef BF_K1
+    const bool head = a.acc != nullptr;
+    if (a.compact == 2) {
+        if (threads <= 256) return head ? launch_bws<true, 256, 2>(a, warp, per_thread, s) : launch_bws<false, 256, 2>(a, warp, per_thread, s);
+        return head ? launch_bws<true, 512, 2>(a, warp, per_thread, s) : launch_bws<false, 512, 2>(a, warp, per_thread, s);
+    }
+    if (a.compact == 3) return head ? launch_bws<true, 1024, 3>(a, warp, per_thread, s) : launch_bws<false, 512, 3>(a, warp, per_thread, s);
+    if (a.compact != 0) return hipErrorInvalidValue;
+    return head ? launch_bws<true, 1024, 0>(a, warp, per_thread, s) : launch_bws<false, 512, 0>(a, warp, per_thread, s);
 }
 
 // One pass of the one-kernel iteration (k_fused_pass).  rows_per_tile: 32 or 64.

@@ -103,6 +103,10 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
             c->dbg_persist_split = atoi(v);
             c->dbg_persist_split_late = strstr(v, ",late") ? 1 : 0;
         }
+        if (const char* v = getenv("BF_DEBUG_MARGIN")) {   // tests only: see kBinMargin
+            c->dbg_margin = atoi(v);
+            if (c->dbg_margin < 1 || c->dbg_margin > 30) return fail(c, BF_ERR_ARG, "BF_DEBUG_MARGIN must be in [1, 30]");
+        }
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
             HIP_TRY(c, hipMalloc(&c->d_tl, 3 * 64 * 2 * 16 * sizeof(unsigned long long)));
@@ -239,12 +243,6 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_binned = (int)value;
         return BF_OK;
     }
-    if (!strcmp(key, "bin_tile")) {
-        if (value != 0 && value != 16 && value != 32 && value != 64 && value != 128)
-            return fail(c, BF_ERR_ARG, "bin_tile must be 0 (auto), 16, 32, 64 or 128");
-        c->opt_bin_tile = (int)value;
-        return BF_OK;
-    }
     if (!strcmp(key, "bin_pack_limit")) {
         if (value < 1 || value > 64) return fail(c, BF_ERR_ARG, "bin_pack_limit must be in [1, 64]");
         c->opt_bin_pack_limit = (int)value;
@@ -252,10 +250,6 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
     }
     if (!strcmp(key, "co_schedule")) {
         c->opt_co_schedule = value != 0;
-        return BF_OK;
-    }
-    if (!strcmp(key, "blocking_poll")) {
-        c->opt_blocking_poll = value != 0;
         return BF_OK;
     }
     if (!strcmp(key, "stream_prealloc")) {   // everything the 16-bit ring hand-off allocates on first use, now
@@ -275,20 +269,8 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_watchdog_s = (double)value * 1e-3;
         return BF_OK;
     }
-    if (!strcmp(key, "bin_tile_rows")) {
-        // (>= 32: the stencil kernel relies on a 16-row tile plus its halo crossing at most one bin boundary)
-        if (value != 0 && (value < 32 || value > 128 || value % 16))
-            return fail(c, BF_ERR_ARG, "bin_tile_rows must be 0 (auto) or a multiple of 16 in [32, 128]");
-        c->opt_bin_tile_rows = (int)value;
-        return BF_OK;
-    }
-    if (!strcmp(key, "bin_ev")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, BF_ERR_ARG, "bin_ev must be 0, 1, 2, 4 or 8");
-        c->opt_bin_ev = (int)value;
-        return BF_OK;
-    }
     if (!strcmp(key, "bin_compact")) {
-        if (value < 0 || value > 3) return fail(c, BF_ERR_ARG, "bin_compact must be 0, 1, 2 or 3");
+        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "bin_compact must be 0 (never), 1 (auto) or 2 (always)");
         c->opt_bin_compact = (int)value;
         return BF_OK;
     }
@@ -301,11 +283,6 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_bin_predict = value != 0;
         return BF_OK;
     }
-    if (!strcmp(key, "bin_threads")) {
-        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, BF_ERR_ARG, "bin_threads must be 0 (auto), 256, 512 or 1024");
-        c->opt_bin_threads = (int)value;
-        return BF_OK;
-    }
     if (!strcmp(key, "fused")) {
         if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "fused must be 0, 1 (auto) or 2");
         c->opt_fused = (int)value;
@@ -316,21 +293,6 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         c->opt_persist = (int)value;
         return BF_OK;
     }
-    if (!strcmp(key, "fused_margin")) {
-        if (value < 1 || value > 30) return fail(c, BF_ERR_ARG, "fused_margin must be in [1, 30]");
-        c->opt_fused_margin = (int)value;
-        return BF_OK;
-    }
-    if (!strcmp(key, "fused_rows")) {
-        if (value != 0 && value != 32 && value != 64) return fail(c, BF_ERR_ARG, "fused_rows must be 0 (auto), 32 or 64");
-        c->opt_fused_rows = (int)value;
-        return BF_OK;
-    }
-    if (!strcmp(key, "bin_margin")) {
-        if (value < 2 || value > 64 || value % 2) return fail(c, BF_ERR_ARG, "bin_margin must be even, in [2, 64]");
-        c->opt_bin_margin = (int)value;
-        return BF_OK;
-    }
     return fail(c, BF_ERR_ARG, "unknown option '%s'", key);
 }
 
@@ -339,6 +301,91 @@ int bf_synchronize(bf_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BF_OK;
+}
+
+// ---- NUMA placement (one feeder thread per GPU, next to the GPU) ----------------------------------------------
+// On an 8-GPU node the GPUs hang off different host NUMA nodes; a worker thread that polls a pinned snapshot, fills pinned
+// staging buffers and launches ~100 000 kernels per second wants to run on the CPUs of ITS GPU's node, and memory it pins
+// should come from there (first touch / preferred node).  Linux only, no libnuma: sysfs + sched_setaffinity + set_mempolicy.
+}  // extern "C"
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+namespace {
+bool read_text(const char* path, char* buf, size_t cap) {
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    const size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+// "0-15,64-79" -> cpu set; false on a syntax error
+bool parse_cpulist(const char* s, cpu_set_t* set, int* count) {
+    CPU_ZERO(set);
+    *count = 0;
+    while (*s && *s != '\n') {
+        char* e = nullptr;
+        const long a = strtol(s, &e, 10);
+        if (e == s || a < 0) return false;
+        long b = a;
+        s = e;
+        if (*s == '-') {
+            b = strtol(s + 1, &e, 10);
+            if (e == s + 1 || b < a) return false;
+            s = e;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, set); ++*count; }
+        if (*s == ',') ++s;
+        else if (*s && *s != '\n') return false;
+    }
+    return true;
+}
+}  // namespace
+extern "C" {
+
+int bf_device_numa_node(int32_t device, int32_t* node_out) {
+    if (!node_out) return BF_ERR_ARG;
+    *node_out = -1;
+    char bus[64];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return BF_ERR_NODEVICE; }
+    for (char* p = bus; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');   // sysfs spells the address in lower case
+    char path[160], text[64];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    if (read_text(path, text, sizeof(text))) *node_out = (int32_t)strtol(text, nullptr, 10);   // (-1: the platform does not say)
+    return BF_OK;
+}
+
+int bf_bind_thread_to_numa_node(int32_t node, int32_t* cpus_out) {
+    if (cpus_out) *cpus_out = 0;
+    if (node < 0) return BF_OK;   // unknown node: leave the thread where it is
+    char path[96], text[4096];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    if (!read_text(path, text, sizeof(text))) return BF_OK;   // no such node here (not a NUMA system): nothing to do
+    cpu_set_t want, have, both;
+    int n = 0;
+    if (!parse_cpulist(text, &want, &n)) return BF_ERR_ARG;
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return BF_OK;
+    CPU_AND(&both, &want, &have);   // a container's cpuset wins: never ask for CPUs the process was not given
+    const int m = CPU_COUNT(&both);
+    if (m == 0) return BF_OK;       // the node's CPUs are not ours: stay
+    if (sched_setaffinity(0, sizeof(both), &both) != 0) return BF_OK;
+    // memory this thread touches first (and pins) from now on: that node if it has room, any other otherwise
+    unsigned long mask[16] = {0};
+    if (node < (int)(sizeof(mask) * 8)) {
+        mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+        (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof(mask) * 8);
+    }
+    if (cpus_out) *cpus_out = m;
+    return BF_OK;
+}
+
+int bf_bind_thread_to_device_numa(int32_t device, int32_t* node_out) {
+    int32_t node = -1;
+    const int rc = bf_device_numa_node(device, &node);
+    if (node_out) *node_out = node;
+    if (rc != BF_OK) return rc;
+    return bf_bind_thread_to_numa_node(node, nullptr);
 }
 
 // ---- raw device buffers -----------------------------------------------------------------------

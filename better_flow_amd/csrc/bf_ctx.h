@@ -42,6 +42,13 @@ struct ProfRec {
 
 }  // namespace
 
+// Margins of the tile-binned loops, in scaled pixels: how far an event may drift from where the counting sort found it before
+// its bin must be re-sorted.  Swept flat over 4 .. 8 in rounds 3 and 4 (EXPERIMENTS: 195.9 / 195.1 / 193.1 Mevents/s at 8 / 6 / 4),
+// so no longer an option.  The tile shape, the scatter work-groups' size and their events per thread are chosen per slice
+// (bf_set_cloud, bf_run): the options that overrode them went with it.
+constexpr int kBinMargin = 8;      // two-kernel loop: D of BinGrid (capped at half the smaller tile side)
+constexpr int kFusedMargin = 8;    // one-kernel loops: D on top of the stencil halo H = scale / 2 + 1
+
 struct bf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -61,18 +68,14 @@ struct bf_ctx {
     // tile-binned scatter
     int opt_binned = 1;              // 0 never, 1 when it pays (dense enough), 2 whenever possible
     bool opt_bin_predict = true;
-    int opt_bin_tile = 0, opt_bin_margin = 8, opt_bin_threads = 0;   // bin_threads 0: by the events per bin   // bin_tile 0: chosen per slice
     bool opt_co_schedule = false;    // several slice contexts share the GPU: the update runs in the stencil kernel's last work-group
     int opt_bin_pack_limit = 64;     // bits available to the per-bin packing (lower only to test the fallback)
-    int opt_bin_tile_rows = 0;       // 0: chosen per slice so that the bins fill the CUs
     int n_cus = 0;
     bool use_binned = false;         // decided per slice in bf_set_cloud
     BinGrid grid;
     // one-kernel iteration (k_fused_pass): the loop of a context that has the GPU to itself
     int opt_fused = 1;               // 0 never, 1 where it is the faster loop (small slices on small images; sparser ones only when
                                      // the context is co-scheduled with others), 2 whenever possible
-    int opt_fused_margin = 8;        // D: scaled pixels an event may move before its tile's neighbours must be re-sorted
-    int opt_fused_rows = 0;          // rows of an image tile: 0 auto, 32 or 64
     bool fused_ok = false;           // decided per slice in bf_set_cloud
     bool fused_shared = false;       // ... and it is also the loop to take when the context shares the GPU ("co_schedule")
     BinGrid fgrid;                   // its sort grid: keys = (tile, zone)
@@ -92,14 +95,14 @@ struct bf_ctx {
     long long persist_giveups = 0;   // bf_get_stat "persist_giveups"
     // test hooks, read from the environment ONCE at bf_create (BF_DEBUG_PERSIST_ABORT / _MUTE / _SPLIT=<pass>[,late])
     int dbg_persist_abort = -1, dbg_persist_mute = -1, dbg_persist_split = -1, dbg_persist_split_late = 0;
+    int dbg_margin = 0;              // BF_DEBUG_MARGIN=<n>: both loops' margin (tests: margins of 1 .. 4 pixels make events outrun their bins)
     uint16_t* d_binid = nullptr;
     uint32_t *d_hist_cnt = nullptr, *d_bin_start = nullptr, *d_cursor = nullptr;
     uint32_t* d_armed = nullptr;
     unsigned long long* d_slabs = nullptr;
     uint16_t* d_cidx = nullptr;      // compact lists: pixel index per entry (same slot count as d_slabs)
     uint32_t* d_chdr = nullptr;      // compact lists: entries per bin
-    int fmt = 0;                     // what this slice's scatter hands to the stencil: 0 dense slabs, 1 merged lists, 2 event lists (bf_set_cloud)
-    int opt_bin_ev = 0;              // events per scatter thread in flight (0: from the events per bin)
+    int fmt = 0;                     // what this slice's scatter hands to the stencil: 0 dense slabs, 2 event lists, 3 own pixels + margin plane (bf_set_cloud)
     int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
     // interior + margin format of a dense slice (fmt 3, bf_binned.hip: flush_split): 0 never, 1 when it is the faster one, 2 always
     int opt_bin_split = 1;
@@ -171,7 +174,6 @@ struct bf_ctx {
 
     DevState* h_state = nullptr;     // pinned, D2H target only: 2 slots (pipelined polling)
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
-    bool opt_blocking_poll = true;
     double opt_watchdog_s = 40.0;    // a cold run whose device iteration counter stands still this long is declared hung
     SliceStats* h_stats = nullptr;   // pinned, D2H target only
 

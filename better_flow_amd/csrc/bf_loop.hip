@@ -557,9 +557,12 @@ static hipError_t launch_loop2(const FusedLoopArgs& a, int n_cus, hipStream_t s)
     hipLaunchKernelGGL((k_fused_loop<HS, NSUB, BF_LOOP_U>), dim3(ntiles), dim3(256 * NSUB), lds, s, a);
     return hipGetLastError();
 }
+// Only the 32-row tiles (NSUB = 2) are instantiated: bf_set_cloud takes 64-row tiles when the nine sort keys per 32-row tile
+// would not fit the counting sort (> 910 tiles), and that many tiles are never all resident -- the persistent form of the
+// 64-row tile could only run when forced by an option, which went in round 5.
 template <int HS>
 static hipError_t launch_loop1(const FusedLoopArgs& a, int rows_per_tile, int n_cus, hipStream_t s) {
-    return rows_per_tile == 64 ? launch_loop2<HS, 4>(a, n_cus, s) : launch_loop2<HS, 2>(a, n_cus, s);
+    return rows_per_tile == 32 ? launch_loop2<HS, 2>(a, n_cus, s) : hipErrorInvalidValue;
 }
 hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_per_tile, int n_cus, hipStream_t s) {
     switch (half_scale) {
@@ -573,9 +576,10 @@ hipError_t launch_fused_loop(const FusedLoopArgs& a, int half_scale, int rows_pe
 }
 template <int HS>
 static bool loop_resident1(int rows_per_tile, int n_cus, int ntiles) {
+    if (rows_per_tile != 32) return false;
     int per_cu = 0;
     size_t lds = 0;
-    const hipError_t e = rows_per_tile == 64 ? loop_setup<HS, 4>(&per_cu, &lds) : loop_setup<HS, 2>(&per_cu, &lds);
+    const hipError_t e = loop_setup<HS, 2>(&per_cu, &lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
     return (long long)per_cu * n_cus >= ntiles;
 }

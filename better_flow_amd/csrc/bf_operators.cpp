@@ -106,18 +106,17 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         // + slab pixels x 2.3 ps                               (every slab pixel is written and re-read)
         // over widths {16, 32, 64} (a power of two) and heights {32 .. 128}; ties go to the larger tile.  Small dense
         // images get small tiles (enough bins to fill the CUs), large images large ones (less margin overhead).
-        // "bin_tile" / "bin_tile_rows" override.
-        g.TS = c->opt_bin_tile > 0 ? c->opt_bin_tile : 64;
-        g.TSR = c->opt_bin_tile_rows > 0 ? c->opt_bin_tile_rows : (g.TS < 32 ? 32 : g.TS);
-        if (c->n_cus > 0 && (c->opt_bin_tile <= 0 || c->opt_bin_tile_rows <= 0)) {
+        // (the margin: kBinMargin, even; BF_DEBUG_MARGIN overrides it for tests)
+        const int bin_margin = c->dbg_margin > 0 ? ((c->dbg_margin + 1) & ~1) : kBinMargin;
+        g.TS = 64;
+        g.TSR = 64;
+        if (c->n_cus > 0) {
             const double density = (double)c->n / ((double)w.scale_img_x * (double)w.scale_img_y);
             double best = -1.0;
             int best_area = 0;
             for (int cols = 16; cols <= 64; cols *= 2) {
-                if (c->opt_bin_tile > 0 && cols != c->opt_bin_tile) continue;
                 for (int rows = 32; rows <= 128; rows += 16) {
-                    if (c->opt_bin_tile_rows > 0 && rows != c->opt_bin_tile_rows) continue;
-                    const int d = c->opt_bin_margin > cols / 2 ? cols / 2 : c->opt_bin_margin;
+                    const int d = bin_margin > cols / 2 ? cols / 2 : bin_margin;
                     if ((size_t)(rows + 2 * d) * (cols + 2 * d) * 8 > 64 * 1024) continue;
                     const int nb = ((w.scale_img_x + rows - 1) / rows) * ((w.scale_img_y + cols - 1) / cols);
                     if (nb > 8192) continue;
@@ -133,7 +132,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         while ((1 << g.lg) < g.TS) ++g.lg;
         g.nbc = (w.scale_img_y + g.TS - 1) / g.TS;
         const int tmin_ = g.TS < g.TSR ? g.TS : g.TSR;
-        g.D = c->opt_bin_margin > tmin_ / 2 ? tmin_ / 2 : c->opt_bin_margin;   // <= 2 x 2 bins per pixel
+        g.D = bin_margin > tmin_ / 2 ? tmin_ / 2 : bin_margin;   // <= 2 x 2 bins per pixel
         g.L = g.TS + 2 * g.D;
         g.LR = g.TSR + 2 * g.D;
         g.mul_r = (uint32_t)(0x100000000ull / (unsigned)g.TSR) + 1u;
@@ -177,8 +176,8 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
             memset(&f, 0, sizeof(f));
             const int Hh = scale / 2 + 1;
             auto tiles = [&](int rows) { return ((w.scale_img_x + rows - 1) / rows) * ((w.scale_img_y + 63) / 64); };
-            int rows = c->opt_fused_rows > 0 ? c->opt_fused_rows : (tiles(32) * kFusedZones <= 8192 ? 32 : 64);
-            int Dm = c->opt_fused_margin;
+            const int rows = tiles(32) * kFusedZones <= 8192 ? 32 : 64;
+            int Dm = c->dbg_margin > 0 ? c->dbg_margin : kFusedMargin;
             if (Dm > rows / 2 - Hh) Dm = rows / 2 - Hh;
             if (Dm >= 1 && tiles(rows) * kFusedZones <= 8192) {
                 f.TS = 64; f.lg = 6; f.TSR = rows; f.D = Dm; f.fz = Hh + Dm;
@@ -213,25 +212,20 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         h.n_events = (uint32_t)c->n;
         h.hot.bin_tbits = tbits > 62 ? 62 : tbits; h.hot.bin_ok = 1; h.hot.need_rebin = 0; h.hot.rebins = 0; h.ovf_total = 0;
         h.hot.flip = 0;
-        // Dense slabs, merged lists or event lists.  A dense slice (one event per four pixels or more) merges its events in
-        // the bin's LDS tile and writes the tile.  A sparse one writes lists, work and traffic following the events: one
-        // entry per EVENT and no LDS tile where events rarely meet at a pixel (at most two events per sensor pixel of the
-        // window: a 1280x720 sensor with 1M events -- the tile of such a bin would fill the CU's LDS and leave one
-        // work-group per CU), one entry per touched PIXEL, merged in the LDS tile, where they do (a small sensor at a large
-        // scale: a third of the entries, and the stencil kernel splats every entry into s x s pixels).  "auto" decides once
-        // per slice: the kernels are compiled per format.  Measured per iteration (dense / merged / events): 1280x720
-        // scale 3: 90 / 81 / 68 us; 346x260 scale 7: 96 / 61 / 103; 640x480 scale 3: 44 / 53 / 52.
+        // Dense slabs or event lists.  A dense slice (one event per four pixels or more) merges its events in the bin's LDS
+        // tile and writes the tile.  A sparse one writes lists, work and traffic following the events: one entry per EVENT
+        // and no LDS tile (a 1280x720 sensor with 1M events -- the tile of such a bin would fill the CU's LDS and leave one
+        // work-group per CU).  "auto" decides once per slice: the kernels are compiled per format.  Measured per iteration
+        // (dense / events): 1280x720 scale 3: 90 / 68 us; 640x480 scale 3: 44 / 52.  (A third form -- lists merged per pixel
+        // in the LDS tile, for small sensors at large scales: 346x260 scale 7 61 against 96 / 103 us -- was removed in round 5:
+        // no BASELINE configuration took it, and every form multiplies the bit-identity matrix.)
         {
             const double P = (double)w.scale_img_x * (double)w.scale_img_y;
-            const double sensor_px = P / ((double)scale * (double)scale);
             const size_t LLg = (size_t)g.LR * (size_t)g.L;
             const bool lists_ok = c->use_binned && LLg <= 65536;                         // 16-bit tile-local pixel indices
-            const bool merged_ok = lists_ok && LLg * 10 + 16 <= (size_t)kBinTileLdsMax;   // tile + index list in LDS
             const int mode = lists_ok ? c->opt_bin_compact : 0;
             c->fmt = 0;
-            if (mode == 2) c->fmt = 2;
-            else if (mode == 3) c->fmt = merged_ok ? 1 : 2;
-            else if (mode == 1 && 4.0 * (double)c->n < P) c->fmt = ((double)c->n <= 2.0 * sensor_px || !merged_ok) ? 2 : 1;
+            if (mode == 2 || (mode == 1 && 4.0 * (double)c->n < P)) c->fmt = 2;
             // Dense slices: the bin's own pixels + a margin plane instead of whole-tile slabs (flush_split).  It moves 0.6 x the
             // slab bytes and a quarter of the stencil kernel's loads; "auto" takes it where that is what the iteration
             // waits for -- a context that has the GPU to itself (update at the scatter head) on an image of >= 1.5 M

@@ -149,18 +149,17 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // large images --, so that twice as many bins are in flight per CU: 84 instead of 91 us per iteration at 1280x720)
     int ev_per_thread = 8;
     const double ev_per_bin = binned ? (double)c->n / (double)(c->grid.nbins > 0 ? c->grid.nbins : 1) : 0.0;
-    // (contexts sharing the GPU, "co_schedule": 512-thread work-groups even for full bins -- a 1024-thread work-group with its
-    // 51 KB tile needs half a CU's wave slots free at once and waits for them while the other contexts' kernels hold a few
-    // each: its launches take 16.7 us instead of 8.0 under four contexts; with 512 threads 170 -> 190 Mevents/s.  A context
-    // alone is faster with 1024: 8.0 against 8.9 us)
-    // (event lists over thousands of bins -- 1280x720 at scale 3: 1620 bins of ~600 events, six per CU -- run 256-thread
-    // work-groups: twice as many bins in flight again, 16.6 against 18.6 us per scatter launch there at 1 M events, 8.2
-    // against 13.3 at 100 k; with a couple of bins per CU -- 640x480, 540 bins -- 512 threads stay ahead, 6.3 against 8.2)
+    // Work-group size of the scatter kernel (bin_scatter_threads, bf_binned.hip).  Dense tiles: 1024 threads for a context that
+    // has the GPU to itself (8.0 against 8.9 us per launch at config 2), 512 for contexts sharing the GPU ("co_schedule": a
+    // 1024-thread work-group with its 51 KB tile needs half a CU's wave slots free at once and waits for them while the other
+    // contexts' kernels hold a few each -- 16.7 instead of 8.0 us under four contexts; with 512 threads 170 -> 190 Mevents/s).
+    // Event lists over thousands of small bins -- 1280x720 at scale 3: 1620 bins of ~600 events, six per CU -- run 256-thread
+    // work-groups (16.6 against 18.6 us per scatter launch there at 1 M events, 8.2 against 13.3 at 100 k); with a couple of
+    // bins per CU -- 640x480, 540 bins -- 512 threads stay ahead (6.3 against 8.2).
     const bool many_small_bins = c->fmt == 2 && c->n_cus > 0 && c->grid.nbins >= 4 * c->n_cus && ev_per_bin < 1024.0;
-    const int bin_threads = c->opt_bin_threads > 0 ? c->opt_bin_threads
-                          : ((ev_per_bin >= 1536.0 && !c->opt_co_schedule) ? 1024 : (many_small_bins ? 256 : 512));
-    if (binned && c->opt_bin_ev > 0) ev_per_thread = c->opt_bin_ev;
-    else if (binned) {
+    const int bin_threads = bin_scatter_threads(c->fmt, head_update, many_small_bins);
+    if (binned) {
+        // events a scatter thread keeps in flight:
         // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a
         // CU, and a bin above the pass size takes a second pass; measured at 1280x720: 512 x 2 69.8 us, 512 x 4 73.5)
         // (dense tiles: a pass should cover the AVERAGE bin, fuller bins take a second pass -- sizing it for 1.5 x the
@@ -263,7 +262,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipEventRecord(c->poll_ev[batch & 1], c->stream));
-        if (warm_start || !c->opt_blocking_poll) {
+        if (warm_start) {
             HIP_TRY(c, hipEventSynchronize(c->poll_ev[batch & 1]));
         } else {
             int rcw = wait_event_sleeping(c, c->poll_ev[batch & 1]);
@@ -454,7 +453,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // Invariant of this mode: the snapshot's `done` word is 0 while the loop runs and takes this run's tag --
             // nothing else -- when it ends (a straggler launch of an earlier run can only leave an older tag, which is
             // read as "not started yet": `it` 0).  The watchdog is a wall-clock deadline since the last PROGRESS of
-            // the device's iteration counter, not a count of looks: a spinning poll (blocking_poll = 0) takes a few
+            // the device's iteration counter, not a count of looks: a look takes a few
             // nanoseconds per look, and one batch can legitimately take long (large poll_interval, 1280x720
             // iterations, several contexts sharing the GPU, a first launch loading code objects).
             auto wd_clock = [] { return std::chrono::steady_clock::now(); };
@@ -472,10 +471,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                     gpu_it = ((int32_t)(uint32_t)(wj & 0xffffffffull) == h.run_tag) ? (int32_t)(uint32_t)(wj >> 32) + 1 : 0;
                 }
                 if (launched_iters - gpu_it <= o.poll_interval) break;   // less than a batch left in the queue: feed it
-                if (c->opt_blocking_poll) {
-                    struct timespec ts = {0, 20000};
-                    nanosleep(&ts, nullptr);
-                }
+                struct timespec ts = {0, 20000};
+                nanosleep(&ts, nullptr);
                 if (gpu_it != wd_it) { wd_it = gpu_it; wd_mark = wd_clock(); }
                 else if ((spins & 1023u) == 0 &&
                          std::chrono::duration<double>(wd_clock() - wd_mark).count() > c->opt_watchdog_s) {
@@ -522,11 +519,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             continue;
         }
         if (host_timing) { const double t = ht_now(); ht_launch += t - ht_mark; ht_mark = t; }
-        if (c->opt_blocking_poll) {
+        {
             int rcw = wait_event_sleeping(c, pev[(batch - 1) & 1]);
             if (rcw != BF_OK) return rcw;
-        } else {
-            HIP_TRY(c, hipEventSynchronize(pev[(batch - 1) & 1]));
         }
         if (host_timing) { const double t = ht_now(); ht_wait += t - ht_mark; ht_mark = t; }
         inf.polls++;
@@ -558,11 +553,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (snap_polled) {   // the final state, consistently: behind everything that is queued
         HIP_TRY(c, hipMemcpyAsync(&c->h_state[1], state_of(launched_iters), sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipEventRecord(c->poll_ev[1], c->stream));
-        if (c->opt_blocking_poll) {
+        {
             int rcw = wait_event_sleeping(c, c->poll_ev[1]);
             if (rcw != BF_OK) return rcw;
-        } else {
-            HIP_TRY(c, hipEventSynchronize(c->poll_ev[1]));
         }
         fin = c->h_state[1];
     }

@@ -1,9 +1,16 @@
-"""Slice farm: independent time slices sharded over ranks / GPUs.
+"""Slice farm: independent time slices farmed over ranks / GPUs.
 
-A slice is a complete optimisation problem (the reference already models work as a queue
-of (events, model) tasks, dvs_flow.h:200-202), so ranks never exchange data: slice i goes
-to rank i mod world, every rank runs its own bf_ctx, and the host gathers 11 doubles per
-slice.  No RCCL collective is on the data path."""
+A slice is a complete optimisation problem -- the reference already models work as a QUEUE of (events, model) tasks
+(dvs_flow.h:200-231) --, so ranks never exchange data: every lane (slice context) of every rank claims its next slice from
+one shared counter (`SliceQueue`: a lock in one process, `TCPStore.add` of the gloo process group across ranks -- an
+8-byte control message per slice, no data-path collective), every rank runs its own bf_ctx per lane, and the host gathers
+11 doubles per slice.  Slices differ widely (config 5 on one GPU: 6 437 iterations per slice on average, up to 33 410), so
+the static round robin `i % world` this replaces left ranks idle behind one long slice; with known costs the queue hands
+slices out longest first.  No RCCL collective is on the data path."""
+import itertools
+import threading
+
+_generation = itertools.count()   # every rank calls run_farm / SliceQueue the same number of times: a common name for the counter
 
 
 def shard(n_slices, rank, world):
@@ -11,6 +18,110 @@ def shard(n_slices, rank, world):
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
     return list(range(rank, n_slices, world))
+
+
+class SliceQueue:
+    """The farm's task queue: `claim()` returns the next unclaimed slice index, or None when all are taken.
+
+    order: index order, or -- when `costs` (any monotone estimate of a slice's work: event count x expected iterations, a
+    previous run's milliseconds) are given -- longest first, ties by index; every rank computes the same order.  The counter is
+    a lock-protected integer in one process and one key of the process group's TCPStore across ranks (`dist`: an initialised
+    torch.distributed; `store.add` is atomic and returns the new value)."""
+
+    def __init__(self, n_slices, costs=None, dist=None, name=None):
+        if costs is not None:
+            if len(costs) != n_slices:
+                raise ValueError("one cost per slice")
+            self.order = sorted(range(n_slices), key=lambda i: (-float(costs[i]), i))
+        else:
+            self.order = list(range(n_slices))
+        self._lock = threading.Lock()
+        self._next = 0
+        self._store = None
+        gen = next(_generation)
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d
+            self._store = distributed_c10d._get_default_store()
+            self._key = "bf_farm/%s/%d" % (name or "queue", gen)
+
+    def claim(self):
+        if self._store is not None:
+            k = int(self._store.add(self._key, 1)) - 1
+        else:
+            with self._lock:
+                k = self._next
+                self._next += 1
+        return self.order[k] if k < len(self.order) else None
+
+
+def run_queue(queue, process_slice, lanes=1):
+    """`lanes` threads of this rank claim slices from `queue` and run process_slice(i) -> dict; returns {i: result} with the
+    lane and the claim / completion times (seconds since this call) added as "lane", "t0", "t1"."""
+    import time
+    results, errors = {}, []
+    lock = threading.Lock()
+    start = time.perf_counter()
+
+    def lane(k):
+        try:
+            while True:
+                i = queue.claim()
+                if i is None:
+                    return
+                t0 = time.perf_counter() - start
+                r = dict(process_slice(i))
+                r.update(lane=k, t0=t0, t1=time.perf_counter() - start)
+                with lock:
+                    results[i] = r
+        except Exception as e:   # noqa: BLE001
+            with lock:
+                errors.append(e)
+    th = [threading.Thread(target=lane, args=(k,)) for k in range(max(1, lanes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
+def balance(merged, world):
+    """Per-rank seconds from the farm's start to the rank's last completed slice ("busy_s"), slices and summed slice
+    milliseconds per rank, and imbalance = slowest rank / mean rank (1.0 = perfectly even)."""
+    busy = [0.0] * world
+    count = [0] * world
+    ms = [0.0] * world
+    for r in merged.values():
+        k = r.get("rank", 0)
+        busy[k] = max(busy[k], r.get("t1", 0.0))
+        count[k] += 1
+        ms[k] += r.get("ms", 0.0)
+    mean = sum(busy) / max(1, world)
+    return {"busy_s": busy, "slices": count, "slice_ms_sum": ms, "imbalance": (max(busy) / mean) if mean > 0 else 1.0}
+
+
+def simulate_makespan(durations, world, lanes=1, costs=None, static=False):
+    """Makespan (same unit as `durations`) of farming slices with the given durations over `world` ranks x `lanes` lanes:
+    static=True: slice i belongs to rank i % world, whose lanes take its slices in index order (the round robin this module
+    used to have); else every lane of every rank claims from one queue -- index order, or longest-`costs`-first.  A lane takes
+    its next slice the moment it is free (list scheduling)."""
+    import heapq
+    n = len(durations)
+
+    def schedule(ids, nlanes):
+        free = [0.0] * nlanes
+        heapq.heapify(free)
+        end = 0.0
+        for i in ids:
+            t = heapq.heappop(free) + durations[i]
+            end = max(end, t)
+            heapq.heappush(free, t)
+        return end
+    if static:
+        return max([schedule(range(r, n, world), lanes) for r in range(world)] or [0.0])
+    order = sorted(range(n), key=lambda i: (-float(costs[i]), i)) if costs is not None else range(n)
+    return schedule(order, world * lanes)
 
 
 def run_shard(slice_ids, process_slice):
@@ -42,61 +153,98 @@ class SliceSpec:
         self.events, self.duration_s = events, duration_s
         self.seed = index if seed is None else seed
         self.arrays = arrays
+        self.path = None    # prepare(share_dir=...): where the rank that generated the slice left it for the others
+        self.cost = None    # optional estimate of the slice's work (SliceQueue hands out longest first)
 
     def load(self):
         if self.arrays is None:   # generated once, outside the farm's lanes (and outside any timed region: prepare())
-            from . import synth
-            self.arrays = synth.make_slice(self.events, self.height, self.width, self.duration_s, seed=self.seed)
+            import os
+            if self.path is not None and os.path.exists(self.path):
+                import numpy as np
+                with np.load(self.path) as z:
+                    self.arrays = {k: z[k] for k in ("fr_x", "fr_y", "t")}
+            else:
+                from . import synth
+                self.arrays = synth.make_slice(self.events, self.height, self.width, self.duration_s, seed=self.seed)
         return self.arrays
+
+    def drop(self):
+        """Forget the arrays of a slice that can be loaded again (shared file): a lane keeps two slices in memory, not 512."""
+        if self.path is not None:
+            self.arrays = None
 
     def count(self):
         return len(self.arrays["t"]) if self.arrays is not None else self.events
 
 
-def prepare(specs, rank=0, world=1):
-    """Load (generate) the event arrays of this rank's slices up front -- the farm's lanes only move and solve them."""
+def prepare(specs, rank=0, world=1, share_dir=None):
+    """Generate the event arrays up front -- the farm's lanes only move and solve them.  One rank: all of them, in memory.
+    Several ranks: rank r generates the slices i % world == r and, since any rank may claim any slice from the shared queue,
+    leaves each as an uncompressed .npz under `share_dir` (a directory all ranks see, e.g. under /dev/shm: 16 bytes per
+    event); the caller puts a barrier between prepare() and run_farm().  Without a share_dir a rank generates a foreign
+    slice when it claims it (correct, slow: inside the timed region)."""
+    import os
+    import numpy as np
     for s in specs:
-        if s.index % world == rank:
-            s.load()
+        if share_dir is not None and world > 1:
+            s.path = os.path.join(share_dir, "bf_farm_slice_%d.npz" % s.index)
+        if s.index % world != rank:
+            continue
+        sl = s.load()
+        if s.path is not None:
+            tmp = s.path + ".tmp.%d.npz" % os.getpid()
+            np.savez(tmp, fr_x=sl["fr_x"], fr_y=sl["fr_y"], t=sl["t"])
+            os.replace(tmp, s.path)
+            s.arrays = None
     return specs
 
 
 def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-1, want_flow_digest=False, dist=None,
-             options=None):
+             options=None, static=False, bind_numa=True):
     """The slice farm on the HIP path (dvs_flow.h:200-231's task queue, over ranks and slice contexts).
 
-    Rank `rank` takes the slices i with i % world == rank and runs them with `concurrent` slice contexts (one host
-    thread + bf_ctx + HIP stream + copy stream each: contexts pull the rank's slices from a shared queue, so a slow slice
-    does not hold the others up); every slice is a cold start (STM off: independent slices).  A lane stages its next
-    slice in pinned memory and uploads it on its copy stream (bf_upload_events_async) while the current one is being
-    solved.  The per-slice records -- return code, iterations, the 88-byte model, events, milliseconds, optionally a digest
+    Every rank runs `concurrent` slice contexts (lanes: one host thread + bf_ctx + HIP stream + copy stream each); every
+    lane of every rank claims its next slice from ONE shared queue (`SliceQueue`: longest first when the specs carry a
+    `cost`), so neither a slow slice nor a slow rank holds the others up; `static=True` is the round robin slice i -> rank
+    i % world (each rank's lanes then share the rank's own queue), kept for A/B runs.  Every slice is a cold start (STM off:
+    independent slices).  A lane stages its next slice in pinned memory and uploads it on its copy stream
+    (bf_upload_events_async) while the current one is being solved.  `bind_numa`: every lane first binds itself to the CPUs
+    of its GPU's NUMA node (bf_bind_thread_to_device_numa), so that its pinned staging buffers and its polling live next to
+    the device (SURVEY 8(e)'s caveat).  The per-slice records -- return code, iterations, the 88-byte model, events, milliseconds, optionally a digest
     of the per-event flow, or the text of an error -- are merged on every rank with all_gather_object when `dist` is an
     initialised torch.distributed (gloo: no data-path collective exists on this path).  An error in any lane of any rank
     is raised on EVERY rank, after the gather (no rank is left waiting in a collective).  Returns {slice index: record}.
     The native form of the same farm, for C++ callers and the command line, is better_flow/slice_farm.h."""
     import hashlib
-    import queue
-    import threading
     import time
     import numpy as np
     from . import accel
-    mine = [s for s in specs if s.index % world == rank]
+    by_index = {s.index: s for s in specs}
+    ids = sorted(by_index)
+    if static:
+        mine = [i for i in ids if i % world == rank]
+        work = SliceQueue(len(mine), costs=None, dist=None)
+        claim = lambda: (lambda k: None if k is None else by_index[mine[k]])(work.claim())   # noqa: E731
+        n_mine = len(mine)
+    else:
+        costs = [by_index[i].cost for i in ids]
+        work = SliceQueue(len(ids), costs=costs if all(c is not None for c in costs) else None, dist=dist, name="run_farm")
+        claim = lambda: (lambda k: None if k is None else by_index[ids[k]])(work.claim())   # noqa: E731
+        n_mine = len(ids)
     results = {}
-    if mine:
-        for s in mine:
-            s.load()
-        hmax = max(s.height for s in mine)
-        wmax = max(s.width for s in mine)
-        nmax = max(s.count() for s in mine)
-        work = queue.Queue()
-        for s in mine:
-            work.put(s)
+    if n_mine:
+        hmax = max(s.height for s in specs)
+        wmax = max(s.width for s in specs)
+        nmax = max(s.count() for s in specs)
         lock = threading.Lock()
+        t_start = time.perf_counter()
 
-        def lane():
+        def lane(lane_no):
             a = None
             cur = None
             try:
+                if bind_numa:
+                    accel.bind_thread_to_device_numa(device)   # before the first pinned allocation of this lane
                 a = accel.Accel(device=device, max_events=nmax, max_rows=scale * hmax + scale, max_cols=scale * wmax + scale)
                 if concurrent > 1:
                     a.set_option("co_schedule", 1)
@@ -108,9 +256,8 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
 
                 def put(slot):
                     """Take the next slice off the queue and start its upload; None when the queue is empty."""
-                    try:
-                        s = work.get_nowait()
-                    except queue.Empty:
+                    s = claim()
+                    if s is None:
                         return None
                     sl = s.load()
                     n = len(sl["t"])
@@ -118,12 +265,14 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
                     t_issue = time.perf_counter()
                     if n > 0:
                         a.upload_events_async(pin[slot][0], pin[slot][1], pin[slot][2], n)
+                    s.drop()
                     return s, n, t_issue
 
                 k = 0
                 nxt = put(0)
                 while nxt is not None:
                     cur, n, t0 = nxt
+                    t_solve = time.perf_counter()
                     if n > 0:
                         a.commit_upload()
                     else:
@@ -133,12 +282,17 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
                     o.res_x, o.res_y, o.max_iter, o.want_uv = cur.height, cur.width, max_iter, 1 if want_flow_digest else 0
                     a.set_cloud(scale, cur.height, cur.width)
                     rc, m, info = a.run(o)
-                    rec = {"rc": int(rc), "iterations": int(info.iterations), "model": m.as_dict(), "events": n, "rank": rank}
+                    rec = {"rc": int(rc), "iterations": int(info.iterations), "model": m.as_dict(), "events": n, "rank": rank,
+                           "lane": lane_no}
                     if want_flow_digest:
                         u, v = a.compute_uv()
                         rec["flow_sha1"] = hashlib.sha1(u.tobytes() + v.tobytes()).hexdigest()
                     a.synchronize()
-                    rec["ms"] = 1e3 * (time.perf_counter() - t0)
+                    now = time.perf_counter()
+                    rec["ms"] = 1e3 * (now - t0)       # from the issue of the slice's upload (under the previous solve) to its model
+                    rec["solve_ms"] = 1e3 * (now - t_solve)   # the lane's own time for this slice: commit, set_cloud, run, read-back
+                    rec["t1"] = now - t_start          # seconds since this rank's farm started
+
                     with lock:
                         results[cur.index] = rec
                     cur = None
@@ -153,7 +307,7 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
                     except Exception:   # noqa: BLE001
                         pass
 
-        threads = [threading.Thread(target=lane) for _ in range(max(1, min(concurrent, len(mine))))]
+        threads = [threading.Thread(target=lane, args=(k,)) for k in range(max(1, min(concurrent, n_mine)))]
         for t in threads:
             t.start()
         for t in threads:

@@ -283,6 +283,8 @@ private:
     }
 
     void work(Worker &wk) {
+        // next to its GPU: the CPUs (and preferred memory) of the device's host NUMA node, where the process may use them
+        (void)bf_bind_thread_to_device_numa(wk.device, nullptr);
         std::deque<Staged> staged;        // tasks this worker has taken, oldest first; their copies are in flight
         for (;;) {
             {   // sleep only when there is nothing to solve

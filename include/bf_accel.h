@@ -158,10 +158,7 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  whenever possible, 0 never.  A "co_schedule" context takes it only for sparser slices (at most one event
  *                  per eight image pixels: launch-bound even with eight contexts in flight).  Bit-identical to the two-kernel loop;
  *                  bf_run_info::overflow_events then counts the passes that were repeated after a re-bin because an
- *                  event had moved further than "fused_margin" (detected exactly, never a wrong sum).
- *   "fused_margin" scaled pixels an event may move between two re-bins of that loop (default 8; at most half a tile
- *                  minus scale / 2 + 1).    "fused_rows"  rows of its image tiles: 0 (default: 32, or 64 when the image
- *                  has too many tiles for the counting sort), 32, 64.
+ *                  event had moved further than the loop's margin of 8 scaled pixels (detected exactly, never a wrong sum).
  *   "persist"      the persistent form of that loop (k_fused_loop, bf_loop.hip): the work-groups stay resident, keep their
  *                  events in registers and run iteration after iteration in ONE launch, exchanging the moment sums through
  *                  tagged records in memory instead of a launch boundary; the launch ends when the loop is over or a re-bin
@@ -171,8 +168,6 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  all be resident at once; 2 for cold runs too (they re-bin a dozen times, each a host round trip: slower).
  *                  Bit-identical to the other loops.
  *   BF_ACCEL_OPTIONS (environment, read by bf_create): "key=value,key=value" applied to every context of the process.
- *   "bin_tile"     tile WIDTH of the binned scatter (0 = default: chosen per slice with the height; or 16, 32,
- *                  64, 128).
  *   "bin_pack_limit"  bits the per-bin accumulator packing may use (default 64).  The counting sort sizes the
  *                  packed count / time-sum fields from the fullest bin; if they do not fit, every event takes the
  *                  exact unpacked path.  Lower values only serve to exercise that fallback in tests.
@@ -181,34 +176,23 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *                  serial tail on one CU, which the other contexts' kernels fill) instead of at the head of the
  *                  next warp+scatter launch by every work-group (the shortest iteration for a context alone, but
  *                  ~1.5 us on all CUs).  Results are identical bit for bit.  Default 0.
- *   "blocking_poll"  1 (default): a cold bf_run sleeps between its progress polls (event query + ~20 us sleep;
- *                  the polls trail the launches by one batch, so the wake-up latency is hidden) instead of
- *                  spinning in hipEventSynchronize: 0.85 instead of 4.1 host cores for 4 slice contexts at the
- *                  same throughput.  0: spin.  Warm-started runs always spin (they wait for the batch just
- *                  launched; latency matters there).
  *   "stream_prealloc"  1: create now what the asynchronous uploads (bf_upload_events_async / bf_upload_ring*_async) create
  *                  on first use -- the copy stream, its events, both staging slots -- so that the first slice of a stream
  *                  does not pay ~20 ms of allocations.
  *   "watchdog_ms"  a cold bf_run whose device iteration counter has not advanced for this long (wall clock, default
  *                  40000) stops with BF_ERR_HIP "device loop makes no progress" instead of waiting for ever.
- *   "bin_tile_rows"  tile HEIGHT (0 = default: chosen per slice among 32 .. 128 so that the bins -- one
- *                  work-group each -- fill the CUs; else a multiple of 16 in [32, 128]).  "bin_tile" is the
- *                  tile width.
- *   "bin_margin"   LDS margin around a bin's tile (even, default 8); events drifting
- *                  further take the exact overflow path and trigger a re-bin.
- *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x margin
- *                  (bounded analytically), i.e. before they overflow; 0: re-bin only on
- *                  observed overflow.
- *   "bin_threads"  work-group size of the binned warp+scatter kernel: 0 (default: 1024 where a bin holds thousands
- *                  of events, 512 where it holds a few hundred), 256, 512, 1024.
- *   "bin_ev"       events a scatter thread keeps in flight: 0 (default: from the events per bin), 1, 2, 4, 8.
+ *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x the bins' margin (8 scaled pixels;
+ *                  bounded analytically), i.e. before they leave their bin's LDS tile and take the exact overflow path;
+ *                  0: re-bin only on observed overflow.
  *   "bin_compact"  what the scatter kernel hands to the stencil kernel: 0 dense tiles (the bin's events merged in an LDS
  *                  tile, one accumulator per tile pixel written), 2 event lists (one entry per event: tile-local pixel
- *                  index + packed accumulator, sorted by tile row; no LDS tile), 3 merged lists (the events merged in the
- *                  LDS tile, one entry per touched pixel); 1 (default): lists when the slice has fewer than one event per
- *                  four pixels -- event lists at up to two events per sensor pixel of the window, merged lists above --,
- *                  dense tiles otherwise.  With lists, traffic and work follow the events instead of the image area.
- *                  Bit-identical results in every form.
+ *                  index + packed accumulator, sorted by tile row; no LDS tile); 1 (default): lists when the slice has
+ *                  fewer than one event per four pixels, dense tiles otherwise.  With lists, traffic and work follow the
+ *                  events instead of the image area.  Bit-identical results in either form.
+ * (Round 5 removed eight keys whose sweeps had been flat for two rounds or that only forced what bf_set_cloud / bf_run choose
+ * per slice -- tile width / height, margins, scatter work-group size and events per thread, the one-kernel loop's tile rows, the
+ * spinning poll -- and the merged-list scatter format; tests reach the paths they forced through geometry, "bin_predict" = 0 and
+ * "bin_pack_limit".)
  *   "bin_split"    dense tiles only: 0 the bin writes its whole LDS tile, margin included, and the stencil kernel merges
  *                  up to 2 x 2 such slabs per pixel; 2 the bin writes its own pixels into a tiled image and ADDS the few
  *                  words its events left in the tile's margin to a margin plane (device atomics; the bin clears them again
@@ -218,7 +202,7 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
 int bf_set_option(bf_ctx *ctx, const char *key, int64_t value);
 
 /* Diagnostics (no reference counterpart).  Keys:
- *   "scatter_format"  what the last bf_set_cloud chose for the tile-binned loop: 0 dense slabs, 1 merged lists, 2 event
+ *   "scatter_format"  what the last bf_set_cloud chose for the tile-binned loop: 0 dense slabs, 2 event
  *                     lists, 3 own pixels + margin plane ("bin_split"); -1 when the slice does not take that loop.
  *   "one_kernel"      1 when bf_run would take the one-kernel iteration for the slice staged now, else 0.
  *   "persistent"      1 when bf_run, called now, would run it as the persistent kernel ("persist"), else 0.
@@ -454,6 +438,20 @@ int bf_local_iteration_step(bf_ctx *ctx, double nx, double ny, double *score, ui
  * :9-13, with the sensor size res_x x res_y) or BF_ERR_NOCONV when max_evaluations (> 0) is
  * reached (the reference has no cap). */
 int bf_local_run(bf_ctx *ctx, int32_t res_x, int32_t res_y, int64_t max_evaluations, bf_local_state *out);
+
+/* NUMA placement of a feeder thread (no reference counterpart: the reference is single-threaded, SURVEY 8(b) "Threading"; the
+ * 8-GPU farm of SURVEY 8(e) wants one feeder thread per GPU with NUMA-local pinned buffers).
+ *   bf_device_numa_node          host NUMA node of HIP device `device` (sysfs numa_node of its PCI function); -1: unknown.
+ *   bf_bind_thread_to_numa_node  restricts the CALLING thread to the CPUs of `node` that the process may use (a container's
+ *                                cpuset wins; no such CPUs, no such node or node < 0: nothing happens) and makes that node the
+ *                                preferred one for memory the thread touches or pins from now on.  cpus_out (may be NULL): CPUs
+ *                                the thread is bound to, 0 when nothing was done.
+ *   bf_bind_thread_to_device_numa  the two together; node_out may be NULL.
+ * Call it on a worker thread before the thread's first bf_create / bf_host_alloc.  bf::SliceFarm's workers, the lanes of
+ * better_flow_amd/farm.py and every rank of bench.py do. */
+int bf_device_numa_node(int32_t device, int32_t *node_out);
+int bf_bind_thread_to_numa_node(int32_t node, int32_t *cpus_out);
+int bf_bind_thread_to_device_numa(int32_t device, int32_t *node_out);
 
 /* For callers that keep slices resident in HBM (bench.py, the streaming front end) and
  * hand them over with bf_upload_events_device.  bf_memcpy_h2d is synchronous.  (The reference's device buffers are

@@ -1,7 +1,7 @@
 """What would ONE launch per iteration for B staged slices cost?  (a lock-step batched bf_run_many.)
 
 A proxy that needs no new kernel: one context solving a slice that is B config-2 slices side by side -- a sensor B times
-the area with B x 1M events at the same density, the same 48 x 64 bins (B x 256 of them) and stencil tiles (B x 752) -- runs
+the area with B x 1M events at the same density, bins of the same kind (chosen per slice by bf_set_cloud) and stencil tiles (B x 752) -- runs
 exactly the work-groups a batched launch of B slices would run, minus the per-slice early exits.  Its time per iteration
 divided by B is the price of a slice-iteration in a batched launch, to be held against the four-context fan-out's
 (bench.py: ms_per_step / iterations per slice).
@@ -18,11 +18,10 @@ from better_flow_amd import accel, synth
 s, iters = 3, 160
 for (B, H, W) in ((1, 260, 346), (4, 520, 692), (8, 520, 1384)):
     sl = synth.make_slice(1000000 * B, H, W, 0.030, seed=1)
-    for name, opts in (("update in the stencil tail, 512-thread bins", dict(co_schedule=1, bin_threads=512)),
-                       ("update in the stencil tail, 1024-thread bins", dict(co_schedule=1, bin_threads=1024)),
-                       ("update at the scatter head, 1024-thread bins", dict(co_schedule=0, bin_threads=1024))):
+    for name, opts in (("update in the stencil tail, 512-thread bins", dict(co_schedule=1)),
+                       ("update at the scatter head, 1024-thread bins", dict(co_schedule=0))):
         a = accel.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
-        for k, v in dict(dict(binned=2, fused=0, bin_compact=0, bin_split=0, bin_tile=64, bin_tile_rows=48), **opts).items():
+        for k, v in dict(dict(binned=2, fused=0, bin_compact=0, bin_split=0), **opts).items():
             a.set_option(k, v)
         o = a.default_opts()
         o.res_x, o.res_y, o.max_iter = H, W, iters

@@ -1,14 +1,14 @@
-"""Copy the judged round-4 rocprofv3 summaries from gpurun_out/prof_r4 into profiles/ (tracked)."""
+"""Copy the judged round-5 rocprofv3 summaries from gpurun_out/prof_r5 into profiles/ (tracked)."""
 import csv, collections, statistics, re, glob, os, shutil, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r4")
+src = os.path.join(ROOT, "gpurun_out", "prof_r5")
 out = os.path.join(ROOT, "profiles")
 def kname(n):
     m = re.search(r"(k_[a-z_0-9]+)(<[^>(]*>)?", n)
     return (m.group(1) + (m.group(2) or "")) if m else n[:40]
-for d, name in (("solo_head", "r4_solo_kernel_stats.csv"), ("solo_tail", "r4_solo_tail_kernel_stats.csv"),
-                ("solo_tail_1024", "r4_solo_tail_1024_kernel_stats.csv"), ("bench", "r4_bench_kernel_stats.csv"),
-                ("chip_full", "r4_chip_full_kernel_stats.csv"), ("ring", "r4_reference_ring_kernel_stats.csv")):
+for d, name in (("solo_head", "r5_solo_kernel_stats.csv"), ("solo_tail", "r5_solo_tail_kernel_stats.csv"),
+                ("bench", "r5_bench_kernel_stats.csv"),
+                ("chip_full", "r5_chip_full_kernel_stats.csv"), ("ring", "r5_reference_ring_kernel_stats.csv")):
     ks = glob.glob(os.path.join(src, d, "**/*kernel_stats.csv"), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(out, name))
@@ -18,7 +18,7 @@ old = {}
 tj = os.path.join(out, "k1_traffic.json")
 if os.path.exists(tj):
     old = json.load(open(tj))
-traffic, lines = dict(old), []
+traffic, lines = {k: v for k, v in old.items() if not k.endswith("_lean1024")}, []   # (the 1024-thread lean kernel is gone)
 def collect(label, suffix, keys):
     """keys: (json key for the scatter kernel, json key for the stencil kernel)"""
     k1, k3 = {}, {}
@@ -43,20 +43,20 @@ def collect(label, suffix, keys):
         traffic[keys[0]] = k1
     if len(k3) >= 3 and keys[1]:
         traffic[keys[1]] = k3
-collect("346x260 lean 1024 + tail update", "346x260_lean1024", ("346x260x3_lean1024", "346x260x3_stencil_tail"))
+collect("346x260 lean 512 + tail update", "346x260_lean512", ("346x260x3_lean512", "346x260x3_stencil_tail"))
 collect("346x260 head update 1024", "346x260_head1024", ("346x260x3_head1024", "346x260x3_stencil_head"))
 collect("640x480 co-scheduled shape", "640x480", ("640x480x3", "640x480x3_stencil_tail"))
 collect("1280x720 co-scheduled shape", "1280x720", ("1280x720x3", "1280x720x3_stencil_tail"))
-traffic["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/profile_r4.sh; keys without a variant suffix and "
+traffic["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/profile_r5.sh; keys without a variant suffix and "
                      "the *_head_split* keys: round 3's scripts/profile_r3.sh), median over the live launches of the named kernel of one "
                      "cold 1M-event slice per geometry; FETCH_SIZE is doubled by the reader (gfx950)")
 json.dump(traffic, open(tj, "w"), indent=1)
-open(os.path.join(out, "r4_pmc_hbm_traffic.txt"), "w").write(
+open(os.path.join(out, "r5_pmc_hbm_traffic.txt"), "w").write(
     "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over one cold 1M-event\n"
     "slice per geometry and kernel variant (scripts/run_once.py 1 <options>; 640x480 and 1280x720: first 300 iterations).\n"
     "KB per dispatch; 'live' excludes the early-exit launches after convergence.  On gfx950 FETCH_SIZE under-reports wide\n"
     "coalesced reads by 2x (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n\n" + "\n".join(lines) + "\n")
-for d, name in (("sq_720", "r4_pmc_sq_720p.txt"), ("sq_346", "r4_pmc_sq_issue.txt")):
+for d, name in (("sq_720", "r5_pmc_sq_720p.txt"), ("sq_346", "r5_pmc_sq_issue.txt")):
     fs = counter_files(d)
     if not fs:
         continue
@@ -77,18 +77,18 @@ for d, name in (("sq_720", "r4_pmc_sq_720p.txt"), ("sq_346", "r4_pmc_sq_issue.tx
                      100 * a["SQ_ACTIVE_INST_VALU"] / wc, 100 * a["SQ_WAIT_ANY"] / wc, 100 * a["SQ_WAIT_INST_ANY"] / wc))
     open(os.path.join(out, name), "w").write("\n".join(rows) + "\n")
     print("\n".join(rows))
-for log, name in (("bench.log", "r4_bench_under_rocprof.json"),):
+for log, name in (("bench.log", "r5_bench_under_rocprof.json"),):
     bl = os.path.join(src, log)
     if os.path.exists(bl):
         for ln in open(bl):
             if ln.startswith('{"metric"'):
                 open(os.path.join(out, name), "w").write(ln)
-for log, name in (("chip_full.log", "r4_chip_full_under_rocprof.txt"), ("ring.log", "r4_reference_ring_under_rocprof.txt")):
+for log, name in (("chip_full.log", "r5_chip_full_under_rocprof.txt"), ("ring.log", "r5_reference_ring_under_rocprof.txt")):
     bl = os.path.join(src, log)
     if os.path.exists(bl):
         shutil.copy(bl, os.path.join(out, name))
-print(open(os.path.join(out, "r4_pmc_hbm_traffic.txt")).read())
-for f in ("r4_solo_kernel_stats.csv", "r4_solo_tail_1024_kernel_stats.csv", "r4_chip_full_kernel_stats.csv", "r4_reference_ring_kernel_stats.csv"):
+print(open(os.path.join(out, "r5_pmc_hbm_traffic.txt")).read())
+for f in ("r5_solo_kernel_stats.csv", "r5_solo_tail_kernel_stats.csv", "r5_chip_full_kernel_stats.csv", "r5_reference_ring_kernel_stats.csv"):
     p = os.path.join(out, f)
     if os.path.exists(p):
         print(f); print("".join(open(p).readlines()[:6]))

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
 from better_flow_amd import accel
+from helpers import make_accel
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -72,20 +73,21 @@ for ci in range(cases):
     ow = oc.set_cloud(s, H, W)
     K = int(rng.integers(2, 40))
     results = {}
+    # ("margin": the library's test hook BF_DEBUG_MARGIN -- tests/helpers.py -- set around the context's creation; tile shapes,
+    # work-group sizes and events per thread follow the random geometry: the options that forced them went in round 5)
     modes = [("default", {}), ("atomics", {"binned": 0}), ("binned", {"binned": 2}),
-             ("tile32", {"binned": 2, "bin_tile": 32, "bin_margin": int(rng.choice([4, 8, 12]))}),
-             ("nopredict", {"binned": 2, "bin_predict": 0, "bin_margin": 2}),
-             ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}), ("merged", {"binned": 2, "bin_compact": 3}), ("merged_co", {"binned": 2, "bin_compact": 3, "co_schedule": 1}),
+             ("margin", {"binned": 2, "debug_margin": int(rng.choice([4, 6, 12]))}),
+             ("nopredict", {"binned": 2, "bin_predict": 0, "debug_margin": 2}),
+             ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}),
              ("dense_co", {"binned": 2, "bin_compact": 0, "co_schedule": 1}), ("compact_co", {"binned": 2, "bin_compact": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
-             ("rows", {"binned": 2, "bin_tile_rows": int(rng.choice([32, 48, 80, 112, 128])), "bin_margin": int(rng.choice([4, 8]))}),
-             ("fused", {"fused": 2, "persist": 0}), ("fused_tight", {"fused": 2, "persist": 0, "fused_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
-             ("fused64", {"fused": 2, "fused_rows": 64, "fused_margin": int(rng.choice([4, 8, 20]))}), ("fused_unpacked", {"fused": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
-             ("persist", {"fused": 2, "persist": 2}), ("persist_tight", {"fused": 2, "persist": 2, "fused_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
-             ("persist64_unpacked", {"fused": 2, "persist": 2, "fused_rows": 64, "bin_pack_limit": int(rng.choice([1, 20, 64]))})]
+             ("split", {"binned": 2, "bin_compact": 0, "bin_split": 2, "debug_margin": int(rng.choice([2, 4, 8]))}),
+             ("split_co", {"binned": 2, "bin_compact": 0, "bin_split": 2, "co_schedule": 1, "bin_predict": int(rng.integers(0, 2))}),
+             ("fused", {"fused": 2, "persist": 0}), ("fused_tight", {"fused": 2, "persist": 0, "debug_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
+             ("fused_unpacked", {"fused": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
+             ("persist", {"fused": 2, "persist": 2}), ("persist_tight", {"fused": 2, "persist": 2, "debug_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),
+             ("persist_unpacked", {"fused": 2, "persist": 2, "bin_pack_limit": int(rng.choice([1, 20, 64]))})]
     for name, kv in modes:
-        a = accel.Accel(max_events=max(n, 16), max_rows=s * H + s, max_cols=s * W + s)
-        for k_, v_ in kv.items():
-            a.set_option(k_, v_)
+        a = make_accel(accel, kv, max_events=max(n, 16), max_rows=s * H + s, max_cols=s * W + s)
         a.upload_events(c["fr_x"], c["fr_y"], c["t"])
         gw = a.set_cloud(s, H, W)
         if name == "default":

@@ -144,9 +144,9 @@ for step in range(steps):
         state["scale"] = int(rng.choice([1, 3, 3, 5, 7]))
         op = ("cloud", state["scale"]); state["cloud"] = True
     elif k == "opt":
-        name = str(rng.choice(["binned", "bin_tile_rows", "bin_margin", "co_schedule", "bin_predict", "bin_pack_limit", "bin_compact", "bin_split", "fused", "fused_margin", "fused_rows", "persist"]))
-        val = {"persist": int(rng.integers(0, 3)), "fused": int(rng.integers(0, 3)), "fused_margin": int(rng.choice([1, 2, 8, 14])), "fused_rows": int(rng.choice([0, 32, 64])), "binned": int(rng.integers(0, 3)), "bin_tile_rows": int(rng.choice([0, 32, 48, 96])), "bin_margin": int(rng.choice([2, 6, 8, 12])),
-               "co_schedule": int(rng.integers(0, 2)), "bin_compact": int(rng.integers(0, 4)), "bin_split": int(rng.integers(0, 3)), "bin_predict": int(rng.integers(0, 2)),
+        name = str(rng.choice(["binned", "co_schedule", "bin_predict", "bin_pack_limit", "bin_compact", "bin_split", "fused", "persist"]))
+        val = {"persist": int(rng.integers(0, 3)), "fused": int(rng.integers(0, 3)), "binned": int(rng.integers(0, 3)),
+               "co_schedule": int(rng.integers(0, 2)), "bin_compact": int(rng.integers(0, 3)), "bin_split": int(rng.integers(0, 3)), "bin_predict": int(rng.integers(0, 2)),
                "bin_pack_limit": int(rng.choice([64, 64, 30, 1]))}[name]
         op = ("opt", name, val)
     elif k == "project":

@@ -250,6 +250,10 @@ int bf_local_run(bf_ctx *c, int32_t res_x, int32_t res_y, int64_t max_evaluation
 int bf_host_alloc(bf_ctx *, int64_t bytes, void **out) { *out = std::malloc((size_t)bytes); return *out ? BF_OK : BF_ERR_HIP; }
 int bf_host_free(bf_ctx *, void *ptr) { std::free(ptr); return BF_OK; }
 int bf_synchronize(bf_ctx *) { return BF_OK; }
+// (no device, no NUMA node of a device: the farm's workers stay where they are)
+int bf_device_numa_node(int32_t, int32_t *node_out) { if (node_out) *node_out = -1; return BF_OK; }
+int bf_bind_thread_to_numa_node(int32_t, int32_t *cpus_out) { if (cpus_out) *cpus_out = 0; return BF_OK; }
+int bf_bind_thread_to_device_numa(int32_t, int32_t *node_out) { if (node_out) *node_out = -1; return BF_OK; }
 int bf_wait_uploads(bf_ctx *) { return BF_OK; }
 
 int bf_upload_ring_async(bf_ctx *c, const int32_t *rx, const int32_t *ry, const uint64_t *rts, const uint8_t *rnoise,

@@ -69,3 +69,133 @@ def test_two_rank_farm_matches_single_process():
         assert merged[i] == single[i], i      # order independent, bit identical
     with pytest.raises(ValueError):
         farm.shard(4, 2, 2)
+
+
+# ---- the shared task queue (dvs_flow.h:200-231 models work as a queue of (events, model) tasks) ----------------------------
+
+def _process_uneven(i):
+    """Deliberately uneven slices: the even ones -- ALL of rank 0's under the round robin i % 2 -- cost ~10 x the odd ones
+    (more events, and the same optimisation solved several times over)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from better_flow_amd import synth
+    heavy = i % 2 == 0
+    sl = synth.make_slice(6000 if heavy else 2000, 60, 80, 0.04, seed=300 + i)
+    for _ in range(12 if heavy else 1):
+        c = oracle.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+        w = c.set_cloud(3, 60, 80)
+        m = oracle.Model()
+        rc, loop, _ = c.run(w, m, max_iter=60, res_x=60, res_y=80)
+    return {"rc": rc, "iters": int(loop.itercount), "model": m.as_dict(), "events": len(sl["t"])}
+
+
+def _queue_worker(rank, world, port, n_slices, use_costs, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from better_flow_amd import farm
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    costs = [24000 if i % 2 == 0 else 2000 for i in range(n_slices)] if use_costs else None
+    work = farm.SliceQueue(n_slices, costs=costs, dist=dist, name="test")
+    dist.barrier()
+    res = farm.run_queue(work, _process_uneven, lanes=1)
+    for r in res.values():
+        r["rank"] = rank
+        r["ms"] = 1e3 * (r["t1"] - r["t0"])
+    merged = farm.gather(res, dist)
+    if rank == 0:
+        q.put(merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_costs", [False, True], ids=["index_order", "longest_first"])
+def test_two_ranks_share_one_queue_and_finish_balanced(use_costs):
+    """Every lane of every rank claims its next slice from ONE counter (TCPStore.add of the gloo group: control messages only).
+    With slices whose cost alternates 10 : 1, the round robin i % 2 gives rank 0 every long one; the queue must hand every
+    slice out exactly once, return the bits of a single process, and end well before the round robin would have."""
+    sys.path.insert(0, ROOT)
+    from better_flow_amd import farm
+    n_slices = 12
+    single = {i: _process_uneven(i) for i in range(n_slices)}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, n_slices, use_costs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(merged) == list(range(n_slices))   # every slice once (gather raises on a slice processed twice)
+    for i in range(n_slices):
+        for k in ("rc", "iters", "model", "events"):
+            assert merged[i][k] == single[i][k], (i, k)
+    dur = [merged[i]["ms"] for i in range(n_slices)]
+    assert min(dur[0::2]) > 3 * max(dur[1::2]), "the test's slices are not uneven enough to show anything"
+    bal = farm.balance(merged, 2)
+    static = farm.simulate_makespan(dur, 2, 1, static=True)
+    dynamic = 1e3 * max(bal["busy_s"])
+    heavy_per_rank = [sum(1 for i in range(0, n_slices, 2) if merged[i]["rank"] == r) for r in range(2)]
+    print("slices per rank %s (long ones %s), busy %.0f / %.0f ms, imbalance %.2f; the round robin would have taken %.0f ms, "
+          "the queue took %.0f ms" % (bal["slices"], heavy_per_rank, 1e3 * bal["busy_s"][0], 1e3 * bal["busy_s"][1], bal["imbalance"],
+                                      static, dynamic))
+    assert min(heavy_per_rank) >= 2, heavy_per_rank          # both ranks took long slices
+    assert dynamic <= 0.8 * static, (dynamic, static)        # (ideal: 0.55)
+    assert bal["imbalance"] <= 1.25, bal
+    if use_costs:   # longest first: the six long slices are the first six claims
+        first = sorted(range(n_slices), key=lambda i: merged[i]["t0"])[:6]
+        assert all(i % 2 == 0 for i in first), first
+
+
+def test_makespan_simulation_and_queue_order():
+    sys.path.insert(0, ROOT)
+    from better_flow_amd import farm
+    d = [10, 1, 10, 1, 10, 1, 10, 1, 1, 1, 1, 1]
+    assert farm.simulate_makespan(d, 2, 1, static=True) == 42      # rank 0: 10 + 10 + 10 + 10 + 1 + 1
+    assert farm.simulate_makespan(d, 2, 1) == 24                   # one queue, index order
+    assert farm.simulate_makespan(d, 2, 1, costs=d) == 24          # longest first
+    assert farm.simulate_makespan(d, 1, 1) == sum(d) == farm.simulate_makespan(d, 1, 1, static=True)
+    assert farm.simulate_makespan(d, 2, 2) <= 13
+    q = farm.SliceQueue(5, costs=[1, 5, 3, 5, 2])
+    assert [q.claim() for _ in range(7)] == [1, 3, 2, 4, 0, None, None]
+    q = farm.SliceQueue(3)
+    assert [q.claim() for _ in range(4)] == [0, 1, 2, None]
+    with pytest.raises(ValueError):
+        farm.SliceQueue(3, costs=[1, 2])
+
+
+def test_numa_binding_is_safe_everywhere():
+    """bf_bind_thread_to_numa_node (include/bf_accel.h): binds the calling thread to the node's CPUs the process may use and
+    never fails on a machine without that node, without NUMA, or inside a cpuset -- it then does nothing."""
+    sys.path.insert(0, ROOT)
+    import threading
+    from better_flow_amd import accel
+    before = os.sched_getaffinity(0)
+    out = {}
+
+    def t():
+        out["none"] = accel.bind_thread_to_numa_node(-1)
+        out["far"] = accel.bind_thread_to_numa_node(4095)
+        out["aff_untouched"] = os.sched_getaffinity(0) == before
+        out["node0"] = accel.bind_thread_to_numa_node(0)
+        out["aff"] = os.sched_getaffinity(0)
+    th = threading.Thread(target=t)
+    th.start()
+    th.join()
+    assert out["none"] == 0 and out["far"] == 0 and out["aff_untouched"]
+    path = "/sys/devices/system/node/node0/cpulist"
+    if os.path.exists(path):
+        cpus = set()
+        for part in open(path).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        want = cpus & before
+        if want:
+            assert out["node0"] == len(want) and out["aff"] == want
+        else:
+            assert out["node0"] == 0 and out["aff"] == before
+    else:
+        assert out["node0"] == 0 and out["aff"] == before
+    assert os.sched_getaffinity(0) == before   # (the binding is the calling thread's, not the process's)

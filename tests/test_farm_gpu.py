@@ -1,7 +1,8 @@
 """The slice farm on the HIP path (better_flow_amd/farm.py: run_farm): two gloo ranks -- both on GPU 0 of the test box --
-shard independent slices i -> rank i % 2 with two slice contexts each; every slice's return code, iteration count,
-model and per-event flow must be bit-identical to the single-rank run (multi-GPU level).  No collective is
-on the data path: the process group only gathers the 88-byte models."""
+with two slice contexts each claim independent slices from ONE shared queue (TCPStore.add of the gloo group; and, for the
+A/B form, the round robin i -> rank i % 2); every slice's return code, iteration count, model and per-event flow must be
+bit-identical to the single-rank run (multi-GPU level).  No collective is on the data path: the process group
+carries the claims and gathers the 88-byte models."""
 import os
 import socket
 import sys
@@ -34,14 +35,15 @@ def _worker(rank, world, port, q):
     from better_flow_amd import farm
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     merged = farm.run_farm(_specs(), rank=rank, world=world, device=0, concurrent=2, want_flow_digest=True, dist=dist)
+    static = farm.run_farm(_specs(), rank=rank, world=world, device=0, concurrent=2, want_flow_digest=True, dist=dist, static=True)
     if rank == 0:
-        q.put(merged)
+        q.put((merged, static))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def _strip(rec):
-    return {k: v for k, v in rec.items() if k not in ("ms", "rank")}
+    return {k: v for k, v in rec.items() if k not in ("ms", "solve_ms", "rank", "lane", "t1")}
 
 
 def test_two_rank_farm_on_the_gpu_matches_single_rank():
@@ -56,11 +58,15 @@ def test_two_rank_farm_on_the_gpu_matches_single_rank():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    merged = q.get(timeout=300)
+    merged, static = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert sorted(merged) == list(range(N_SLICES))
+    assert sorted(merged) == list(range(N_SLICES)) == sorted(static)
     for i in range(N_SLICES):
-        assert merged[i]["rank"] == i % 2
-        assert _strip(merged[i]) == _strip(single[i]), i
+        assert static[i]["rank"] == i % 2                      # the round robin, kept for A/B runs
+        assert _strip(merged[i]) == _strip(single[i]), i       # the shared queue: whoever took the slice, the same bits
+        assert _strip(static[i]) == _strip(single[i]), i
+    assert {merged[i]["rank"] for i in range(N_SLICES)} == {0, 1}, "both ranks must have claimed slices"
+    bal = farm.balance(merged, 2)
+    assert sum(bal["slices"]) == N_SLICES and bal["imbalance"] < 2.0, bal

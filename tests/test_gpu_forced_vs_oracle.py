@@ -38,7 +38,6 @@ FORMS = {
         (dict(binned=2, fused=0, bin_compact=0, bin_split=2, co_schedule=1), 3, 0),
     "dense slabs, update in the stencil tail": (dict(binned=2, fused=0, bin_compact=0, bin_split=0, co_schedule=1), 0, 0),
     "event lists (bin_compact=2)": (dict(binned=2, fused=0, bin_compact=2), 2, 0),
-    "merged lists (bin_compact=3)": (dict(binned=2, fused=0, bin_compact=3), 1, 0),
     "global atomics (binned=0)": (dict(binned=0, fused=0), -1, 0),
 }
 

@@ -4,7 +4,7 @@ work-group, events of a tile's edge strips read by the neighbouring tiles' work-
 It must return the bits of the two-kernel tile-binned loop (same integer accumulators, same per-sub-tile f64 partials) --
 model, iteration count, every trace record, per-event flow, and the warm start that follows -- with the default margin,
 with margins so small that events outrun their bins (the `lost` flag, a re-bin, the pass repeated before its update),
-with 64-row tiles, with the unpacked LDS planes, without the predictive re-bin -- and so must its persistent form
+with 64-row tiles (the 640x480 case: too many 32-row tiles for the counting sort), with the unpacked LDS planes, without the predictive re-bin -- and so must its persistent form
 (k_fused_loop, bf_loop.hip: many iterations per launch, sums exchanged through tagged records), forced for the cold run
 as well ("persist" = 2; by default only the warm start takes it).  And `auto` must take the one-kernel loop exactly for
 the slices it was measured to be faster on (bf_set_cloud).
@@ -13,14 +13,13 @@ import numpy as np
 import pytest
 
 from better_flow_amd import synth
+from helpers import make_accel
 
 pytestmark = pytest.mark.gpu
 
 
 def run(accel_mod, sl, H, W, s, opts, max_iter=-1):
-    a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
-    for k, v in opts.items():
-        a.set_option(k, v)
+    a = make_accel(accel_mod, opts, max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)   # ("debug_margin": tests/helpers.py)
     a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
     a.set_cloud(s, H, W)
     persistent = a.get_stat("persistent")
@@ -40,10 +39,10 @@ def run(accel_mod, sl, H, W, s, opts, max_iter=-1):
                 giveups=giveups)
 
 
-VARIANTS = (("default margin", {}), ("persistent kernel", {"persist": 2}), ("persistent kernel, margin 2", {"persist": 2, "fused_margin": 2}),
-            ("persistent kernel, 64-row tiles, unpacked planes", {"persist": 2, "fused_rows": 64, "bin_pack_limit": 20}), ("margin 2", {"fused_margin": 2}), ("margin 1", {"fused_margin": 1}),
-            ("64-row tiles", {"fused_rows": 64}), ("unpacked planes", {"bin_pack_limit": 20}),
-            ("no predictive re-bin, margin 3", {"bin_predict": 0, "fused_margin": 3}))
+VARIANTS = (("default margin", {}), ("persistent kernel", {"persist": 2}), ("persistent kernel, margin 2", {"persist": 2, "debug_margin": 2}),
+            ("persistent kernel, unpacked planes", {"persist": 2, "bin_pack_limit": 20}), ("margin 2", {"debug_margin": 2}), ("margin 1", {"debug_margin": 1}),
+            ("unpacked planes", {"bin_pack_limit": 20}), ("no predictive re-bin", {"bin_predict": 0}),
+            ("no predictive re-bin, margin 3", {"bin_predict": 0, "debug_margin": 3}))
 
 
 @pytest.mark.parametrize("case", [(1000000, 260, 346, 3, 1, -1), (300000, 480, 640, 3, 2, -1), (200000, 180, 240, 5, 3, -1),

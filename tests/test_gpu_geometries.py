@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from better_flow_amd import synth
+from helpers import make_accel
 
 pytestmark = pytest.mark.gpu
 
@@ -31,9 +32,7 @@ def _flow_close(u, ou, rel=1e-4, abs_=0.02):
 
 
 def _gpu_run(accel_mod, sl, H, W, s, max_iter, trace_cap, warm=None, **options):
-    a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
-    for k, v in options.items():
-        a.set_option(k, v)
+    a = make_accel(accel_mod, options, max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)   # ("debug_margin": tests/helpers.py)
     a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
     a.set_cloud(s, H, W)
     if warm is not None:
@@ -99,9 +98,8 @@ def test_large_geometry_against_oracle(oracle_lib, accel_mod, H, W, K):
     runs = {}
     for name, opts in (("binned", dict(binned=2)), ("atomics", dict(binned=0)), ("auto", dict()),
                        ("compact", dict(binned=2, bin_compact=2)), ("dense", dict(binned=2, bin_compact=0)),
-                       ("merged", dict(binned=2, bin_compact=3)),
                        ("tail_update", dict(binned=2, co_schedule=1)),
-                       ("no_predict", dict(binned=2, bin_margin=4, bin_predict=0))):
+                       ("no_predict", dict(binned=2, debug_margin=4, bin_predict=0))):
         runs[name] = _gpu_run(accel_mod, sl, H, W, s, K, K + 1, **opts)
     b = runs["binned"]
     assert b[0] == 0 and b[2].iterations == K + 1
@@ -112,7 +110,7 @@ def test_large_geometry_against_oracle(oracle_lib, accel_mod, H, W, K):
     # prediction a re-bin is only asked for once events HAVE overflowed: live whatever the timing.
     assert runs["no_predict"][2].overflow_events > 0, "overflow path + the stencil's overflow branch must be live at this geometry"
     assert runs["auto"][2].rebins >= 1, "1M events at this geometry are dense enough for the binned path by default"
-    for name in ("atomics", "auto", "compact", "dense", "merged", "tail_update", "no_predict"):   # integer accumulators: every scatter mode gives the same bits
+    for name in ("atomics", "auto", "compact", "dense", "tail_update", "no_predict"):   # integer accumulators: every scatter mode gives the same bits
         r = runs[name]
         assert (r[0], r[2].iterations, r[1].as_dict(), r[3]) == (b[0], b[2].iterations, b[1].as_dict(), b[3]), name
         assert np.array_equal(r[4], b[4]) and np.array_equal(r[5], b[5]), name

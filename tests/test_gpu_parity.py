@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from better_flow_amd import synth
+from helpers import make_accel
 
 pytestmark = pytest.mark.gpu
 
@@ -401,12 +402,10 @@ def test_golden_stream_gpu(accel_mod):
 
 
 def _run_mode(accel_mod, sl, H, W, scale, trace_cap=0, warm=None, **options):
-    acc = accel_mod.Accel(max_events=max(len(sl["t"]), 8192), max_rows=scale * H + scale,
-                          max_cols=scale * W + scale)
     if options.get("binned") == 2 and "fused" not in options:
         options = dict(options, fused=0)   # "binned = 2" names the two-kernel tile-binned loop; the one-kernel loop is asked for by name
-    for k, v in options.items():
-        acc.set_option(k, v)
+    acc = make_accel(accel_mod, options, max_events=max(len(sl["t"]), 8192), max_rows=scale * H + scale,
+                     max_cols=scale * W + scale)   # ("debug_margin": tests/helpers.py)
     acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
     acc.set_cloud(scale, H, W)
     if warm is not None:
@@ -431,11 +430,11 @@ def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
     ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=0)
     assert ref[2].rebins == 0
     # (fused = 2: the one-kernel iteration, k_fused_pass -- default margin, margins so small that events outrun their
-    # bins and passes are repeated on fresh ones, 64-row tiles, the unpacked LDS planes)
-    for opts in (dict(binned=2), dict(binned=2, bin_tile=32, bin_margin=2),
-                 dict(binned=2, bin_tile=16, bin_margin=4), dict(binned=2, bin_tile=128, bin_margin=6),
-                 dict(fused=2), dict(fused=2, fused_margin=1), dict(fused=2, fused_margin=2, bin_predict=0),
-                 dict(fused=2, fused_rows=64), dict(fused=2, bin_pack_limit=20)):
+    # bins and passes are repeated on fresh ones, the unpacked LDS planes)
+    for opts in (dict(binned=2), dict(binned=2, debug_margin=2), dict(binned=2, debug_margin=4), dict(binned=2, debug_margin=6),
+                 dict(binned=2, co_schedule=1, debug_margin=2),
+                 dict(fused=2), dict(fused=2, debug_margin=1), dict(fused=2, debug_margin=2, bin_predict=0),
+                 dict(fused=2, bin_pack_limit=20)):
         got = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, **opts)
         assert got[0] == ref[0] and got[2].iterations == ref[2].iterations, opts
         assert got[2].rebins >= 1
@@ -447,8 +446,7 @@ def test_binned_scatter_is_bit_identical_to_global_atomics(accel_mod, scale):
         assert np.array_equal(got[5], ref[5]) and np.array_equal(got[6], ref[6]), opts
     # without the drift prediction the re-bin is triggered by observed overflow only: the exact
     # global-atomic overflow path must give the same bits
-    tiny = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=2, bin_tile=32, bin_margin=2,
-                     bin_predict=0)
+    tiny = _run_mode(accel_mod, sl, H, W, scale, trace_cap=256, binned=2, debug_margin=2, bin_predict=0)
     assert tiny[2].overflow_events > 0 and tiny[2].rebins > 1, "margin 2 must exercise overflow + re-bin"
     assert tiny[1].as_dict() == ref[1].as_dict() and tiny[2].iterations == ref[2].iterations
     for a, b in zip(tiny[4], ref[4]):
@@ -468,9 +466,7 @@ def test_overflow_path_flags_and_sparse_clearing(accel_mod):
     other = synth.make_slice(200000, H, W, 0.03, seed=42)
 
     def chain(opts):
-        a = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
-        for k, v in opts.items():
-            a.set_option(k, v)
+        a = make_accel(accel_mod, opts, max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         out = []
         a.upload_events(other["fr_x"], other["fr_y"], other["t"])
         a.set_cloud(s, H, W)
@@ -492,7 +488,7 @@ def test_overflow_path_flags_and_sparse_clearing(accel_mod):
     ref, _ = chain({"binned": 0, "fused": 0})
     for opts in ({"bin_compact": 0, "bin_split": 0}, {"bin_compact": 0, "bin_split": 2}, {"bin_compact": 2},
                  {"bin_compact": 0, "bin_split": 0, "co_schedule": 1}, {"bin_compact": 0, "bin_split": 2, "co_schedule": 1}):
-        got, infos = chain(dict({"binned": 2, "fused": 0, "bin_margin": 2, "bin_predict": 0}, **opts))
+        got, infos = chain(dict({"binned": 2, "fused": 0, "debug_margin": 2, "bin_predict": 0}, **opts))
         assert all(i.overflow_events > 20 * i.iterations for i in infos), (opts, [i.overflow_events for i in infos])
         assert got == ref, opts
 
@@ -503,7 +499,7 @@ def test_binned_warm_start_bit_identical(accel_mod):
     b = synth.make_slice(40000, H, W, 0.05, seed=32)
     cold = _run_mode(accel_mod, a, H, W, 3, binned=0)
     w0 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], binned=0)
-    for opts in (dict(binned=2), dict(fused=2), dict(fused=2, fused_margin=1)):
+    for opts in (dict(binned=2), dict(fused=2), dict(fused=2, debug_margin=1)):
         w1 = _run_mode(accel_mod, b, H, W, 3, warm=cold[1], **opts)
         assert w0[2].iterations == w1[2].iterations and w0[1].as_dict() == w1[1].as_dict(), opts
         for x, y in zip(w0[4], w1[4]):
@@ -666,7 +662,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
     runs = {}
     for name, opts in (("binned", dict(binned=2, fused=0)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2, fused=0)), ("fused", dict(fused=2)),
                        ("tail_update", dict(binned=2, co_schedule=1)), ("compact", dict(binned=2, bin_compact=2)),
-                       ("dense", dict(binned=2, bin_compact=0)), ("merged", dict(binned=2, bin_compact=3))):
+                       ("dense", dict(binned=2, bin_compact=0))):
         a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         for k, v in opts.items():
             a2.set_option(k, v)
@@ -677,7 +673,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
         rc, m, info = a2.run(o)
         runs[name] = (rc, info.iterations, m.as_dict(), [t_.model.as_dict() for t_ in a2.get_trace(K + 1)], a2.compute_uv())
         a2.close()
-    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4] == runs["compact"][:4] == runs["dense"][:4] == runs["merged"][:4] == runs["fused"][:4]
+    assert runs["binned"][:4] == runs["atomics"][:4] == runs["binned2"][:4] == runs["tail_update"][:4] == runs["compact"][:4] == runs["dense"][:4] == runs["fused"][:4]
     assert np.array_equal(runs["binned"][4][0], runs["atomics"][4][0])
     assert np.array_equal(runs["binned"][4][0], runs["fused"][4][0]) and np.array_equal(runs["binned"][4][1], runs["fused"][4][1])
     assert runs["binned"][1] == oloop.itercount == K + 1
@@ -945,8 +941,8 @@ def test_event_lists_full_bins_and_second_pass(accel_mod):
     entries from the stored products; empty bins write empty lists.  Every case must give the bits of the global-atomic
     scatter."""
     for (n, H, W, scale, opts, want_overflow) in (
-            (60000, 60, 80, 1, dict(bin_tile=32, bin_tile_rows=32, bin_threads=256, bin_ev=1), True),    # lists of 48 x 48 entries, ~10 000 events per bin
-            (60000, 120, 160, 3, dict(bin_tile=64, bin_tile_rows=64, bin_threads=256, bin_ev=1), False),  # ~40 passes per bin
+            (60000, 60, 80, 1, dict(), True),      # a 61 x 81 image: a dozen bins of thousands of events, lists of <= 48 x 32 entries
+            (60000, 120, 160, 3, dict(), False),   # several passes per bin
             (1500, 180, 240, 5, dict(), False)):                                                        # mostly empty bins
         sl = synth.make_slice(n, H, W, 0.05, seed=23)
         ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=0)
@@ -1182,18 +1178,16 @@ def test_ring16_hand_off_with_noise_and_flow_ring(oracle_lib, accel_mod):
     acc.close()
 
 
-def test_spinning_poll_with_long_batches(accel_mod):
-    """blocking_poll = 0 (the host spins on the pinned snapshot instead of sleeping) with a poll interval of 256
-    iterations: the watchdog of the progress poll is a wall-clock deadline since the device's last progress, so a healthy
-    run whose batches take milliseconds is not declared hung -- and gives the bits of the default run."""
+def test_long_batches_are_not_declared_hung(accel_mod):
+    """A poll interval of 256 iterations: the watchdog of the progress poll is a wall-clock deadline since the device's last
+    progress, so a healthy run whose batches take milliseconds is not declared hung -- and gives the bits of the default
+    run, in every loop (one-kernel passes that wait for a re-bin count their progress in launches)."""
     H, W, s = 260, 346, 3
     sl = synth.make_slice(400000, H, W, 0.030, seed=2)
 
     def go(**opt):
-        acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         poll = opt.pop("poll", None)
-        for k, v in opt.items():
-            acc.set_option(k, v)
+        acc = make_accel(accel_mod, opt, max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
         acc.set_cloud(s, H, W)
         o = acc.default_opts()
@@ -1209,11 +1203,11 @@ def test_spinning_poll_with_long_batches(accel_mod):
     want = go(binned=2)
     assert want[0] == 0 and want[2] > 100
     assert go(fused=2) == want
-    assert go(fused=2, blocking_poll=0, poll=256) == want
-    assert go(fused=2, fused_margin=1, blocking_poll=0, poll=64) == want   # (passes that wait for a re-bin: progress is counted in launches)
-    assert go(binned=2, blocking_poll=0, poll=256) == want
-    assert go(binned=2, blocking_poll=0, poll=256, co_schedule=1) == want
-    assert go(binned=2, blocking_poll=0, poll=256, watchdog_ms=2000) == want
+    assert go(fused=2, poll=256) == want
+    assert go(fused=2, debug_margin=1, poll=64) == want   # (passes that wait for a re-bin: progress is counted in launches)
+    assert go(binned=2, poll=256) == want
+    assert go(binned=2, poll=256, co_schedule=1) == want
+    assert go(binned=2, poll=256, watchdog_ms=2000) == want
 
 
 def test_run_many_equals_one_by_one(accel_mod):

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from better_flow_amd import synth
+from helpers import make_accel
 
 pytestmark = pytest.mark.gpu
 
@@ -33,10 +34,7 @@ def solve(a, sl, H, W, s, max_iter=-1, warm_from=None):
 
 
 def ctx(accel_mod, n, H, W, s, opts):
-    a = accel_mod.Accel(max_events=n, max_rows=s * H + s, max_cols=s * W + s)
-    for k, v in opts.items():
-        a.set_option(k, v)
-    return a
+    return make_accel(accel_mod, opts, max_events=n, max_rows=s * H + s, max_cols=s * W + s)   # ("debug_margin": tests/helpers.py)
 
 
 @pytest.mark.parametrize("case", [(1000000, 260, 346, 3, 1, -1), (600000, 480, 640, 3, 2, 120), (400000, 180, 240, 5, 3, -1),
@@ -48,8 +46,8 @@ def test_same_bits_as_dense_slabs(accel_mod, case, co):
     sl = synth.make_slice(n, H, W, 0.03, seed=seed)
     base = {"binned": 2, "fused": 0, "bin_compact": 0, "co_schedule": co}
     res = {}
-    for name, o in (("dense", {"bin_split": 0}), ("split", {"bin_split": 2}), ("split, margin 4", {"bin_split": 2, "bin_margin": 4}),
-                    ("split, margin 2, no prediction", {"bin_split": 2, "bin_margin": 2, "bin_predict": 0})):
+    for name, o in (("dense", {"bin_split": 0}), ("split", {"bin_split": 2}), ("split, margin 4", {"bin_split": 2, "debug_margin": 4}),
+                    ("split, margin 2, no prediction", {"bin_split": 2, "debug_margin": 2, "bin_predict": 0})):
         a = ctx(accel_mod, len(sl["t"]), H, W, s, dict(base, **o))
         cold, m, fmt, info = solve(a, sl, H, W, s, max_iter)
         assert fmt == (0 if name == "dense" else 3), (name, fmt)

@@ -637,10 +637,12 @@ def test_cli_reference_ring_same_bytes_on_every_device_loop(tmp_path):
     path = str(tmp_path / "ring.bin")
     synth.write_stream_bin(path, 8, 250000, 180, 240, duration_s=0.033)
 
-    def go(tag, options, extra=()):
+    def go(tag, options, extra=(), margin=None):
         out, log = str(tmp_path / (tag + ".txt")), str(tmp_path / (tag + ".log"))
         env = dict(os.environ)
         env["BF_ACCEL_OPTIONS"] = options
+        if margin is not None:
+            env["BF_DEBUG_MARGIN"] = str(margin)   # the library's test hook: a 1-pixel margin makes events outrun their bins
         r = subprocess.run([gpu_cli, "--quiet", "--res-x=180", "--res-y=240", "-o", out, "--slice-log=" + log] + list(extra) + [path],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -653,6 +655,6 @@ def test_cli_reference_ring_same_bytes_on_every_device_loop(tmp_path):
     assert go("fused", "fused=2,persist=0") == ref
     assert go("persistent", "fused=2,persist=2") == ref          # the persistent kernel for every slice, cold ones too
     assert go("persistent_auto", "fused=2") == ref               # ... and as the default takes it: warm-started slices only
-    assert go("fused_tight", "fused=2,fused_margin=1") == ref
+    assert go("fused_tight", "fused=2", margin=1) == ref
     assert go("atomics", "fused=0,binned=0") == ref
     assert go("fused_sync", "fused=2", ["--sync"]) == ref

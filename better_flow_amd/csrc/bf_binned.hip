@@ -1726,10 +1726,12 @@ void launch_rebin(const EvSets& sets, int has_perm, long long n, DevState* st, c
 // The scatter kernel's instantiations are the ones the host really picks (bf_run), not the full product: the update's home
 // fixes the form -- HEAD: every work-group applies the pending update itself (a context that has the GPU to itself), lean: the
 // stencil kernel's last work-group did ("co_schedule") -- and form + format fix the work-group sizes:
-//     dense slabs / own pixels + margin plane:  head 1024 threads, lean 512
+//     dense slabs / own pixels + margin plane:  head 1024 threads (bins of >= 1536 events) or 512, lean 512
 //     event lists:                              256 (thousands of small bins) or 512, either form
-// times 1, 2, 4 or 8 events per thread and warp / no warp (the first pass of a cold run): 64 kernels, where the full product
-// of the knobs that used to be options (3 sizes x 4 formats, both forms) was 192.
+// times 1, 2, 4 or 8 events per thread and warp / no warp (the first pass of a cold run): 80 kernels, where the full product
+// of the knobs that used to be options (3 sizes x 4 formats, both forms) was 192.  (The 512-thread head form is what a
+// context alone runs at 640x480 -- BASELINE config 3: 540-690 bins of ~1500 events -- 11.7 us per launch against 17.4 with
+// 1024 threads: measured when round 5's pruning first took it out.)
 template <bool HEAD, int THREADS, int U, int FMT>
 static hipError_t launch_bws2(const BinScatterArgs& a, bool warp, hipStream_t s) {
     // dynamic LDS: the bin's tile; event lists: none
@@ -1771,9 +1773,9 @@ static hipError_t launch_bws(const BinScatterArgs& a, bool warp, int per_thread,
 
 // `threads`: bin_scatter_threads()'s answer for this slice; `per_thread`: events a thread keeps in flight (1, 2, 4 or 8).
 // a.acc != NULL: the head form (the pending update's sums), else the lean one.
-int bin_scatter_threads(int fmt, bool head, bool many_small_bins) {
+int bin_scatter_threads(int fmt, bool head, bool many_small_bins, double events_per_bin) {
     if (fmt == 2) return many_small_bins ? 256 : 512;
-    return head ? 1024 : 512;
+    return (head && events_per_bin >= 1536.0) ? 1024 : 512;
 }
 hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s) {
     const bool head = a.acc != nullptr;
@@ -1781,9 +1783,13 @@ hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threa
         if (threads <= 256) return head ? launch_bws<true, 256, 2>(a, warp, per_thread, s) : launch_bws<false, 256, 2>(a, warp, per_thread, s);
         return head ? launch_bws<true, 512, 2>(a, warp, per_thread, s) : launch_bws<false, 512, 2>(a, warp, per_thread, s);
     }
-    if (a.compact == 3) return head ? launch_bws<true, 1024, 3>(a, warp, per_thread, s) : launch_bws<false, 512, 3>(a, warp, per_thread, s);
+    const bool wide = head && threads >= 1024;
+    if (a.compact == 3)
+        return wide ? launch_bws<true, 1024, 3>(a, warp, per_thread, s)
+                    : (head ? launch_bws<true, 512, 3>(a, warp, per_thread, s) : launch_bws<false, 512, 3>(a, warp, per_thread, s));
     if (a.compact != 0) return hipErrorInvalidValue;
-    return head ? launch_bws<true, 1024, 0>(a, warp, per_thread, s) : launch_bws<false, 512, 0>(a, warp, per_thread, s);
+    return wide ? launch_bws<true, 1024, 0>(a, warp, per_thread, s)
+                : (head ? launch_bws<true, 512, 0>(a, warp, per_thread, s) : launch_bws<false, 512, 0>(a, warp, per_thread, s));
 }
 
 // One pass of the one-kernel iteration (k_fused_pass).  rows_per_tile: 32 or 64.

@@ -380,7 +380,7 @@ __device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
     pc = fma(pc, z, 1.0 / 24.0);
     // cos x = 1 - w, w = z (1/2 - z pc) <= 0.031: ONE rounding at the size of the result (w carries ~2^-52 w of its own, a
     // twentieth of the result's ulp at most).  (1 - z/2) + z^2 pc, the form this replaces, rounded twice at that size: up to
-    // 1.008 ulp, 9 % of the results one ulp off libm's -- measured by tests/test_gpu_parity.py, round 5.)
+    // 1.008 ulp -- measured by tests/test_gpu_parity.py, round 5.)
     *cs = 1.0 - z * fma(-z, pc, 0.5);
 }
 

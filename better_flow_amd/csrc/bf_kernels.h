@@ -171,8 +171,8 @@ struct BinScatterArgs {
     int mcap;
 };
 // work-group size of the scatter kernel for a slice: format (0 dense slabs, 2 event lists, 3 own pixels + margin plane), where the
-// update runs, and -- lists -- whether the grid is thousands of small bins
-int bin_scatter_threads(int fmt, bool head, bool many_small_bins);
+// update runs, -- lists -- whether the grid is thousands of small bins, and -- dense tiles -- the events per bin
+int bin_scatter_threads(int fmt, bool head, bool many_small_bins, double events_per_bin);
 hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
 // The one-kernel iteration (k_fused_pass, bf_binned.hip): warp + scatter + stencil + moments of one image tile per work-group.
 struct FusedArgs {

@@ -150,14 +150,15 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     int ev_per_thread = 8;
     const double ev_per_bin = binned ? (double)c->n / (double)(c->grid.nbins > 0 ? c->grid.nbins : 1) : 0.0;
     // Work-group size of the scatter kernel (bin_scatter_threads, bf_binned.hip).  Dense tiles: 1024 threads for a context that
-    // has the GPU to itself (8.0 against 8.9 us per launch at config 2), 512 for contexts sharing the GPU ("co_schedule": a
+    // has the GPU to itself and bins of thousands of events (8.0 against 8.9 us per launch at config 2; at 640x480, bins of
+    // ~1500 events, 512 threads: 11.7 against 17.4 us), 512 for contexts sharing the GPU ("co_schedule": a
     // 1024-thread work-group with its 51 KB tile needs half a CU's wave slots free at once and waits for them while the other
     // contexts' kernels hold a few each -- 16.7 instead of 8.0 us under four contexts; with 512 threads 170 -> 190 Mevents/s).
     // Event lists over thousands of small bins -- 1280x720 at scale 3: 1620 bins of ~600 events, six per CU -- run 256-thread
     // work-groups (16.6 against 18.6 us per scatter launch there at 1 M events, 8.2 against 13.3 at 100 k); with a couple of
     // bins per CU -- 640x480, 540 bins -- 512 threads stay ahead (6.3 against 8.2).
     const bool many_small_bins = c->fmt == 2 && c->n_cus > 0 && c->grid.nbins >= 4 * c->n_cus && ev_per_bin < 1024.0;
-    const int bin_threads = bin_scatter_threads(c->fmt, head_update, many_small_bins);
+    const int bin_threads = bin_scatter_threads(c->fmt, head_update, many_small_bins, ev_per_bin);
     if (binned) {
         // events a scatter thread keeps in flight:
         // (event lists: registers, not LDS, set the occupancy there -- two events per thread keep four work-groups on a

@@ -1247,8 +1247,8 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(const uint32_t* __res
     tl_stamp(a.tl, a.j, 7);
     __syncthreads();
     tl_stamp(a.tl, a.j, 8);
-    Sums sm;
-    sums_zero(sm);
+    SumsT smt;   // (a thread's own pixels: 32-bit integer sums, see bf_device_fns.h)
+    sums_zero(smt);
     const int hR = R / 2, hC = C / 2;
 #pragma unroll
     for (int k = 0; k < (TR * TC) / 256; ++k) {
@@ -1257,9 +1257,10 @@ __global__ __launch_bounds__(256 * NSUB) void k_fused_pass(const uint32_t* __res
         const int gr = r0 + lr, gc = c0 + lc;
         if (gr < R && gc < C) {
             float gx, gy;
-            stencil_px<TW>(&s_time[g][(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, sm, gx, gy);
+            stencil_px<TW>(&s_time[g][(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, smt, gx, gy);
         }
     }
+    const Sums sm = sums_widen(smt);
     constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
     tl_stamp(a.tl, a.j, 9);
     block_reduce_publish<256, kPack>(sm, s_rpart[g], lt, r0 - hR, c0 - hC);
@@ -1309,8 +1310,13 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
     __shared__ unsigned long long s_acc[PR * PC];
     __shared__ float s_time[TH * TW];
     __shared__ Sums s_red[NT / 64];
+    __shared__ double s_rcp[kRcpTab];   // 1 / i (time_from_sums): requested with the first loads, in LDS before the first barrier
+    static_assert(NT >= kRcpTab, "one table entry per thread");
     const int R = pre.R, C = pre.C;
     const int tid = threadIdx.x;
+    // (the table's address comes with the code -- see c_rcp --, so this load leaves at once, ahead of everything that waits for
+    // the argument block; parked in LDS before the first barrier)
+    const double rcp_v = tid < kRcpTab ? c_rcp.v[tid] : 0.0;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
     BinGrid g = a.g;   // (the fields the slab addresses use come from the preloaded arguments)
@@ -1573,26 +1579,27 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
             s_bits[i] = (gr >= 0 && gr < R) ? a.ovf_bits[(size_t)gr * (size_t)a.ovf_pitch + (size_t)((c0 >> 5) + (i & 3))] : 0u;
         }
     }
+    if (tid < kRcpTab) s_rcp[tid] = rcp_v;
     tl_stamp(a.tl, a.tl_launch, 2);
     __syncthreads();
     tl_stamp(a.tl, a.tl_launch, 3);
     // (same thread mapping: uniform row, one column per lane -- the box's LDS addresses are one per-thread base plus
     // immediates, the row tests are scalar)
-    auto time_px = [&](const int tr, const int tc) {
+    // s x s box sum == the s x s splat of accel_lib.h:160-165 on integer planes (lists: the plane already holds box sums)
+    auto box_at = [&](const int tr, const int tc) {
+        if (compact) return s_acc[tr * TW + tc];
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int da = 0; da <= 2 * HS; ++da)
+#pragma unroll
+            for (int db = 0; db <= 2 * HS; ++db) pk += s_acc[(tr + da) * PC + (tc + db)];
+        return pk;
+    };
+    auto time_px = [&](const int tr, const int tc, const unsigned long long pk) {
         const int idx = tr * TW + tc;
         const int gr = r0 - 1 + tr, gc = c0 - 1 + tc;
         float tv = 0.f;
         if (gr >= 0 && gr < R && gc >= 0 && gc < C) {
-            // s x s box sum == the s x s splat of accel_lib.h:160-165 on integer planes
-            unsigned long long pk = 0;
-            if (compact) {
-                pk = s_acc[idx];   // already the box sum
-            } else {
-#pragma unroll
-                for (int da = 0; da <= 2 * HS; ++da)
-#pragma unroll
-                    for (int db = 0; db <= 2 * HS; ++db) pk += s_acc[(tr + da) * PC + (tc + db)];
-            }
             unsigned long long acc = pk & bm;
             uint32_t cacc = (uint32_t)(pk >> bt);
             bool box_dirty = false;
@@ -1619,28 +1626,53 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
                         }
                     }
             }
-            tv = time_from_sums(cacc, (long long)acc, a.tmin);
-            if (tr >= 1 && tr <= TR && tc >= 1 && tc <= TC) {
-                if (a.time_out) a.time_out[(size_t)gr * C + gc] = tv;
-                if (a.count_out) a.count_out[(size_t)gr * C + gc] = cacc;
-            }
+            tv = time_from_sums(cacc, (long long)acc, a.tmin, s_rcp);
+            // (no time / count image out of this kernel: only bf_run launches it -- the stand-alone operators read the planes
+            // with k_stencil, bf_kernels.hip)
         }
         s_time[idx] = tv;
     };
+    constexpr int LW = TH % NW;   // the first LW waves take KT rows, the others KT - 1 (LW == 0: all KT)
+    if constexpr (COMPACT) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const int tr = wv + k * NW;
-        if (tr < TH) time_px(tr, lane);
+        for (int k = 0; k < KT; ++k) {
+            const int tr = wv + k * NW;
+            if (tr < TH) time_px(tr, lane, box_at(tr, lane));
+        }
+    } else {
+        // Dense planes: a wave takes CONSECUTIVE rows (which rows a wave takes is free: the time tile is complete before anybody
+        // reads it, and the order of the moment sums is the tail's, not this loop's), so that a lane's boxes share their rows:
+        // the horizontal sums of the n + 2 HS plane rows under its n pixels once, then each box as 2 HS + 1 of them -- for
+        // scale 3 and five rows 21 LDS reads and 24 64-bit adds instead of 45 and 40.
+        const int nrows = (LW == 0 || wv < LW) ? KT : KT - 1;                              // (uniform)
+        const int rbeg = (LW == 0 || wv < LW) ? wv * KT : LW * KT + (wv - LW) * (KT - 1);
+        unsigned long long hsum[KT + 2 * HS];
+#pragma unroll
+        for (int j = 0; j < KT + 2 * HS; ++j) {
+            hsum[j] = 0ull;
+            if (j < nrows + 2 * HS) {
+#pragma unroll
+                for (int db = 0; db <= 2 * HS; ++db) hsum[j] += s_acc[(rbeg + j) * PC + (lane + db)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            if (i < nrows) {
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int da = 0; da <= 2 * HS; ++da) pk += hsum[i + da];
+                time_px(rbeg + i, lane, pk);
+            }
+        }
     }
     // the tile's last XT columns: one column each for the waves that had a row less than the others (with 18 rows on four
     // waves: waves 2 and 3), so that every wave makes the same number of passes
-    constexpr int LW = TH % NW;   // the first LW waves took KT rows
     if constexpr (LW != 0 && NW - LW >= XT && TH <= 64) {
-        if (wv >= LW && wv < LW + XT && lane < TH) time_px(lane, 64 + (wv - LW));
+        if (wv >= LW && wv < LW + XT && lane < TH) time_px(lane, 64 + (wv - LW), box_at(lane, 64 + (wv - LW)));
     } else {
         if (lane < KT * XT) {
             const int tr = wv + (lane / XT) * NW;
-            if (tr < TH) time_px(tr, 64 + lane % XT);
+            if (tr < TH) time_px(tr, 64 + lane % XT, box_at(tr, 64 + lane % XT));
         }
     }
     __syncthreads();
@@ -1648,7 +1680,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
     const bool do_zero = a.zero_plane && sload(a.ovf_prev) != 0;   // the other plane buffer is dirty: clear it for the next iteration
     // (the accumulator plane is free from here on: the wave totals of the moment sums go through it)
     static_assert((size_t)PR * PC >= (size_t)(NT / 64) * 192, "the reduction's scratch fits the accumulator plane");
-    stencil_tail<TR, TC, NT>(a, s_time, s_red, r0, c0, do_zero, reinterpret_cast<double*>(s_acc));
+    stencil_tail<TR, TC, NT, false>(a, s_time, s_red, r0, c0, do_zero, reinterpret_cast<double*>(s_acc));
 }
 
 // Two builds of each: as the compiler allocates it (~100 scalar registers: the rows live in the scalar unit), and with

@@ -35,6 +35,7 @@ constexpr int kEvPerThread = 4;   // 16-byte vector loads of xy / t / p
 constexpr int kTileR = 16;        // stencil tile: rows
 constexpr int kTileC = 64;        // stencil tile: columns
 constexpr int kMaxHalfScale = 4;  // scale <= 9
+constexpr int kRcpTab = 256;      // entries of the reciprocal table of the stencil kernel's division by the event count (time_from_sums)
 // overflow counter of one iteration (tile-binned loop): a flag line and 16 counter lines of 32 words (bf_device_fns.h)
 constexpr int kOvfLines = 16, kOvfStride = 32, kOvfSlotWords = (1 + kOvfLines) * kOvfStride;
 

@@ -341,11 +341,35 @@ __device__ __forceinline__ Sums block_reduce_sums(const Sums& sm, unsigned long 
 
 // Mean time of one pixel from its exact integer sums (accel_lib.h:162,172): the f32 sum of
 // seconds is the integer-ns sum rounded once, then the f32 divide by the count.
-__device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_biased, long long tmin) {
+// `rcp` (optional, LDS): rcp[i] = RN64(1.0 / i) for i < kRcpTab.  The f32 division by the pixel's event count -- ~11 vector
+// instructions of scale / reciprocal / refinement / fix-up, once per time pixel -- then becomes a conversion, a table read
+// and one f64 product, and gives the SAME bits: with q = a / b the real quotient of an f32 a by an integer 1 <= b < 2^8,
+// t = RN64(a * RN64(1 / b)) = q (1 + d), |d| <= 2^-52; RN32(t) differs from RN32(q) only if a midpoint m between two
+// adjacent f32 values lies between q and t.  a and b m are both multiples of 2^(e - 24) (e the binade of q), so q - m =
+// k 2^(e - 24) / b for an integer k, and k = 0 would mean a = b m with m an odd multiple of 2^(e - 24) of 25 significant
+// bits: for odd b >= 3 the product b m is odd and wider than a's 24 bits, for even b halve a and b first, for b a power of
+// two the division is exact in f32 and in f64.  So |q - m| >= 2^(e - 24) / 255 > 2^(e - 32), while |t - q| < 2^(e - 51).
+// (tests/exhaustive_div.c (d) checks the identity for EVERY finite f32 a and every b in [1, 255]: no mismatch with a normal
+// quotient; a sum of integer nanoseconds is 0 or >= 1e-9, far above the subnormal range.)
+// RN64(1 / i), i < kRcpTab, for time_from_sums' division by the pixel's event count: a compile-time table in constant memory.
+// (Its address comes with the code, not through the argument block: a first version passed a pointer in StencilArgs and
+// loaded the table at the kernel's entry -- the load's address then waited for the argument block's fetch ahead of EVERY
+// slab load, which the preloaded arguments exist to avoid: alone the kernel was still 9 % faster, with four contexts on the
+// GPU the bench fell from 201 to 135 Mevents/s.)
+struct RcpTab {
+    double v[kRcpTab];
+    constexpr RcpTab() : v{} {
+        for (int i = 1; i < kRcpTab; ++i) v[i] = 1.0 / (double)i;
+    }
+};
+static __constant__ RcpTab c_rcp = RcpTab();
+
+__device__ __forceinline__ float time_from_sums(uint32_t cnt, long long tsum_biased, long long tmin, const double* rcp = nullptr) {
     if (cnt == 0) return 0.f;
     // (tmin is a slice-local time that fits 32 bits: one v_mad_i64_i32 instead of a 64 x 64-bit multiply)
     const long long ts = tsum_biased + (long long)(int)cnt * (long long)(int)tmin;
     const float sum_s = (float)div_1e9((double)ts);
+    if (rcp && cnt < (uint32_t)kRcpTab) return (float)((double)sum_s * rcp[cnt]);
     return sum_s / (float)cnt;
 }
 
@@ -627,61 +651,79 @@ __device__ __forceinline__ void model_update_rest(DevState* st, bf_trace_rec* tr
 // One pixel of the gated 3x3 Scharr (accel_lib.h:513-615) and its contribution to the centre-of-
 // mass and moment sums (object_model.cpp:4-39,103-126).  tp points at the pixel inside an LDS time
 // tile whose row pitch is TW (halo 1 all round); (gr, gc) is the pixel in the R x C image.
-template <int TW>
-__device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int R, int C, int hR, int hC, Sums& sm,
+// The same sums with 32-bit integer fields: what one THREAD accumulates over its handful of pixels (the 64-bit adds of
+// `Sums` are two vector instructions each, three of them per valid pixel); widened by sums_widen before any reduction.
+struct SumsT {
+    int n, sci, scj;
+    double sgx, sgy, sigx, sigy, sjgx, sjgy;
+};
+__device__ __forceinline__ void sums_zero(SumsT& s) {
+    s.n = s.sci = s.scj = 0;
+    s.sgx = s.sgy = s.sigx = s.sigy = s.sjgx = s.sjgy = 0.0;
+}
+__device__ __forceinline__ Sums sums_widen(const SumsT& t) {
+    Sums s;
+    s.n = t.n; s.sci = t.sci; s.scj = t.scj;
+    s.sgx = t.sgx; s.sgy = t.sgy; s.sigx = t.sigx; s.sigy = t.sigy; s.sjgx = t.sjgx; s.sjgy = t.sjgy;
+    return s;
+}
+
+// BRANCH-FREE: every lane reads its nine taps and does the arithmetic, the gates select at the end.  (With `if (valid)` /
+// `if (all)` blocks the compiler kept the running sums in different registers on the two paths and paid for it in copies --
+// ~20 v_mov per pixel -- while a wave only skips a block when all 64 lanes agree, i.e. almost never.)  Same bits: what the
+// gates used to skip is replaced by adding +0.0 -- x + 0.0 == x for every x but -0.0, and a running sum is never -0.0 (it
+// starts as +0.0, and in round-to-nearest a sum is -0.0 only if both terms are) -- and by fma(c, +0.0, s) = s + (+-0.0) = s.
+template <int TW, class S>
+__device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int R, int C, int hR, int hC, S& sm,
                                            float& gx, float& gy) {
     const float ctr = tp[0];
-    gx = 0.f;
-    gy = 0.f;
     const bool v = valid_px(ctr);
-    if (v && gr >= 1 && gr < R - 1 && gc >= 1 && gc < C - 1) {
-        // accel_lib.h:594-604: k = column offset (outer), l = row offset (inner),
-        // idx = 3k + l; sharr_x = {3,0,-3,10,0,-10,3,0,-3},
-        // sharr_y = {3,10,3,0,0,0,-3,-10,-3}; any tap <= 1e-6 -> gradient stays 0.
-        const float t00 = tp[-TW - 1], t10 = tp[-1], t20 = tp[TW - 1];
-        const float t01 = tp[-TW], t21 = tp[TW];
-        const float t02 = tp[-TW + 1], t12 = tp[1], t22 = tp[TW + 1];
-        const bool all = valid_px(t00) && valid_px(t10) && valid_px(t20) &&
-                         valid_px(t01) && valid_px(t21) && valid_px(t02) &&
-                         valid_px(t12) && valid_px(t22);
-        if (all) {
-            // The reference adds all nine weight * tap products in this order, including the weights that are 0.
-            // Those terms are dropped here without changing a bit: every tap passed valid_px, so it is a finite
-            // positive number and tap * 0.f == +0.f; the running sum is never -0.f (it starts as 0.f + a positive
-            // product, and a sum of non-zero terms can only cancel to +0.f in round-to-nearest), and x + (+0.f) == x
-            // for every x other than -0.f.
-            float dx = 0.f, dy = 0.f;
-            // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
-            dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
-            /* t10 * 0.f */        dy = dy + t10 * 10.f;
-            dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
-            // k = 1 (column c): dy's three weights are 0, dx's centre weight is 0
-            dx = dx + t01 * 10.f;
-            dx = dx + t21 * -10.f;
-            // k = 2 (column c+1)
-            dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
-            /* t12 * 0.f */        dy = dy + t12 * -10.f;
-            dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
-            gx = dx;
-            gy = dy;
-        }
-    }
-    if (v) {
-        // object_model.cpp:22-30 and :112-116 in one pass, centred coordinates
-        const int ci = gr - hR, cj = gc - hC;
-        sm.n += 1;
-        sm.sci += ci;
-        sm.scj += cj;
-        const double gxd = (double)gx, gyd = (double)gy;
-        sm.sgx += gxd;
-        sm.sgy += gyd;
-        // (an integer below 2^21 times an f32 value is exact in f64, so the fused multiply-add rounds exactly where the
-        // separate multiply and add did: same bits, four instructions fewer per pixel)
-        sm.sigx = fma((double)ci, gxd, sm.sigx);
-        sm.sigy = fma((double)ci, gyd, sm.sigy);
-        sm.sjgx = fma((double)cj, gxd, sm.sjgx);
-        sm.sjgy = fma((double)cj, gyd, sm.sjgy);
-    }
+    // accel_lib.h:594-604: k = column offset (outer), l = row offset (inner),
+    // idx = 3k + l; sharr_x = {3,0,-3,10,0,-10,3,0,-3},
+    // sharr_y = {3,10,3,0,0,0,-3,-10,-3}; any tap <= 1e-6 -> gradient stays 0.
+    const float t00 = tp[-TW - 1], t10 = tp[-1], t20 = tp[TW - 1];
+    const float t01 = tp[-TW], t21 = tp[TW];
+    const float t02 = tp[-TW + 1], t12 = tp[1], t22 = tp[TW + 1];
+    // "all eight taps > 1e-6f" as ONE comparison of their minimum -- taken on the bit patterns as signed integers (three
+    // v_min3_i32 + one v_min_i32 instead of eight compares): for non-negative floats the integer order is the float order;
+    // a negative tap (mean time before the slice start) or -0.f has the sign bit set, is the integer minimum, and fails
+    // the test as it must.  No NaN can be here: a time pixel is 0 or a finite quotient.
+    const int m8 = min(min(min(__float_as_int(t00), __float_as_int(t10)), min(__float_as_int(t20), __float_as_int(t01))),
+                       min(min(__float_as_int(t21), __float_as_int(t02)), min(__float_as_int(t12), __float_as_int(t22))));
+    const bool grad = v && valid_px(__int_as_float(m8)) && gr >= 1 && gr < R - 1 && gc >= 1 && gc < C - 1;
+    // The reference adds all nine weight * tap products in this order, including the weights that are 0.
+    // Those terms are dropped here without changing a bit: every tap passed valid_px, so it is a finite
+    // positive number and tap * 0.f == +0.f; the running sum is never -0.f (it starts as 0.f + a positive
+    // product, and a sum of non-zero terms can only cancel to +0.f in round-to-nearest), and x + (+0.f) == x
+    // for every x other than -0.f.  (Where the gate is closed the taps may be anything finite: the result is discarded.)
+    float dx = 0.f, dy = 0.f;
+    // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
+    dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
+    /* t10 * 0.f */        dy = dy + t10 * 10.f;
+    dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
+    // k = 1 (column c): dy's three weights are 0, dx's centre weight is 0
+    dx = dx + t01 * 10.f;
+    dx = dx + t21 * -10.f;
+    // k = 2 (column c+1)
+    dx = dx + t02 * 3.f;   dy = dy + t02 * -3.f;
+    /* t12 * 0.f */        dy = dy + t12 * -10.f;
+    dx = dx + t22 * -3.f;  dy = dy + t22 * -3.f;
+    gx = grad ? dx : 0.f;
+    gy = grad ? dy : 0.f;
+    // object_model.cpp:22-30 and :112-116 in one pass, centred coordinates; an invalid pixel adds zeros
+    const int ci = gr - hR, cj = gc - hC;
+    sm.n += v ? 1 : 0;
+    sm.sci += v ? ci : 0;
+    sm.scj += v ? cj : 0;
+    const double gxd = (double)gx, gyd = (double)gy;   // (+0.0 wherever the gradient gate is closed)
+    sm.sgx += gxd;
+    sm.sgy += gyd;
+    // (an integer below 2^21 times an f32 value is exact in f64, so the fused multiply-add rounds exactly where the
+    // separate multiply and add did: same bits, four instructions fewer per pixel)
+    sm.sigx = fma((double)ci, gxd, sm.sigx);
+    sm.sigy = fma((double)ci, gyd, sm.sigy);
+    sm.sjgx = fma((double)cj, gxd, sm.sjgx);
+    sm.sjgy = fma((double)cj, gyd, sm.sjgy);
 }
 
 typedef unsigned int bf_u32x4 __attribute__((ext_vector_type(4)));
@@ -797,14 +839,16 @@ __device__ __forceinline__ unsigned long long acc_reduce_wave(const unsigned lon
 // (object_model.cpp:4-39,103-126), optional gradient output, clearing of the other plane
 // buffer, and the wave64-shuffle + LDS reduction into one Partial per work-group.
 // NT: threads of the work-group (256, or 512 on small images: half the pixels per thread, a shorter dependent chain).
-template <int TR, int TC, int NT>
+// OUT: the caller may ask for the gradient planes (the stand-alone operators); the loop's stencil kernel never does, and the
+// compiled-out stores take their address arithmetic and their scalar registers with them.
+template <int TR, int TC, int NT, bool OUT = true>
 __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* s_time, Sums* s_red,
                                              int r0, int c0, bool do_zero, double* s_scr = nullptr /* NT / 64 x 192 doubles of free LDS */) {
     constexpr int TW = TC + 2;
     const int R = a.R, C = a.C;
     const int tid = threadIdx.x;
-    Sums sm;
-    sums_zero(sm);
+    SumsT smt;   // (a thread's own pixels: 32-bit integer sums)
+    sums_zero(smt);
     const int hR = R / 2, hC = C / 2;
     // (a wave covers one tile row: the row is uniform -- scalar unit --, the column is the lane)
     static_assert(TC == 64 && NT % 64 == 0, "one lane per tile column");
@@ -815,8 +859,8 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         const int gr = r0 + lr, gc = c0 + lc;
         if (gr < R && gc < C) {
             float gx, gy;
-            stencil_px<TW>(&s_time[(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, sm, gx, gy);
-            if (a.gx_out) {
+            stencil_px<TW>(&s_time[(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, smt, gx, gy);
+            if (OUT && a.gx_out) {
                 a.gx_out[(size_t)gr * C + gc] = gx;
                 a.gy_out[(size_t)gr * C + gc] = gy;
             }
@@ -840,6 +884,7 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
             }
         }
     }
+    const Sums sm = sums_widen(smt);
     if (a.acc) {
         tl_stamp(a.tl, a.tl_launch, 5);
         // Fused-update form (a.ticket): the state is stable while this kernel runs (only its own last work-group writes

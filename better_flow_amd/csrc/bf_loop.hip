@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
         tl_stamp(a.tl, j, 4);
         __syncthreads();
         tl_stamp(a.tl, j, 5);
-        Sums sm;
-        sums_zero(sm);
+        SumsT smt;   // (a thread's own pixels: 32-bit integer sums, see bf_device_fns.h)
+        sums_zero(smt);
 #pragma unroll
         for (int k = 0; k < (TR * TC) / 256; ++k) {
             const int pidx = lt_ + k * 256;
@@ -351,9 +351,10 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
             const int gr = r0 + lr, gc = c0 + lc;
             if (gr < R && gc < C) {
                 float gx, gy;
-                stencil_px<TW>(&s_time[g][(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, sm, gx, gy);
+                stencil_px<TW>(&s_time[g][(lr + 1) * TW + (lc + 1)], gr, gc, R, C, hR, hC, smt, gx, gy);
             }
         }
+        const Sums sm = sums_widen(smt);
         constexpr bool kPack = TR * TC <= 1024 && TR <= 64 && TC <= 64;
         tl_stamp(a.tl, j, 6);
         block_reduce_publish<256, kPack>(sm, s_rpart[g], lt_, r0 - hR, c0 - hC);   // (work-group barrier inside)

@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         // whatever the bins' sizes, and it costs two memory round trips (counts, entries) like any gather.
         constexpr int kMaxBins = 32;
         __shared__ uint32_t s_eoff[kMaxBins + 1];
-        __shared__ int s_ebase[kMaxBins], s_eoy[kMaxBins], s_eox[kMaxBins];
+        __shared__ int2 s_ebin[kMaxBins];   // x: element offset of the bin's list minus its first flattened entry number; y: oy << 16 | ox & 0xffff
         const int ncol = bc_hi - bc_lo + 1;
         const int nbin_ = min((br_hi - br_lo + 1) * ncol, kMaxBins);
         if (tid < 64) {
@@ -1380,9 +1380,8 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
             }
             if (tid < nbin_) {
                 s_eoff[tid + 1] = incl;
-                s_ebase[tid] = bin * LLi + (int)first - (int)(incl - n);
-                s_eoy[tid] = (br_lo + r) * g.TSR - g.D - (r0 - 1);
-                s_eox[tid] = ((bc_lo + cc) << g.lg) - g.D - (c0 - 1);
+                const int oy_ = (br_lo + r) * g.TSR - g.D - (r0 - 1), ox_ = ((bc_lo + cc) << g.lg) - g.D - (c0 - 1);   // (|.| < 2^15)
+                s_ebin[tid] = make_int2(bin * LLi + (int)first - (int)(incl - n), (int)(((uint32_t)oy_ << 16) | ((uint32_t)ox_ & 0xffffu)));
             }
             if (tid == 0) s_eoff[0] = 0;
         }
@@ -1390,25 +1389,30 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         __syncthreads();   // (the box plane is zero, the bin table is in place)
         const uint32_t E = s_eoff[nbin_];
         for (uint32_t e = tid; e < E; e += NT) {
-            int base = s_ebase[0], oy = s_eoy[0], ox = s_eox[0];
-            for (int j = 1; j < nbin_; ++j) {   // (uniform trip count, LDS broadcast reads)
-                const bool ge = e >= s_eoff[j];
-                base = ge ? s_ebase[j] : base;
-                oy = ge ? s_eoy[j] : oy;
-                ox = ge ? s_eox[j] : ox;
-            }
+            // which bin's list holds entry e: the number of bins whose first entry number is <= e (a compare and an add per
+            // bin; uniform trip count, LDS broadcast reads), then ONE gather of that bin's record
+            int jb = 0;
+            for (int j = 1; j < nbin_; ++j) jb += e >= s_eoff[j] ? 1 : 0;
+            const int2 eb = s_ebin[jb];
+            const int base = eb.x, oy = eb.y >> 16, ox = (int)(short)(eb.y & 0xffff);
             const uint32_t idx = a.cidx[(uint32_t)(base + (int)e)];
             const unsigned long long v = pre.slabs[(uint32_t)(base + (int)e)];
             const int lx = (int)__umulhi(idx, g.mul_l);            // idx / L
             const int tr = oy + lx, tc = ox + (int)idx - lx * g.L;  // the point, in time-pixel coordinates
             if (tr >= -HS && tr < TH + HS && tc >= -HS && tc < TW + HS) {
+                // (one unsigned compare per box row and per box column, not four signed ones per add)
+                bool okr[2 * HS + 1], okc[2 * HS + 1];
 #pragma unroll
-                for (int da = -HS; da <= HS; ++da)
+                for (int d = 0; d <= 2 * HS; ++d) {
+                    okr[d] = (unsigned)(tr + d - HS) < (unsigned)TH;
+                    okc[d] = (unsigned)(tc + d - HS) < (unsigned)TW;
+                }
+                unsigned long long* q = &s_acc[(tr - HS) * TW + (tc - HS)];
 #pragma unroll
-                    for (int db = -HS; db <= HS; ++db) {
-                        const int rr = tr + da, cc = tc + db;
-                        if (rr >= 0 && rr < TH && cc >= 0 && cc < TW) atomicAdd(&s_acc[rr * TW + cc], v);
-                    }
+                for (int da = 0; da <= 2 * HS; ++da)
+#pragma unroll
+                    for (int db = 0; db <= 2 * HS; ++db)
+                        if (okr[da] && okc[db]) atomicAdd(&q[da * TW + db], v);
             }
         }
     } else if constexpr (MODE == 2) {

@@ -577,13 +577,6 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     if (split) {   // the last executed iteration added to margin plane b0 ^ ((it - 1) & 1), and the lists name those pixels
         if (d.hot.it > 0) c->m_dirty_plane = b0 ^ ((d.hot.it - 1) & 1);
         c->m_unknown = d.rc < 0;   // (a run stopped at the iteration cap may have one executed launch more than `it` counts)
-        if (getenv("BF_DEBUG_MARGIN")) {   // entries of the bins' margin lists after the last executed launch
-            std::vector<uint32_t> mc((size_t)c->m_nbins);
-            HIP_TRY(c, hipMemcpy(mc.data(), c->d_mcount, mc.size() * 4, hipMemcpyDeviceToHost));
-            unsigned long long tot = 0; uint32_t mx = 0;
-            for (uint32_t v : mc) { tot += v; mx = v > mx ? v : mx; }
-            fprintf(stderr, "margin entries after %d iterations: %llu in %d bins (max %u of %d)\n", d.hot.it, tot, c->m_nbins, mx, c->m_cap);
-        }
     }
     if (binned && !fused) {   // the last iteration scattered its overflow events into buffer b0 ^ ((it - 1) & 1); the other one is clean
         h.hot.ovf_cnt[b0 ^ (d.hot.it & 1)] = 0;

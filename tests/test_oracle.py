@@ -462,3 +462,30 @@ def test_color_time_img_structure(oracle_lib):
         diff = np.abs(img.astype(np.int64) - want.astype(np.int64)).max(axis=2)
         # f32 running sums vs float64 sums: only pixels sitting on a hue / saturation truncation boundary may move
         assert (diff > 0).mean() < 0.01 and diff.max() <= 10, (sc, (diff > 0).mean(), diff.max())
+
+
+def test_division_by_event_count_as_table_product():
+    """The device's stencil kernel replaces the reference's `sum / count` (f32 / f32, accel_lib.h:172) by
+    (float)((double)sum * RN64(1.0 / count)) for counts below 256 (bf_device_fns.h: time_from_sums).  tests/exhaustive_div.c (d)
+    proves the identity for EVERY finite f32 sum and every count in [1, 255] (run once per change of that code: 10 minutes);
+    this is the sampled form that runs with the suite: 4 M random dividends of all magnitudes a time sum can have, every
+    count, plus dividends adjacent to exact multiples (where a quotient comes closest to a rounding boundary)."""
+    rng = np.random.default_rng(7)
+    a = np.concatenate([
+        (10.0 ** rng.uniform(-9, 1.5, 2000000)).astype(np.float32),                       # 1 ns .. 30 s
+        rng.uniform(0, 8, 1000000).astype(np.float32),
+        -(10.0 ** rng.uniform(-9, 0, 500000)).astype(np.float32),                          # events before the slice start
+        np.array([0.0, 1e-9, 3e-2, 7.65], np.float32),
+    ])
+    # neighbours of exact products q * b: quotients next to representable values
+    q = rng.uniform(1e-6, 1.0, 500000).astype(np.float32)
+    b_ = rng.integers(1, 256, 500000).astype(np.float32)
+    prod = (q * b_).astype(np.float32)
+    a = np.concatenate([a, prod, np.nextafter(prod, np.float32(np.inf)), np.nextafter(prod, np.float32(-np.inf))])
+    rcp = 1.0 / np.arange(1, 256, dtype=np.float64)
+    bad = 0
+    for b in range(1, 256):
+        ref = a / np.float32(b)
+        got = (a.astype(np.float64) * rcp[b - 1]).astype(np.float32)
+        bad += int(np.count_nonzero(ref.view(np.uint32) != got.view(np.uint32)))
+    assert bad == 0, bad

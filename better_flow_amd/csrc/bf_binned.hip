@@ -41,6 +41,13 @@ __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* b
     return *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// Element idx of an array at a uniform base: scalar base register pair + 32-bit per-thread byte offset (no 64-bit vector address
+// arithmetic per access).  The event arrays of a tile-binned slice stay below 2^32 bytes (bf_set_cloud: < 2^29 events).
+template <class T>
+__device__ __forceinline__ T ld_idx(const T* base, uint32_t idx) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (uint32_t)sizeof(T));
+}
+
 // Image tile of the current target of one event (clamped into the grid: events whose target
 // is outside the image are rejected by the scatter but still need a home bin).
 __device__ __forceinline__ int bin_of(uint32_t xy, float2 p, const HotState& hs, const BinGrid& g) {
@@ -404,7 +411,7 @@ __device__ __forceinline__ bool event_target(const ScatterHot& hs, float2* p, ui
         double nx, ny;
         warp_products(hs.wp, pr_x, pr_y, ti, q, nx, ny);
         // write-through as well (see the slab flush)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&p[i]),
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p) + i * 8u),
                            ((unsigned long long)__float_as_uint(q.y) << 32) | (unsigned long long)__float_as_uint(q.x),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pr_x = pr_from_p(fx, q.x);
@@ -413,7 +420,8 @@ __device__ __forceinline__ bool event_target(const ScatterHot& hs, float2* p, ui
     const int s = hs.scale, hsc = hs.scale / 2;
     X = trunc_scatter(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
     Y = trunc_scatter(pr_y * (double)s + (double)hs.y_sh);
-    return !((X >= hs.wsx + hsc) || (X < hsc) || (Y >= hs.wsy + hsc) || (Y < hsc));
+    // accel_lib.h:157-158: hsc <= X < wsx + hsc and the same for Y -- one unsigned compare each
+    return (unsigned)(X - hsc) < (unsigned)hs.wsx && (unsigned)(Y - hsc) < (unsigned)hs.wsy;
 }
 // the exact slow path: straight into the overflow planes
 __device__ __forceinline__ void overflow_add(const ScatterHot& hs, const BinScatterArgs& a, int X, int Y, unsigned long long dt) {
@@ -433,7 +441,7 @@ __device__ __forceinline__ void scatter_event(const ScatterHot& hs, const Scatte
     if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return;
     const unsigned long long dt = (unsigned long long)((long long)ti - hs.tmin);
     const int lx = X - sg.X0, ly = Y - sg.Y0;
-    if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
+    if (hs.bin_ok && (unsigned)lx < (unsigned)sg.LR && (unsigned)ly < (unsigned)sg.L) {
         atomicAdd(&s_tile[__mul24(lx, sg.L) + ly], (1ull << hs.bin_tbits) + dt);
     } else {   // drifted out of this bin's tile: exact, slow path
         overflow_add(hs, a, X, Y, dt);
@@ -461,7 +469,7 @@ __device__ __forceinline__ uint32_t list_event(const ScatterHot& hs, const Scatt
     row = 0;
     if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return kNoEntry;
     const int lx = X - sg.X0, ly = Y - sg.Y0;
-    if (hs.bin_ok && lx >= 0 && lx < sg.LR && ly >= 0 && ly < sg.L) {
+    if (hs.bin_ok && (unsigned)lx < (unsigned)sg.LR && (unsigned)ly < (unsigned)sg.L) {
         row = lx;
         return (uint32_t)(__mul24(lx, sg.L) + ly);
     }
@@ -689,9 +697,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
             // unconditional loads from a clamped index (no branch per load); dead slots are skipped below
             uint32_t i = base + k * THREADS + tid;
             i = i < end ? i : beg;
-            vxy[k] = xy[i];
-            vt[k] = t[i];
-            vp[k] = p[i];
+            vxy[k] = ld_idx(xy, i);
+            vt[k] = ld_idx(t, i);
+            vp[k] = ld_idx(p, i);
         }
     };
     const uint32_t m_e0 = SPLIT ? margin_preload(a, b, m_prev_n, tid) : 0xffffffffu;   // (ahead of the events: see the lean form)
@@ -870,9 +878,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_
         for (int k = 0; k < U; ++k) {
             uint32_t i = base + k * THREADS + tid;
             i = i < end ? i : beg;
-            vxy[k] = xy[i];
-            vt[k] = t[i];
-            vp[k] = p[i];
+            vxy[k] = ld_idx(xy, i);
+            vt[k] = ld_idx(t, i);
+            vp[k] = ld_idx(p, i);
         }
     };
     if constexpr (COMPACT) {   // event lists: see k_bin_warp_scatter

@@ -149,7 +149,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         const bool dense = (double)w.scale_img_x * (double)w.scale_img_y < 12.0 * (double)c->n ||
                            (double)w.scale_img_x * (double)w.scale_img_y <= 9.0e6;
         c->use_binned = (c->opt_binned == 2 || (c->opt_binned == 1 && dense)) && !c->force_split && !c->has_noise && c->n > 0 &&
-                        g.nbins <= 8192 &&
+                        g.nbins <= 8192 && c->cap_events < (1ll << 29) &&   // (32-bit byte offsets into the event arrays: ld_idx)
                         (size_t)g.LR * g.L * 8 <= (size_t)kBinTileLdsMax && w.scale_img_x < (1 << 20);
         if (c->use_binned) {
             int rc = ensure_cplanes(c);

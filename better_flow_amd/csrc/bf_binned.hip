@@ -418,8 +418,16 @@ __device__ __forceinline__ bool event_target(const ScatterHot& hs, float2* p, ui
         pr_y = pr_from_p(fy, q.y);
     }
     const int s = hs.scale, hsc = hs.scale / 2;
-    X = trunc_scatter(pr_x * (double)s + (double)hs.x_sh);   // accel_lib.h:154-158
-    Y = trunc_scatter(pr_y * (double)s + (double)hs.y_sh);
+    // accel_lib.h:154-158.  The x86 conversion turns NaN into INT_MIN (rejected below); the hardware's turns it into 0 -- which
+    // the window test rejects as well whenever scale / 2 >= 1 (0 < hsc), so only scale 1 needs the two-instruction fix-up
+    // per coordinate (trunc_scatter); the branch is uniform.
+    if (hsc > 0) {
+        X = __double2int_rz(pr_x * (double)s + (double)hs.x_sh);
+        Y = __double2int_rz(pr_y * (double)s + (double)hs.y_sh);
+    } else {
+        X = trunc_scatter(pr_x * (double)s + (double)hs.x_sh);
+        Y = trunc_scatter(pr_y * (double)s + (double)hs.y_sh);
+    }
     // accel_lib.h:157-158: hsc <= X < wsx + hsc and the same for Y -- one unsigned compare each
     return (unsigned)(X - hsc) < (unsigned)hs.wsx && (unsigned)(Y - hsc) < (unsigned)hs.wsy;
 }

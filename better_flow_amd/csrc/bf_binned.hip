@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <limits.h>
+#include <cstdlib>
 
 #include "bf_device.h"
 #include "bf_device_fns.h"

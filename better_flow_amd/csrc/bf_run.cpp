@@ -409,9 +409,13 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 a.tl = c->d_tl;
                 a.tl_launch = launched_iters;
                 ProfScope ps(c, 1);
-                // (contexts of this process sharing the GPU: the other contexts' kernels hold CU slots too -- count the GPU as full whatever
-                // this grid's size, i.e. take the stencil kernel's build that fits 8 work-groups per CU)
-                launch_stencil(a, stencil_src(c, binned), c->stream, (c->opt_co_schedule && g_live_ctx[c->device & 63].load() > 1) ? 1 : c->n_cus);
+                // (contexts of this process sharing the GPU: the other contexts' kernels hold CU slots too.  For event lists -- large
+                // sparse images -- count the GPU as full whatever this grid's size, i.e. take the stencil kernel's build that fits 8
+                // work-groups per CU: config 5 with four contexts 3.27 against 2.90 Mevents/s.  Dense tiles on a grid that does not fill
+                // the GPU by itself keep the plain build: config 2 with four contexts 208.3 against 206.5, round 5 -- since its
+                // instruction diet the kernel gains less from two more work-groups per CU than it loses to the spills.)
+                const bool shared_lists = c->opt_co_schedule && c->fmt == 2 && g_live_ctx[c->device & 63].load() > 1;
+                launch_stencil(a, stencil_src(c, binned), c->stream, shared_lists ? 1 : c->n_cus);
             }
             first = false;
             buf ^= 1;

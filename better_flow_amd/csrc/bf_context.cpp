@@ -6,7 +6,7 @@ std::atomic<int> g_live_ctx[64];
 
 extern "C" {
 
-const char* bf_version(void) { return "bf_accel gfx950 r1"; }
+const char* bf_version(void) { return "bf_accel gfx950 r5"; }
 
 int bf_device_count(int32_t* count) {
     int n = 0;
@@ -458,32 +458,36 @@ int bf_copy_bandwidth(bf_ctx* c, int64_t bytes, int32_t reps, double* gbps_out) 
     HIP_TRY(c, hipSetDevice(c->device));
     bytes &= ~(int64_t)15;
     void *a = nullptr, *b = nullptr;
-    HIP_TRY(c, hipMalloc(&a, (size_t)bytes));
-    HIP_TRY(c, hipMalloc(&b, (size_t)bytes));
-    HIP_TRY(c, hipMemsetAsync(a, 1, (size_t)bytes, c->stream));
-    hipEvent_t e0, e1;
-    HIP_TRY(c, hipEventCreate(&e0));
-    HIP_TRY(c, hipEventCreate(&e1));
-    // the ceiling is the best of a few launch shapes (work-groups per CU, plain / non-temporal accesses), each warmed up
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     double best = 0.0;
-    for (int nt = 0; nt < 2; ++nt)
-        for (int blocks : {1024, 2048, 4096, 8192}) {
-            launch_copy(a, b, bytes, blocks, nt != 0, c->stream);   // warm-up
-            for (int r = 0; r < reps; ++r) {
-                HIP_TRY(c, hipEventRecord(e0, c->stream));
-                launch_copy(a, b, bytes, blocks, nt != 0, c->stream);
-                HIP_TRY(c, hipEventRecord(e1, c->stream));
-                HIP_TRY(c, hipEventSynchronize(e1));
-                float ms = 0.f;
-                HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
-                const double g = 2.0 * (double)bytes / ((double)ms * 1e-3) / 1e9;
-                if (g > best) best = g;
+    const int rc = [&]() -> int {   // (whatever fails, the buffers and events below are released)
+        HIP_TRY(c, hipMalloc(&a, (size_t)bytes));
+        HIP_TRY(c, hipMalloc(&b, (size_t)bytes));
+        HIP_TRY(c, hipMemsetAsync(a, 1, (size_t)bytes, c->stream));
+        HIP_TRY(c, hipEventCreate(&e0));
+        HIP_TRY(c, hipEventCreate(&e1));
+        // the ceiling is the best of a few launch shapes (work-groups per CU, plain / non-temporal accesses), each warmed up
+        for (int nt = 0; nt < 2; ++nt)
+            for (int blocks : {1024, 2048, 4096, 8192}) {
+                launch_copy(a, b, bytes, blocks, nt != 0, c->stream);   // warm-up
+                for (int r = 0; r < reps; ++r) {
+                    HIP_TRY(c, hipEventRecord(e0, c->stream));
+                    launch_copy(a, b, bytes, blocks, nt != 0, c->stream);
+                    HIP_TRY(c, hipEventRecord(e1, c->stream));
+                    HIP_TRY(c, hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+                    const double g = 2.0 * (double)bytes / ((double)ms * 1e-3) / 1e9;
+                    if (g > best) best = g;
+                }
             }
-        }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(a);
-    (void)hipFree(b);
+        return BF_OK;
+    }();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (rc != BF_OK) return rc;
     *gbps_out = best;
     return BF_OK;
 }

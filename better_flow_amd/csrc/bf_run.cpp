@@ -615,6 +615,8 @@ int bf_run_many(bf_ctx* const* ctxs, int32_t n, const bf_run_opts* opts, bf_mode
     auto one = [&](int i) {
         bf_model m;
         bf_run_info inf;
+        memset(&m, 0, sizeof(m));   // (a run refused before it starts writes neither)
+        memset(&inf, 0, sizeof(inf));
         rc[(size_t)i] = bf_run(ctxs[i], opts, &m, &inf);
         if (models_out) models_out[i] = m;
         if (infos_out) { infos_out[i] = inf; infos_out[i].rc = rc[(size_t)i]; }

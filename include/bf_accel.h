@@ -130,7 +130,7 @@ void bf_destroy(bf_ctx *ctx);
  * "OpenCL Error: <n>" prints (accel_lib.h:125,138,253,299,361): errors are returned, the text is kept here. */
 const char *bf_last_error(const bf_ctx *ctx);
 
-/* Library / build identification, e.g. "bf_accel gfx950 r1" (printed by `bf_motion_compensator --version`
+/* Library / build identification, e.g. "bf_accel gfx950 r5" (printed by `bf_motion_compensator --version`
  * next to the reference's version line, bf_motion_compensator.cpp:26-33). */
 const char *bf_version(void);
 

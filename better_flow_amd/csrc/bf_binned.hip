@@ -36,10 +36,19 @@ namespace bf {
 constexpr int kStencilSgprs = 74;
 __device__ __forceinline__ int row_bin(int row, const BinGrid& g) { return (int)__umulhi((uint32_t)row, g.mul_r); }
 
-// 64-bit load at (uniform base) + (per-thread byte offset): the form a global load takes with a scalar base register pair
-// and a 32-bit vector offset -- no vector instruction for the address.
-__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* base, uint32_t byte_off) {
-    return *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(base) + byte_off);
+// 64-bit load at (uniform base) + (uniform byte offset) + (per-thread byte offset): a BUFFER load -- base in a resource
+// descriptor (four scalar registers), the row part of the offset in a scalar register, the column part in one vector register
+// that is the same for every row of the thread.  No vector instruction per load for its address: as plain global loads the
+// compiler formed every address with a 64-bit vector add (the zero-extended column offset is computed in another basic block
+// than the load, so its scalar-base + 32-bit-offset form was not matched): 26 of the stencil kernel's ~620 vector
+// instructions per wave.  (num_records = 2^32 - 1 bytes: no clamping is relied on; word 3: 32-bit raw data format, gfx9.)
+typedef unsigned int bf_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ unsigned long long buf_ld_u64(__amdgpu_buffer_rsrc_t r, uint32_t thread_bytes, uint32_t uniform_bytes) {
+    const bf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)thread_bytes, (int)uniform_bytes, 0);
+    return ((unsigned long long)v.y << 32) | (unsigned long long)v.x;
 }
 
 // Element idx of an array at a uniform base: scalar base register pair + 32-bit per-thread byte offset (no 64-bit vector address
@@ -1460,6 +1469,7 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         moff = __mul24(gr, C);
     };
     unsigned long long w[KR][2], we[XE][2];
+    const __amdgpu_buffer_rsrc_t slab_buf = buf_of(pre.slabs), margin_buf = buf_of(a.m_cur);
     bool c_in, c_edge;
     int c_off, c_gc;
     col_of(lane, c_in, c_edge, c_off, c_gc);
@@ -1470,8 +1480,8 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         row_of(wv + k * NW, r_in, r_edge, r_off, r_moff);   // (uniform: scalar unit)
         w[k][0] = w[k][1] = 0ull;
         if (r_in && c_in) {
-            w[k][0] = ld_u64(pre.slabs + (uint32_t)r_off, (uint32_t)c_off * 8u);
-            if (r_edge || c_edge) w[k][1] = ld_u64(a.m_cur + (uint32_t)r_moff, (uint32_t)c_gc * 8u);
+            w[k][0] = buf_ld_u64(slab_buf, (uint32_t)c_off * 8u, (uint32_t)r_off * 8u);
+            if (r_edge || c_edge) w[k][1] = buf_ld_u64(margin_buf, (uint32_t)c_gc * 8u, (uint32_t)r_moff * 8u);
         }
     }
 #pragma unroll
@@ -1537,28 +1547,35 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         two = brh > brl;
     };
     unsigned long long w[KR][4], we[XE][4];
+    const __amdgpu_buffer_rsrc_t slab_buf = buf_of(pre.slabs);
     bool c_in, c_two;
     int c_lo, c_hi;
     col_of(lane, c_in, c_two, c_lo, c_hi);
+    // No per-lane masking of the loads: a lane whose column lies outside the image, and the second-bin slot of a lane whose
+    // column has no second bin, read an ALWAYS-ZERO cell instead -- column offset 0 of the row, i.e. local column 0 of the
+    // slab of bin column 0, image column -D < 0, which no event is ever added to (the scatter kernel's window test) and which
+    // the scatter kernel's flush writes as 0 in every launch.  What depends on the row (is it inside the image, does it have
+    // a second bin row) is uniform: scalar branches, and the sums below repeat them -- so nothing is zero-filled and no
+    // execution mask is touched: per row two to four loads and one to three 64-bit adds (before: four register pairs
+    // zeroed, the execution mask saved and restored around each conditional load, three adds).  Integer sums: same bits.
+    const uint32_t vo_lo = c_in ? (uint32_t)c_lo * 8u : 0u;
+    const uint32_t vo_hi = (c_in && c_two) ? (uint32_t)c_hi * 8u : 0u;
+    bool rin[KR], rtwo[KR];   // (uniform)
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
-        bool r_in, r_two;
         int r_lo, r_hi;
-        row_of(wv + k * NW, r_in, r_two, r_lo, r_hi);   // (uniform: scalar unit)
-        w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0ull;
-        if (r_in && c_in) {
-            const unsigned long long* pl = pre.slabs + (uint32_t)r_lo;
-            w[k][0] = ld_u64(pl, (uint32_t)c_lo * 8u);
-            if (c_two) w[k][1] = ld_u64(pl, (uint32_t)c_hi * 8u);
-            if (r_two) {
-                const unsigned long long* ph = pre.slabs + (uint32_t)r_hi;
-                w[k][2] = ld_u64(ph, (uint32_t)c_lo * 8u);
-                if (c_two) w[k][3] = ld_u64(ph, (uint32_t)c_hi * 8u);
+        row_of(wv + k * NW, rin[k], rtwo[k], r_lo, r_hi);   // (uniform: scalar unit)
+        if (rin[k]) {
+            w[k][0] = buf_ld_u64(slab_buf, vo_lo, (uint32_t)r_lo * 8u);
+            w[k][1] = buf_ld_u64(slab_buf, vo_hi, (uint32_t)r_lo * 8u);
+            if (rtwo[k]) {
+                w[k][2] = buf_ld_u64(slab_buf, vo_lo, (uint32_t)r_hi * 8u);
+                w[k][3] = buf_ld_u64(slab_buf, vo_hi, (uint32_t)r_hi * 8u);
             }
         }
     }
 #pragma unroll
-    for (int x = 0; x < XE; ++x) {
+    for (int x = 0; x < XE; ++x) {   // the columns beyond the 64th: per-lane rows, so per-lane conditions as before
         const int e = lane + 64 * x;
         bool r_in, r_two, x_in, x_two;
         int r_lo, r_hi, x_lo, x_hi;
@@ -1566,11 +1583,11 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         col_of(64 + e % XC, x_in, x_two, x_lo, x_hi);
         we[x][0] = we[x][1] = we[x][2] = we[x][3] = 0ull;
         if (e < KR * XC && r_in && x_in) {
-            // 32-bit element offsets (the slabs and planes are far below 2^32 bytes): base + offset addressing
-            we[x][0] = pre.slabs[(uint32_t)(r_lo + x_lo)];
-            if (x_two) we[x][1] = pre.slabs[(uint32_t)(r_lo + x_hi)];
-            if (r_two) we[x][2] = pre.slabs[(uint32_t)(r_hi + x_lo)];
-            if (r_two && x_two) we[x][3] = pre.slabs[(uint32_t)(r_hi + x_hi)];
+            // 32-bit byte offsets (the slabs are far below 2^32 bytes)
+            we[x][0] = buf_ld_u64(slab_buf, (uint32_t)(r_lo + x_lo) * 8u, 0u);
+            if (x_two) we[x][1] = buf_ld_u64(slab_buf, (uint32_t)(r_lo + x_hi) * 8u, 0u);
+            if (r_two) we[x][2] = buf_ld_u64(slab_buf, (uint32_t)(r_hi + x_lo) * 8u, 0u);
+            if (r_two && x_two) we[x][3] = buf_ld_u64(slab_buf, (uint32_t)(r_hi + x_hi) * 8u, 0u);
         }
     }
     if (a.check_done && hs.done) return;   // (uniform; before the first barrier -- the loads above are already out)
@@ -1581,7 +1598,14 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
         const int pr = wv + k * NW;
-        if (pr < PR) s_acc[pr * PC + lane] = (w[k][0] + w[k][1]) + (w[k][2] + w[k][3]);
+        if (pr < PR) {
+            unsigned long long sum = 0ull;
+            if (rin[k]) {
+                sum = w[k][0] + w[k][1];
+                if (rtwo[k]) sum += w[k][2] + w[k][3];
+            }
+            s_acc[pr * PC + lane] = sum;
+        }
     }
 #pragma unroll
     for (int x = 0; x < XE; ++x) {

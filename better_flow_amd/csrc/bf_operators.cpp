@@ -151,6 +151,8 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
         c->use_binned = (c->opt_binned == 2 || (c->opt_binned == 1 && dense)) && !c->force_split && !c->has_noise && c->n > 0 &&
                         g.nbins <= 8192 && c->cap_events < (1ll << 29) &&   // (32-bit byte offsets into the event arrays: ld_idx)
                         (size_t)g.LR * g.L * 8 <= (size_t)kBinTileLdsMax && w.scale_img_x < (1 << 20);
+        // (<= 8192 bins x <= 156 KB: slabs, tiled image and margin plane stay below 2^31 bytes -- the stencil kernel's buffer loads
+        // carry 32-bit byte offsets, buf_ld_u64)
         if (c->use_binned) {
             int rc = ensure_cplanes(c);
             if (rc == BF_OK) rc = ensure_bin_buffers(c, g);

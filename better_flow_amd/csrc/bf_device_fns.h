@@ -698,9 +698,9 @@ __device__ __forceinline__ void stencil_px(const float* tp, int gr, int gc, int 
     // positive number and tap * 0.f == +0.f; the running sum is never -0.f (it starts as 0.f + a positive
     // product, and a sum of non-zero terms can only cancel to +0.f in round-to-nearest), and x + (+0.f) == x
     // for every x other than -0.f.  (Where the gate is closed the taps may be anything finite: the result is discarded.)
-    float dx = 0.f, dy = 0.f;
     // k = 0 (column c-1): l = 0,1,2 (rows r-1, r, r+1)
-    dx = dx + t00 * 3.f;   dy = dy + t00 * 3.f;
+    // (the reference's 0.f + t00 * 3.f: with the gate open t00 > 1e-6f, the product is positive and 0.f + it is itself)
+    float dx = t00 * 3.f, dy = dx;
     /* t10 * 0.f */        dy = dy + t10 * 10.f;
     dx = dx + t20 * -3.f;  dy = dy + t20 * 3.f;
     // k = 1 (column c): dy's three weights are 0, dx's centre weight is 0

@@ -104,7 +104,7 @@ struct bf_ctx {
     uint32_t* d_chdr = nullptr;      // compact lists: entries per bin
     int fmt = 0;                     // what this slice's scatter hands to the stencil: 0 dense slabs, 2 event lists, 3 own pixels + margin plane (bf_set_cloud)
     int opt_bin_compact = 1;         // 0 never, 1 when the image is sparse (decided per iteration on the device), 2 always
-    // interior + margin format of a dense slice (fmt 3, bf_binned.hip: flush_split): 0 never, 1 when it is the faster one, 2 always
+    // interior + margin format of a dense slice (fmt 3, bf_scatter.hip: flush_split): 0 never, 1 when it is the faster one, 2 always
     int opt_bin_split = 1;
     unsigned long long* d_mplane[2] = {nullptr, nullptr};   // margin planes (cap_px words each), double buffered like d_plane
     uint32_t* d_mlist = nullptr;     // per bin: the pixels of the margin plane it added to in its last executed launch

@@ -62,7 +62,7 @@ struct MomentAcc {
     unsigned long long f[16];   // 128 bytes: one line per group
 };
 
-// Geometry of the tile-binned scatter (bf_binned.hip): image tiles of TSR rows x TS columns of scaled
+// Geometry of the tile-binned scatter (bf_scatter.hip): image tiles of TSR rows x TS columns of scaled
 // pixels, LDS / slab tiles of LR x L = (TSR + 2 D) x (TS + 2 D), nbr x nbc bins.  TS is a power of two
 // (column -> bin by a shift); TSR is any multiple of 16 (row -> bin by an exact multiply-high), chosen by the
 // host so that the number of bins fills the CUs (one work-group per bin).
@@ -77,7 +77,7 @@ struct BinGrid {
     uint32_t mul_h;    // floor(2^32 / (L / 2)) + 1: row of a 16-byte PAIR of tile pixels (interior + margin format; L is even)
 };
 
-// One-kernel iteration (bf_binned.hip, k_fused_pass).  A tile's events are sorted into nine zones by where their target
+// One-kernel iteration (bf_fused.hip, k_fused_pass).  A tile's events are sorted into nine zones by where their target
 // lay when the bins were built: the centre and, clockwise from the top-left corner, the eight pieces of the strip of width
 // E = H + D along the tile's edge (H = scale / 2 + 1: box sum + Scharr halo; D: the drift a binning tolerates).  A
 // work-group reads its own tile's events and the strips of the eight neighbouring tiles that face it -- ten contiguous
@@ -109,7 +109,7 @@ struct HotState {
                                       // that wait for a re-bin or repeat one do not advance the iteration);
                                       // spare_: launches of the persistent loop kernel (k_fused_loop) completed in this run
     int32_t cs, flip, bin_ok, fmt;    // live event set; flip = a re-bin moved the events to set cs^1; fmt = this slice's scatter writes
-                                      // COMPACT lists (1) instead of dense slabs (0) (informative: bf_binned.hip);
+                                      // COMPACT lists (1) instead of dense slabs (0) (informative: bf_scatter.hip);
                                       // bin_ok = the per-bin packing of this binning fits 64 bits (else: overflow path)
                                     // (committed by the next update)
     // window (host-written at set_cloud)

@@ -1,4 +1,4 @@
-// bf_device_fns.h -- device-side helpers shared by bf_kernels.hip and bf_binned.hip.
+// bf_device_fns.h -- device-side helpers shared by the kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -119,6 +119,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+
+// Row -> bin row of the tile-binned loops: exact division by the (not necessarily power-of-two) tile height.
+__device__ __forceinline__ int row_bin(int row, const BinGrid& g) { return (int)__umulhi((uint32_t)row, g.mul_r); }
 
 constexpr int kTicketGroups = 32;   // arrival counters of the fused reduction (64 B apart)
 

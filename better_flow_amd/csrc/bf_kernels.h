@@ -2,6 +2,7 @@
 // bf_kernels.hip (gfx950 kernels).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "bf_device.h"
@@ -88,6 +89,17 @@ struct LaunchTimer {
     bool consumed = false;
 };
 LaunchTimer& launch_timer();   // thread local
+// Plain launch, or (profiling armed) an extended launch whose events carry the kernel's own timestamps.
+template <class K, class... A>
+static inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
+    LaunchTimer& t = launch_timer();
+    if (t.start && !t.consumed) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, t.start, t.stop, 0, args...);
+        t.consumed = true;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+    }
+}
 
 void launch_set_state(DevState* st, const DevState& v, hipStream_t s);
 // the run's final warp with compute_uv fused (outputs in slot order): one event per thread
@@ -130,7 +142,7 @@ void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm
 int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s);
 void launch_fill_states(DevState* states, const DevState& tmpl, int nt, hipStream_t s);
 
-// bf_binned.hip
+// bf_rebin.hip / bf_scatter.hip / bf_stencil.hip / bf_fused.hip (the tile-binned loops)
 int bin_kernel_setup();
 void launch_stencil_binned(const StencilArgs& a, dim3 grid, hipStream_t s, int n_cus);
 // interior + margin format: clear what the bins' lists name in `mplane`, empty the lists (a run that cannot rely on the
@@ -174,7 +186,7 @@ struct BinScatterArgs {
 // update runs, -- lists -- whether the grid is thousands of small bins, and -- dense tiles -- the events per bin
 int bin_scatter_threads(int fmt, bool head, bool many_small_bins, double events_per_bin);
 hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threads, int per_thread, hipStream_t s);
-// The one-kernel iteration (k_fused_pass, bf_binned.hip): warp + scatter + stencil + moments of one image tile per work-group.
+// The one-kernel iteration (k_fused_pass, bf_fused.hip): warp + scatter + stencil + moments of one image tile per work-group.
 struct FusedArgs {
     EvSets sets;
     const uint32_t* ftab;            // FusedTab per tile (written by the counting sort's scan)

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const int32_t* __restrict_
 }
 
 // SRC 0: packed u64 plane; 1: split u64 sum + u32 count planes; 2: f32 time image.
-// (The tile-binned source has its own kernel, k_stencil_binned in bf_binned.hip.)
+// (The tile-binned source has its own kernel, k_stencil_binned in bf_stencil.hip.)
 template <int SRC, int NT>
 __global__ __launch_bounds__(NT) void k_stencil(StencilArgs a) {
     if (a.check_done && a.st->hot.done) return;

@@ -1,7 +1,7 @@
 // bf_loop.hip -- the persistent form of the one-kernel iteration: MANY iterations of OptimizerRolling::run
 // (optimizer_rolling.h:48-125,305-347) per launch, for a slice context that has the GPU to itself.
 //
-// Why.  k_fused_pass (bf_binned.hip) made an iteration one launch, and for the reference's own operating point -- the
+// Why.  k_fused_pass (bf_fused.hip) made an iteration one launch, and for the reference's own operating point -- the
 // compiled-in ring of 50 000 events on a 240x180 sensor, ~115 iterations per warm-started slice
 // (bf_motion_compensator.cpp:6-10,135) -- that launch IS the iteration: 11.7 us of which 3.6 are the gap between two
 // dependent launches and 2.0 the head's reload of state, accumulators and events.  Here the work-groups stay resident

@@ -149,7 +149,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // large images --, so that twice as many bins are in flight per CU: 84 instead of 91 us per iteration at 1280x720)
     int ev_per_thread = 8;
     const double ev_per_bin = binned ? (double)c->n / (double)(c->grid.nbins > 0 ? c->grid.nbins : 1) : 0.0;
-    // Work-group size of the scatter kernel (bin_scatter_threads, bf_binned.hip).  Dense tiles: 1024 threads for a context that
+    // Work-group size of the scatter kernel (bin_scatter_threads, bf_scatter.hip).  Dense tiles: 1024 threads for a context that
     // has the GPU to itself and bins of thousands of events (8.0 against 8.9 us per launch at config 2; at 640x480, bins of
     // ~1500 events, 512 threads: 11.7 against 17.4 us), 512 for contexts sharing the GPU ("co_schedule": a
     // 1024-thread work-group with its 51 KB tile needs half a CU's wave slots free at once and waits for them while the other

@@ -1,4 +1,4 @@
-"""The one-kernel iteration (k_fused_pass, bf_binned.hip): warp + scatter + stencil + moments of one image tile per
+"""The one-kernel iteration (k_fused_pass, bf_fused.hip): warp + scatter + stencil + moments of one image tile per
 work-group, events of a tile's edge strips read by the neighbouring tiles' work-groups as well.
 
 It must return the bits of the two-kernel tile-binned loop (same integer accumulators, same per-sub-tile f64 partials) --

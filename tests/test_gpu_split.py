@@ -1,4 +1,4 @@
-"""The interior + margin format of the tile-binned scatter ("bin_split", bf_binned.hip: flush_split).
+"""The interior + margin format of the tile-binned scatter ("bin_split", bf_scatter.hip: flush_split).
 
 A dense slice's bin writes its own pixels into a tiled image and adds the words its events left in the margin of its LDS
 tile to a double-buffered margin plane, which it clears again -- from a per-bin list -- at its next executed launch.  All

@@ -170,6 +170,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // 15.3 us with four events per thread, half of every thread's slots empty, against 12.1 us with two and a second pass
         // for the fuller bins; measured at 1M events on 440 / 520 / 560 x 480 sensors)
         ev_per_thread = per_bin <= 1 ? 1 : (per_bin <= 2.83 ? 2 : (per_bin <= 4 ? 4 : 8));
+        // (dense slabs on 512-thread work-groups with bins of thousands of events -- config 2 under "co_schedule": 272 bins, 3673
+        // events on average, 4912 in the fullest -- : the pass covers the FULLEST bin, ~1.35 x the average; with 8 per thread two
+        // thirds of the bins took a second pass: 8.45 -> 8.13 us per launch alone, 8.2 -> 7.8 under four contexts)
+        if (c->fmt == 0 && bin_threads == 512 && per_bin > 6.5) ev_per_thread = per_bin <= 8.2 ? 10 : 12;
     }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of

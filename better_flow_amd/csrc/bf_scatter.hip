@@ -662,7 +662,7 @@ __global__ __launch_bounds__(64) void k_finish_update(DevState* st, MomentAcc* a
 // stencil kernel's last work-group did ("co_schedule") -- and form + format fix the work-group sizes:
 //     dense slabs / own pixels + margin plane:  head 1024 threads (bins of >= 1536 events) or 512, lean 512
 //     event lists:                              256 (thousands of small bins) or 512, either form
-// times 1, 2, 4 or 8 events per thread and warp / no warp (the first pass of a cold run): 80 kernels, where the full product
+// times 1, 2, 4 or 8 events per thread (dense slabs on 512 threads: also 10 and 12) and warp / no warp (the first pass of a cold run): 88 kernels, where the full product
 // of the knobs that used to be options (3 sizes x 4 formats, both forms) was 192.  (The 512-thread head form is what a
 // context alone runs at 640x480 -- BASELINE config 3: 540-690 bins of ~1500 events -- 11.7 us per launch against 17.4 with
 // 1024 threads: measured when round 5's pruning first took it out.)
@@ -705,7 +705,7 @@ static hipError_t launch_bws(const BinScatterArgs& a, bool warp, int per_thread,
     return launch_bws2<HEAD, THREADS, 8, FMT>(a, warp, s);
 }
 
-// `threads`: bin_scatter_threads()'s answer for this slice; `per_thread`: events a thread keeps in flight (1, 2, 4 or 8).
+// `threads`: bin_scatter_threads()'s answer for this slice; `per_thread`: events a thread keeps in flight (1, 2, 4 or 8; dense slabs on 512 threads also 10 or 12).
 // a.acc != NULL: the head form (the pending update's sums), else the lean one.
 int bin_scatter_threads(int fmt, bool head, bool many_small_bins, double events_per_bin) {
     if (fmt == 2) return many_small_bins ? 256 : 512;
@@ -722,6 +722,10 @@ hipError_t launch_bin_warp_scatter(const BinScatterArgs& a, bool warp, int threa
         return wide ? launch_bws<true, 1024, 3>(a, warp, per_thread, s)
                     : (head ? launch_bws<true, 512, 3>(a, warp, per_thread, s) : launch_bws<false, 512, 3>(a, warp, per_thread, s));
     if (a.compact != 0) return hipErrorInvalidValue;
+    // Dense bins of several thousand events on 512 threads: a pass that covers the FULLEST bin, not the average one (config 2:
+    // 272 bins, 3673 events on average, 4912 at most -- with 8 per thread two thirds of the bins took a second pass)
+    if (!wide && per_thread >= 12) return head ? launch_bws2<true, 512, 12, 0>(a, warp, s) : launch_bws2<false, 512, 12, 0>(a, warp, s);
+    if (!wide && per_thread >= 10) return head ? launch_bws2<true, 512, 10, 0>(a, warp, s) : launch_bws2<false, 512, 10, 0>(a, warp, s);
     return wide ? launch_bws<true, 1024, 0>(a, warp, per_thread, s)
                 : (head ? launch_bws<true, 512, 0>(a, warp, per_thread, s) : launch_bws<false, 512, 0>(a, warp, per_thread, s));
 }

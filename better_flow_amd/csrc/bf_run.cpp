@@ -174,6 +174,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // events on average, 4912 in the fullest -- : the pass covers the FULLEST bin, ~1.35 x the average; with 8 per thread two
         // thirds of the bins took a second pass: 8.45 -> 8.13 us per launch alone, 8.2 -> 7.8 under four contexts)
         if (c->fmt == 0 && bin_threads == 512 && per_bin > 6.5) ev_per_thread = per_bin <= 8.2 ? 10 : 12;
+        // (event lists, update in the stencil tail, thousands of small bins on 256 threads -- 1280x720: 1620 bins, 608 events on average,
+        // 877 in the fullest: four per thread cover every bin in one pass, 14.3-14.6 -> 13.5 us per launch; the head form, whose
+        // registers also hold the update, loses with four: 14.8 -> 16.5)
+        if (c->fmt == 2 && !head_update && bin_threads == 256 && per_bin > 2.0) ev_per_thread = 4;
     }
     // Pipelined polling: batch b+1 is enqueued BEFORE the host waits for the state snapshot
     // taken after batch b, so the GPU never idles on the host (a blocking poll costs ~25 us of

@@ -133,6 +133,7 @@ struct bf_ctx {
     bool staged_valid[2] = {false, false};
     long long pending_n[2] = {0, 0};
     bool pending_ts64[2] = {false, false};       // slot holds absolute 64-bit timestamps (ring hand-off)
+    bool pending_ts32[2] = {false, false};       // ... of which only the low 32 bits were sent (bf_upload_ring16t32_async)
     bool pending_addr16[2] = {false, false};     // ... and 16-bit addresses in d_in16 (bf_upload_ring16_async)
     bool pending_noise[2] = {false, false};      // ... and Event::noise flags in d_in_noise
     uint16_t* d_in16[2] = {nullptr, nullptr};    // row[cap_events] then col[cap_events]

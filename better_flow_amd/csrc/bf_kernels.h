@@ -110,7 +110,8 @@ void launch_prepare(const int32_t* fr_x, const int32_t* fr_y, const int32_t* t_i
                     int32_t* t_out, float2* p, long long n, long long n_pad, SliceStats* stats,
                     hipStream_t s);
 void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s);
-void launch_local_time16(const unsigned long long* ts, const uint16_t* row, const uint16_t* col, unsigned long long t0,
+// (ts32: `ts` holds 32-bit words, the low halves of the timestamps)
+void launch_local_time16(const unsigned long long* ts, bool ts32, const uint16_t* row, const uint16_t* col, unsigned long long t0,
                          int32_t* x_out, int32_t* y_out, int32_t* t_out, long long n, hipStream_t s);
 void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s, int n_cus = 0);   // n_cus: lets the tile-binned form pick its build by how often the grid fills the GPU

@@ -367,15 +367,22 @@ __global__ __launch_bounds__(kThreads) void k_local_time(const unsigned long lon
 }
 
 // The same for a ring with 16-bit addresses (bf_upload_ring16_async): one pass widens row / column for the staging kernel.
+// TS32 (bf_upload_ring16t32_async): only the low 32 bits of every timestamp came over the link; the difference of the low
+// halves, taken modulo 2^32 and read as a signed number, IS the slice-local time while |timestamp - t0| < 2^31 ns.
+template <bool TS32>
 __global__ __launch_bounds__(kThreads) void k_local_time16(const unsigned long long* __restrict__ ts,
                                                            const uint16_t* __restrict__ row, const uint16_t* __restrict__ col,
                                                            unsigned long long t0, int32_t* __restrict__ x_out,
                                                            int32_t* __restrict__ y_out, int32_t* __restrict__ t_out, long long n) {
     const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long v = ts[i];
-    const long long t = v > t0 ? (long long)(v - t0) : -(long long)(t0 - v);
-    t_out[i] = (t > (long long)INT_MAX || t <= (long long)INT_MIN) ? INT_MIN : (int32_t)t;
+    if (TS32) {
+        t_out[i] = (int32_t)(reinterpret_cast<const uint32_t*>(ts)[i] - (uint32_t)t0);
+    } else {
+        const unsigned long long v = ts[i];
+        const long long t = v > t0 ? (long long)(v - t0) : -(long long)(t0 - v);
+        t_out[i] = (t > (long long)INT_MAX || t <= (long long)INT_MIN) ? INT_MIN : (int32_t)t;
+    }
     x_out[i] = (int32_t)row[i];
     y_out[i] = (int32_t)col[i];
 }
@@ -383,11 +390,12 @@ __global__ __launch_bounds__(kThreads) void k_local_time16(const unsigned long l
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-void launch_local_time16(const unsigned long long* ts, const uint16_t* row, const uint16_t* col, unsigned long long t0,
+void launch_local_time16(const unsigned long long* ts, bool ts32, const uint16_t* row, const uint16_t* col, unsigned long long t0,
                          int32_t* x_out, int32_t* y_out, int32_t* t_out, long long n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_local_time16, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, ts, row, col, t0,
-                       x_out, y_out, t_out, n);
+    const dim3 grid((unsigned)((n + kThreads - 1) / kThreads));
+    if (ts32) hipLaunchKernelGGL(k_local_time16<true>, grid, dim3(kThreads), 0, s, ts, row, col, t0, x_out, y_out, t_out, n);
+    else hipLaunchKernelGGL(k_local_time16<false>, grid, dim3(kThreads), 0, s, ts, row, col, t0, x_out, y_out, t_out, n);
 }
 
 void launch_local_time(const unsigned long long* ts, unsigned long long t0, int32_t* t_out, long long n, hipStream_t s) {

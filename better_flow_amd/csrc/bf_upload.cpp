@@ -4,9 +4,10 @@
 
 // The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays ring in pinned
 // memory: up to two contiguous pieces per array, no repacking on the host.  ADDR is int32_t (bf_upload_ring_async) or
-// uint16_t (bf_upload_ring16_async: the addresses travel as 16-bit values and are widened by the staging kernel).
-template <class ADDR>
-static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const uint64_t* ring_ts, const uint8_t* ring_noise,
+// uint16_t (bf_upload_ring16_async: the addresses travel as 16-bit values and are widened by the staging kernel); TS is uint64_t
+// (absolute nanoseconds) or uint32_t (their low 32 bits, bf_upload_ring16t32_async: 8 bytes per event over the link).
+template <class ADDR, class TS>
+static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const TS* ring_ts, const uint8_t* ring_noise,
                        int64_t cap, int64_t first, int64_t n, uint64_t t0) {
     if (!c) return BF_ERR_ARG;
     if (n <= 0 || cap <= 0 || first < 0 || first >= cap || n > cap || !ring_x || !ring_y || !ring_ts)
@@ -30,17 +31,19 @@ static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const 
     const int64_t n0 = (first + n <= cap) ? n : cap - first, n1 = n - n0;   // [first, first + n0) then [0, n1)
     HIP_TRY(c, hipMemcpyAsync(dx, ring_x + first, (size_t)n0 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(c, hipMemcpyAsync(dy, ring_y + first, (size_t)n0 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot], ring_ts + first, (size_t)n0 * 8, hipMemcpyHostToDevice, c->copy_stream));
+    TS* dts = reinterpret_cast<TS*>(c->d_in_ts[slot]);   // (cap_events x 8 bytes: the 32-bit form uses half of it)
+    HIP_TRY(c, hipMemcpyAsync(dts, ring_ts + first, (size_t)n0 * sizeof(TS), hipMemcpyHostToDevice, c->copy_stream));
     if (ring_noise) HIP_TRY(c, hipMemcpyAsync(c->d_in_noise[slot], ring_noise + first, (size_t)n0, hipMemcpyHostToDevice, c->copy_stream));
     if (n1 > 0) {
         HIP_TRY(c, hipMemcpyAsync(dx + n0, ring_x, (size_t)n1 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
         HIP_TRY(c, hipMemcpyAsync(dy + n0, ring_y, (size_t)n1 * sizeof(ADDR), hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_in_ts[slot] + n0, ring_ts, (size_t)n1 * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(dts + n0, ring_ts, (size_t)n1 * sizeof(TS), hipMemcpyHostToDevice, c->copy_stream));
         if (ring_noise) HIP_TRY(c, hipMemcpyAsync(c->d_in_noise[slot] + n0, ring_noise, (size_t)n1, hipMemcpyHostToDevice, c->copy_stream));
     }
     HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
     c->pending_n[slot] = n;
     c->pending_ts64[slot] = true;
+    c->pending_ts32[slot] = sizeof(TS) == 4;
     c->pending_addr16[slot] = narrow;
     c->pending_noise[slot] = ring_noise != nullptr;
     c->pending_t0[slot] = t0;
@@ -138,12 +141,22 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
 
 int bf_upload_ring_async(bf_ctx* c, const int32_t* ring_x, const int32_t* ring_y, const uint64_t* ring_ts, const uint8_t* ring_noise,
                          int64_t cap, int64_t first, int64_t n, uint64_t t0) {
-    return upload_ring<int32_t>(c, ring_x, ring_y, ring_ts, ring_noise, cap, first, n, t0);
+    return upload_ring<int32_t, uint64_t>(c, ring_x, ring_y, ring_ts, ring_noise, cap, first, n, t0);
 }
 
 int bf_upload_ring16_async(bf_ctx* c, const uint16_t* ring_row, const uint16_t* ring_col, const uint64_t* ring_ts,
                            const uint8_t* ring_noise, int64_t cap, int64_t first, int64_t n, uint64_t t0) {
-    return upload_ring<uint16_t>(c, ring_row, ring_col, ring_ts, ring_noise, cap, first, n, t0);
+    return upload_ring<uint16_t, uint64_t>(c, ring_row, ring_col, ring_ts, ring_noise, cap, first, n, t0);
+}
+
+int bf_upload_ring16t32_async(bf_ctx* c, const uint16_t* ring_row, const uint16_t* ring_col, const uint32_t* ring_t32,
+                              const uint8_t* ring_noise, int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    return upload_ring<uint16_t, uint32_t>(c, ring_row, ring_col, ring_t32, ring_noise, cap, first, n, t0);
+}
+
+int bf_upload_events16_async(bf_ctx* c, const uint16_t* fr_x, const uint16_t* fr_y, const int32_t* t_ns, int64_t n) {
+    // (slice-local times are their own low 32 bits relative to t0 = 0)
+    return upload_ring<uint16_t, uint32_t>(c, fr_x, fr_y, reinterpret_cast<const uint32_t*>(t_ns), nullptr, n, 0, n, 0);
 }
 
 int bf_wait_uploads(bf_ctx* c) {
@@ -163,7 +176,7 @@ int bf_commit_upload(bf_ctx* c) {
     c->has_noise = false;
     if (c->pending_ts64[slot]) {   // absolute timestamps -> slice-local 32-bit times (Event::set_local_time)
         if (c->pending_addr16[slot])   // ... and 16-bit addresses -> the staging kernel's int32 columns, same pass
-            launch_local_time16(c->d_in_ts[slot], c->d_in16[slot], c->d_in16[slot] + c->cap_events, c->pending_t0[slot],
+            launch_local_time16(c->d_in_ts[slot], c->pending_ts32[slot], c->d_in16[slot], c->d_in16[slot] + c->cap_events, c->pending_t0[slot],
                                 slot ? c->d_in2[0] : c->d_in_x, slot ? c->d_in2[1] : c->d_in_y, slot ? c->d_in2[2] : c->d_in_t,
                                 c->pending_n[slot], c->stream);
         else

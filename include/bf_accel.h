@@ -23,7 +23,7 @@
  * (no per-slice allocation), owns all of its device memory, pinned staging and its HIP
  * stream, and is NOT thread-safe -- with one exception, which the stream engine
  * (better_flow/slice_farm.h) relies on: the asynchronous uploads (bf_upload_events_async,
- * bf_upload_ring_async, bf_upload_ring16_async) and bf_wait_uploads touch only the
+ * bf_upload_ring_async, bf_upload_ring16_async, bf_upload_ring16t32_async, bf_upload_events16_async) and bf_wait_uploads touch only the
  * context's staging slots and copy stream and may be called from a SECOND thread while
  * the owning thread is inside bf_set_cloud, bf_set_model, bf_run or bf_compute_uv*.  The
  * caller serialises them against each other and against bf_commit_upload (one mutex),
@@ -393,6 +393,20 @@ int bf_upload_ring_async(bf_ctx *ctx, const int32_t *ring_fr_x, const int32_t *r
 int bf_upload_ring16_async(bf_ctx *ctx, const uint16_t *ring_row, const uint16_t *ring_col,
                            const uint64_t *ring_timestamp_ns, const uint8_t *ring_noise, int64_t cap,
                            int64_t first, int64_t n, uint64_t t0_ns);
+
+/* ... and with 32-bit timestamps: 8 bytes per event over the link instead of 12 -- a warm-started stream (a handful of
+ * iterations per slice) is bound by that link: 1M-event slices from pinned memory at 47-51 GB/s are 0.25 ms of copy against
+ * 0.1-0.2 ms of solve.  ring_t32[i] holds the LOW 32 bits of event i's nanosecond timestamp; t0_ns is the slice start in full.
+ * The device forms Event::set_local_time (event.h:61-63) as (int32)(ring_t32[i] - (uint32)t0_ns), which is the exact
+ * difference while |timestamp - t0_ns| < 2^31 ns = 2.1 s (the caller's contract: a slice is at most SPAN long, dvs_flow.h:21,156 -- 0.2 s in the
+ * command line, bf_motion_compensator.cpp:7,135; the 64-bit forms report a time that does not fit through bf_set_cloud, this one cannot). */
+int bf_upload_ring16t32_async(bf_ctx *ctx, const uint16_t *ring_row, const uint16_t *ring_col,
+                              const uint32_t *ring_t32, const uint8_t *ring_noise, int64_t cap,
+                              int64_t first, int64_t n, uint64_t t0_ns);
+/* bf_upload_events_async for a slice whose addresses are held as 16-bit values (AccelLib::init_gpu's int fr_x, fr_y, t,
+ * accel_lib.h:83-85,101-103, with the two addresses narrowed: a sensor address fits 16 bits): 8 bytes per event. */
+int bf_upload_events16_async(bf_ctx *ctx, const uint16_t *fr_x, const uint16_t *fr_y, const int32_t *t_ns,
+                             int64_t n);
 
 /* Event::compute_uv (event.h:135-142) of the current slice written straight into a ring of interleaved (u, v)
  * pairs: event i of the slice goes to uv_ring[2 * ((first + i) % cap)] and [... + 1].  No intermediate host copy:

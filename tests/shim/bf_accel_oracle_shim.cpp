@@ -264,6 +264,13 @@ int bf_upload_ring16_async(bf_ctx *c, const uint16_t *rrow, const uint16_t *rcol
                            int64_t cap, int64_t first, int64_t n, uint64_t t0) {
     return ring_slice(c, rrow, rcol, rts, rnoise, cap, first, n, t0);
 }
+// low 32 bits of the timestamps: the difference modulo 2^32, read as signed (see bf_accel.h)
+int bf_upload_ring16t32_async(bf_ctx *c, const uint16_t *rrow, const uint16_t *rcol, const uint32_t *rt32, const uint8_t *rnoise,
+                              int64_t cap, int64_t first, int64_t n, uint64_t t0) {
+    std::vector<uint64_t> full((size_t)cap);
+    for (int64_t k = 0; k < cap; ++k) full[(size_t)k] = (uint64_t)((int64_t)t0 + (int64_t)(int32_t)(rt32[k] - (uint32_t)t0));
+    return ring_slice(c, rrow, rcol, full.data(), rnoise, cap, first, n, t0);
+}
 
 // slice event i (oldest -> newest) -> uv_ring[2 * ((first + i) % cap)]
 int bf_compute_uv_ring(bf_ctx *c, double *uv_ring, int64_t cap, int64_t first) {
@@ -290,6 +297,11 @@ int bf_upload_events_async(bf_ctx *c, const int32_t *fr_x, const int32_t *fr_y, 
     u.noise.assign(n, 0);
     u.linear = true;
     return BF_OK;
+}
+
+int bf_upload_events16_async(bf_ctx *c, const uint16_t *fr_x, const uint16_t *fr_y, const int32_t *t_ns, int64_t n) {
+    std::vector<int32_t> x(fr_x, fr_x + n), y(fr_y, fr_y + n);
+    return bf_upload_events_async(c, x.data(), y.data(), t_ns, n);
 }
 
 int bf_commit_upload(bf_ctx *c) {

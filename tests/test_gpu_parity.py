@@ -1175,6 +1175,33 @@ def test_ring16_hand_off_with_noise_and_flow_ring(oracle_lib, accel_mod):
     acc.commit_upload()
     got = solve(acc)
     assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    # 8 bytes per event: the LOW 32 bits of the timestamps (bf_upload_ring16t32_async) -- with slice starts whose low halves sit
+    # just below a multiple of 2^32, so that the low halves of the slice's timestamps wrap inside the slice, and one whose
+    # events lie partly BEFORE t0 (negative local times exist in the reference too, event.h:61-63)
+    for t0b in (t0, (7 << 32) - 12_345_678, (1 << 32) - 1, 3 * (1 << 32) + 5):
+        ts_b = np.zeros(cap, np.uint64)
+        ts_b[idx] = sl["t"].astype(np.uint64) + np.uint64(t0b)
+        acc.upload_ring_async(ring_row, ring_col, (ts_b & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0b, ring_noise)
+        acc.commit_upload()
+        got = solve(acc)
+        assert np.array_equal(got[0], want[0]) and got[1:] == want[1:], t0b
+    shift = 9_000_000                                               # the slice start in the middle of the slice: t in [-9 ms, 31 ms)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"] - shift, noise)
+    want_neg = solve(acc)
+    acc.upload_ring_async(ring_row, ring_col, (ring_ts & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0 + shift, ring_noise)
+    acc.commit_upload()
+    got = solve(acc)
+    assert np.array_equal(got[0], want_neg[0]) and got[1:] == want_neg[1:]
+    # ... and a linear slice with 16-bit addresses and its own int32 times (bf_upload_events16_async), both staging slots
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    want_lin = solve(acc)
+    x16, y16, t32 = acc.pinned_array(n, np.uint16), acc.pinned_array(n, np.uint16), acc.pinned_array(n, np.int32)
+    x16[:], y16[:], t32[:] = sl["fr_x"], sl["fr_y"], sl["t"]
+    for _ in range(3):
+        acc.upload_events_async(x16, y16, t32, n)
+        acc.commit_upload()
+        got = solve(acc)
+        assert np.array_equal(got[0], want_lin[0]) and got[1:] == want_lin[1:]
     acc.close()
 
 

@@ -53,36 +53,10 @@ def host_cores():
 
 
 def spawn_ranks(n, argv):
-    """`python bench.py --gpus N` without a launcher: run N ranks of this script, rank r on device r, and wait.
-
-    The children find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment exactly as under
-    torch.distributed.run; rank 0 prints the JSON line on the inherited stdout.  A rank that fails takes the job down:
-    the others (which may be waiting in a barrier) are terminated by PID and the exit code is the failing rank's."""
-    import socket
-    import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), BF_BENCH_SPAWNED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.05)
-        for p_ in list(live):
-            code = p_.poll()
-            if code is None:
-                continue
-            live.remove(p_)
-            if code != 0 and rc == 0:
-                rc = code
-                for q_ in live:   # (exact PIDs of our own children)
-                    q_.terminate()
-    return rc
+    """`python bench.py --gpus N` without a launcher: N ranks of this script, rank r on device r (better_flow_amd/farm.py:
+    spawn_local_ranks -- a rank that fails takes the job down with its own exit code, nothing is left running)."""
+    from better_flow_amd import farm
+    return farm.spawn_local_ranks(n, os.path.abspath(__file__), argv)
 
 
 def main():
@@ -202,27 +176,36 @@ def main():
         # so each rank leaves the slices it generated where the others can map them (16 B per event under /dev/shm)
         share_dir = None
         if world > 1 and not args.farm_static:
-            share_dir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bf_farm_%s" % os.environ.get("MASTER_PORT", "0"))
-            os.makedirs(share_dir, exist_ok=True)
-        farm.prepare(specs, rank=rank, world=world, share_dir=share_dir)
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        merged = farm.run_farm(specs, rank=rank, world=world, device=device, concurrent=max(1, args.concurrent), scale=s,
-                               dist=dist, options={k_: int(v_) for k_, v_ in (o_.split("=") for o_ in args.opt)},
-                               static=args.farm_static)
-        if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-            tt = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt[0])
-        if share_dir is not None:
+            # rank 0 makes a fresh directory with room for the batch (16 B per event; /dev/shm, else the temporary directory)
+            # and tells the others; removed in the `finally` below whatever happens
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = farm.make_share_dir(16 * args.events * args.farm_slices, tag="farm_%s" % os.environ.get("MASTER_PORT", "0"))
+                except RuntimeError as e:
+                    box[0] = e
+            dist.broadcast_object_list(box, src=0)
+            if isinstance(box[0], Exception):
+                raise SystemExit("bench.py: %s" % box[0])
+            share_dir = box[0]
+        try:
+            farm.prepare(specs, rank=rank, world=world, share_dir=share_dir)
             if dist is not None:
                 dist.barrier()
-            if rank == 0:
+            t0 = time.perf_counter()
+            merged = farm.run_farm(specs, rank=rank, world=world, device=device, concurrent=max(1, args.concurrent), scale=s,
+                                   dist=dist, options={k_: int(v_) for k_, v_ in (o_.split("=") for o_ in args.opt)},
+                                   static=args.farm_static)
+            if dist is not None:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+            if dist is not None:
+                import torch
+                tt = torch.tensor([elapsed], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                elapsed = float(tt[0])
+        finally:
+            if share_dir is not None and rank == 0:   # (the slices were loaded by their claimers before run_farm returned or raised)
                 import shutil
                 shutil.rmtree(share_dir, ignore_errors=True)
         if rank == 0:

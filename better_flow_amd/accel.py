@@ -12,6 +12,9 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BF_ACCEL_LIB") or os.path.join(_DIR, "libbf_accel.so")
+# The test build (`make -C better_flow_amd/csrc debug`): the same objects plus the BF_DEBUG_* environment hooks the release
+# library does not contain.  Only tests load it (tests/helpers.py), by passing lib=DEBUG_LIB_PATH.
+DEBUG_LIB_PATH = os.path.join(_DIR, "debug", "libbf_accel.so")
 
 BF_OK, BF_SKIPPED = 0, 1
 BF_ERR_ARG, BF_ERR_HIP, BF_ERR_STATE, BF_ERR_NOCONV, BF_ERR_NODEVICE, BF_ERR_CAPACITY = (
@@ -164,16 +167,20 @@ class BfError(RuntimeError):
         self.code = code
 
 
-def load():
-    """Load libbf_accel.so; raises (never falls back) when it has not been built."""
+_libs = {}
+
+
+def load(path=None):
+    """Load libbf_accel.so (or the build at `path`); raises (never falls back) when it has not been built."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise RuntimeError(
                 "libbf_accel.so is missing (%s): build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or "
-                "`make -C better_flow_amd/csrc`" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+                "`make -C better_flow_amd/csrc`" % path)
+        L = C.CDLL(path)
         L.bf_last_error.restype = C.c_char_p
         L.bf_version.restype = C.c_char_p
         L.bf_create.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
@@ -228,8 +235,10 @@ def load():
         L.bf_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.bf_upload_events_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.bf_commit_upload.argtypes = [C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[path] = L
+        if path == LIB_PATH:
+            _lib = L
+    return _libs[path]
 
 
 def device_count():
@@ -245,8 +254,8 @@ def _ptr(a):
 class Accel:
     """One bf_ctx: the AccelLib-equivalent plus the fused OptimizerRolling::run."""
 
-    def __init__(self, device=0, max_events=1 << 20, max_rows=1024, max_cols=1280, stream=None):
-        self.L = load()
+    def __init__(self, device=0, max_events=1 << 20, max_rows=1024, max_cols=1280, stream=None, lib=None):
+        self.L = load(lib)
         h = C.c_void_p()
         rc = self.L.bf_create(device, max_events, max_rows, max_cols, stream, C.byref(h))
         if rc != BF_OK:

@@ -96,7 +96,11 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
         c->d_stats = c->h_stats;   // k_prepare writes its per-work-group records straight into pinned host memory: no copy command
         HIP_TRY(c, hipMemsetAsync(c->d_state, 0, 2 * sizeof(DevState), c->stream));
-        // test hooks of the persistent loop kernel: read here, once (bf_run may run on several threads: no getenv there)
+        // Test hooks and the phase-stamp dump exist only in the debug / timeline builds (`make debug`: debug/libbf_accel.so,
+        // -DBF_DEBUG_HOOKS; `make tl`: -DBF_TIMELINE).  The release library reads nothing of this kind from its host's
+        // environment: a stray variable cannot change a margin or make the persistent kernel give up.
+#ifdef BF_DEBUG_HOOKS
+        // (read here, once: bf_run may run on several threads -- no getenv there)
         if (const char* v = getenv("BF_DEBUG_PERSIST_ABORT")) c->dbg_persist_abort = atoi(v);
         if (const char* v = getenv("BF_DEBUG_PERSIST_MUTE")) c->dbg_persist_mute = atoi(v);
         if (const char* v = getenv("BF_DEBUG_PERSIST_SPLIT")) {
@@ -107,11 +111,14 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
             c->dbg_margin = atoi(v);
             if (c->dbg_margin < 1 || c->dbg_margin > 30) return fail(c, BF_ERR_ARG, "BF_DEBUG_MARGIN must be in [1, 30]");
         }
+#endif
+#ifdef BF_TIMELINE
         c->tl_path = getenv("BF_TIMELINE");
         if (c->tl_path && *c->tl_path) {
             HIP_TRY(c, hipMalloc(&c->d_tl, 3 * 64 * 2 * 16 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMemsetAsync(c->d_tl, 0, 3 * 64 * 2 * 16 * sizeof(unsigned long long), c->stream));
         }
+#endif
         int r = clear_planes(c);
         if (r != BF_OK) return r;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -163,7 +170,7 @@ void bf_destroy(bf_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tl) {   // debug timeline dump: launch group slot ticks(100 MHz)
-        std::vector<unsigned long long> tl(3 * 64 * 2 * 16);   // [kernel][launch][group][slot]; third block: (BF_CENSUS builds) resident stencil work-groups per CU, counts then maxima
+        std::vector<unsigned long long> tl(3 * 64 * 2 * 16);   // [kernel][launch][group][slot]
         (void)hipMemcpy(tl.data(), c->d_tl, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(c->tl_path, "w")) {
             for (size_t i = 0; i < tl.size(); ++i)

@@ -423,7 +423,7 @@ int ensure_bin_buffers(bf_ctx* c, const BinGrid& g) {
         HIP_TRY(c, hipMalloc(&c->d_hist_cnt, kHistCopies * nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_bin_start, nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_cursor, nb * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_chdr, nb * 200 * sizeof(uint32_t)));   // compact lists: LR + 1 <= 193 row offsets per bin
+        HIP_TRY(c, hipMalloc(&c->d_chdr, nb * 580 * sizeof(uint32_t)));   // event lists: 3 LR + 1 <= 577 key offsets per bin ((column zone, row) keys)
         HIP_TRY(c, hipMemsetAsync(c->d_hist_cnt, 0, kHistCopies * nb * sizeof(uint32_t), c->stream));
         c->bins_alloc = g.nbins;
     }

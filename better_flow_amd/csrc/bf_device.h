@@ -75,6 +75,8 @@ struct BinGrid {
     int32_t fz;        // one-kernel iteration (k_fused_pass): width E of the edge strips of a tile, 0 = the two-kernel loop.
                        // The counting sort then keys events by (bin, zone): nbins counts KEYS, kFusedZones per image tile.
     uint32_t mul_h;    // floor(2^32 / (L / 2)) + 1: row of a 16-byte PAIR of tile pixels (interior + margin format; L is even)
+    int32_t zw;        // event lists: entries sorted by (column zone, row) with zones [0, zw), [zw, L - zw), [L - zw, L) of the tile's
+                       // columns; zw = D + scale / 2 + 1 (what a neighbouring stencil tile can reach); 0: sorted by row only
 };
 
 // One-kernel iteration (bf_fused.hip, k_fused_pass).  A tile's events are sorted into nine zones by where their target

@@ -916,12 +916,6 @@ __device__ __forceinline__ void stencil_tail(const StencilArgs& a, const float* 
         const int me = blockIdx.y * gridDim.x + blockIdx.x;
         // every work-group adds its sums to the exact accumulators (order-free: see MomentAcc)
         acc_add(a.acc, me % kAccGroups, blk, tid);
-#ifdef BF_CENSUS
-        if (a.tl && tid == 0) {
-            const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(6164);
-            atomicAdd(&(a.tl + 2 * 64 * 2 * 16)[(xcc & 7u) * 128u + ((hw >> 8) & 127u)], ~0ull);
-        }
-#endif
         if (!a.ticket) {
             // Tile-binned loop: that is all.  The total is formed and the model / loop update runs at the head of the next
             // warp+scatter launch (k_bin_warp_scatter), by every work-group for itself -- no ticket, no last work-group,

@@ -51,9 +51,7 @@
 
 namespace bf {
 
-#ifndef BF_LOOP_U
-#define BF_LOOP_U 4   // events a thread keeps in registers (experiment builds override)
-#endif
+#define BF_LOOP_U 4   // events a thread keeps in registers
 constexpr int kLoopReducers = 16;
 constexpr int kRecWords = 32;   // a record: 16 lanes x (payload u64, tag u64)
 
@@ -181,11 +179,7 @@ __global__ __launch_bounds__(256 * NSUB, NSUB == 2 ? 4 : 2) void k_fused_loop(Fu
     float2* const p_cur = lds_sreg(&s_state.hot.pp) ? ev.p2 : ev.p;
     const int br = b / a.nbc, bc = b - br * a.nbc;
     const int X0 = br * TSR - H, Y0 = bc * TC - H;
-#ifdef BF_PROTO_OWNONLY   // timing prototype: the tile's own events only (WRONG sums: the neighbours' strips are missing)
-    const uint32_t M = ft.pre[1], own = ft.pre[1];
-#else
     const uint32_t M = ft.total, own = ft.pre[1];
-#endif
     const bool single = M <= (uint32_t)(THREADS * U);   // the whole list lives in registers
     uint32_t vxy[U], vi[U];
     int32_t vt[U];

@@ -220,7 +220,11 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     int stall_allowance = 0;   // launches that may have been spent waiting for a re-bin (one-kernel iteration)
     bool final_done = false;   // the gated final warp of a warm start's first batch already ran
     int skip_rebin_checks = 0;
-    static const bool host_timing = getenv("BF_HOST_TIMING") != nullptr;   // debug: where the host thread's time goes
+#ifdef BF_DEBUG_HOOKS
+    static const bool host_timing = getenv("BF_HOST_TIMING") != nullptr;   // debug build: where the host thread's time goes
+#else
+    constexpr bool host_timing = false;
+#endif
     double ht_launch = 0, ht_wait = 0;
     auto ht_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double ht_mark = host_timing ? ht_now() : 0;

@@ -45,6 +45,7 @@ constexpr int kMaxTileRows = 192;   // LR = TSR + 2 D <= 128 + 64
 // drifted out of this bin's tile -- the exact overflow path.
 struct ScatterGeo {
     int X0, Y0, L, LR;
+    int zw;   // event lists: width of the two column zones along the tile's left / right edge (BinGrid::zw; 0: one zone)
 };
 // The warp of one event and its splat centre (accel_lib.h:154-158); false: the event falls outside the window.
 template <bool WARP>
@@ -108,7 +109,11 @@ __device__ __forceinline__ void scatter_event(const ScatterHot& hs, const Scatte
 // that almost never meet at a pixel.  Instead every event becomes one ENTRY (tile-local pixel index, packed accumulator
 // of one event) of the bin's list, SORTED BY TILE ROW (counting sort: per-row counts in LDS, an exclusive scan, cursors),
 // with the first entry of every row in `crow` (LR + 1 words per bin): the stencil kernel reads exactly the rows it needs
-// and splats entries with LDS atomics, so duplicates simply add.  No LDS tile: occupancy is set by registers, all bins of
+// and splats entries with LDS atomics, so duplicates simply add.  With column ZONES (BinGrid::zw > 0; round 6) the sort key
+// is zone * LR + row, zone = 0 / 1 / 2 for the tile's first zw columns / the middle / its last zw columns, and `crow` holds
+// 3 LR + 1 words: a stencil tile takes from a NEIGHBOURING bin column only the zone that faces it (zw = D + scale / 2 + 1
+// columns of the bin's TS + 2 D: what a box sum at the tile's edge can reach) instead of the bin's full width -- at 1280x720
+// a 16 x 64 stencil tile gathered the rows of three 80-column bins (240 columns) for a 68-column window; now 80 + 10 + 10.  No LDS tile: occupancy is set by registers, all bins of
 // a 1280x720 slice are resident at once.  The order inside a row is whatever the atomics make it (integers).  A list
 // holds LL entries (the slab's size); a bin with more events sends the surplus down the overflow path.
 constexpr uint32_t kNoEntry = 0xffffffffu;
@@ -123,7 +128,8 @@ __device__ __forceinline__ uint32_t list_event(const ScatterHot& hs, const Scatt
     if (!event_target<WARP>(hs, p, i, v, ti, pr_x, pr_y, X, Y)) return kNoEntry;
     const int lx = X - sg.X0, ly = Y - sg.Y0;
     if (hs.bin_ok && (unsigned)lx < (unsigned)sg.LR && (unsigned)ly < (unsigned)sg.L) {
-        row = lx;
+        // (the sort key: [zone *] LR + row)
+        row = lx + (sg.zw ? (ly < sg.zw ? 0 : (ly >= sg.L - sg.zw ? 2 * sg.LR : sg.LR)) : 0);
         return (uint32_t)(__mul24(lx, sg.L) + ly);
     }
     if (take_overflow) {
@@ -132,7 +138,8 @@ __device__ __forceinline__ uint32_t list_event(const ScatterHot& hs, const Scatt
     }
     return kNoEntry;
 }
-// exclusive scan of the row counts s_row[1 .. LR] (one wave, 64 rows per step): cursors in LDS, row starts in `crow`
+// exclusive scan of the key counts s_row[1 .. LR] (LR here: the number of sort keys -- rows, or 3 x rows with column zones;
+// one wave, 64 keys per step): cursors in LDS, key starts in `crow`
 __device__ __forceinline__ void list_row_scan(uint32_t* s_row, int LR, uint32_t* crow, int lane) {
     uint32_t carry = 0;
     for (int r0 = 0; r0 < LR; r0 += 64) {
@@ -164,7 +171,8 @@ __device__ __forceinline__ void list_put(const ScatterHot& hs, const ScatterGeo&
         vals[slot] = (1ull << hs.bin_tbits) + dt;
         cidx[slot] = (uint16_t)code;
     } else {
-        overflow_add(hs, a, sg.X0 + row, sg.Y0 + (int)code - __mul24(row, sg.L), dt);
+        const int lx = row >= 2 * sg.LR ? row - 2 * sg.LR : (row >= sg.LR ? row - sg.LR : row);   // (key -> tile row; without zones key < LR)
+        overflow_add(hs, a, sg.X0 + lx, sg.Y0 + (int)code - __mul24(lx, sg.L), dt);
         ++n_ovf;
     }
 }
@@ -292,10 +300,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
     constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
     __shared__ DevState s_state;
-    __shared__ uint32_t s_row[FMT == 2 ? 1 + kMaxTileRows : 1];   // lists: entries per tile row, then the rows' cursors
+    __shared__ uint32_t s_row[FMT == 2 ? 1 + 3 * kMaxTileRows : 1];   // lists: entries per sort key ([zone,] tile row), then the keys' cursors
     __shared__ uint32_t s_mcnt[2];
     if (FMT == 2)
-        for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
+        for (int r = threadIdx.x; r <= 3 * kMaxTileRows; r += THREADS) s_row[r] = 0;
     if (SPLIT && threadIdx.x < 2) s_mcnt[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
         return;
     }
     if (pending && tid < 64) previous_positions();
-    const ScatterGeo sg = {X0, Y0, L, LR};
+    const ScatterGeo sg = {X0, Y0, L, LR, FMT == 2 ? g.zw : 0};
     uint32_t n_ovf = 0;
     if constexpr (COMPACT) {
         // Event lists.  Pass A: warp, store the products, count the entries per tile row (a bin of the usual size is one
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter(const uint32_t* __
         __syncthreads();
         tl_stamp(a.tl, a.j, 3);
         store_state();
-        if (tid < 64) list_row_scan(s_row, LR, a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+        if (tid < 64) list_row_scan(s_row, (g.zw ? 3 : 1) * LR, a.chdr + (size_t)b * (size_t)((g.zw ? 3 : 1) * LR + 1), tid);
         __syncthreads();
         unsigned long long* vals = a.slabs + (size_t)b * (size_t)LL;
         uint16_t* cidx = a.cidx + (size_t)b * (size_t)LL;
@@ -485,10 +493,10 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_
     constexpr bool COMPACT = FMT == 2;   // event lists / (0) dense slabs   (FMT 1, lists merged per pixel in the LDS tile, went in round 5: no BASELINE configuration took it)
     constexpr bool SPLIT = FMT == 3;                        // interior + margin (see flush_split)
     extern __shared__ unsigned long long s_tile[];   // (dense slabs only)
-    __shared__ uint32_t s_row[FMT == 2 ? 1 + kMaxTileRows : 1];   // lists: entries per tile row, then the rows' cursors
+    __shared__ uint32_t s_row[FMT == 2 ? 1 + 3 * kMaxTileRows : 1];   // lists: entries per sort key ([zone,] tile row), then the keys' cursors
     __shared__ uint32_t s_mcnt[2];
     if (FMT == 2)
-        for (int r = threadIdx.x; r <= kMaxTileRows; r += THREADS) s_row[r] = 0;
+        for (int r = threadIdx.x; r <= 3 * kMaxTileRows; r += THREADS) s_row[r] = 0;
     if (SPLIT && threadIdx.x < 2) s_mcnt[threadIdx.x] = 0;
     const BinGrid& g = a.g;
     const int L = g.L, LR = g.LR, LL = g.LR * g.L;
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_
     const uint32_t* __restrict__ xy = ev.xy;
     const int32_t* __restrict__ t = ev.t;
     float2* __restrict__ p = ev.p;
-    const ScatterGeo sg = {X0, Y0, L, LR};
+    const ScatterGeo sg = {X0, Y0, L, LR, FMT == 2 ? g.zw : 0};
     uint32_t n_ovf = 0;
     __syncthreads();
     uint32_t vxy[U];
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(THREADS) void k_bin_warp_scatter_lean(const uint32_
             }
         }
         __syncthreads();
-        if (tid < 64) list_row_scan(s_row, LR, a.chdr + (size_t)b * (size_t)(LR + 1), tid);
+        if (tid < 64) list_row_scan(s_row, (g.zw ? 3 : 1) * LR, a.chdr + (size_t)b * (size_t)((g.zw ? 3 : 1) * LR + 1), tid);
         __syncthreads();
         unsigned long long* vals = a.slabs + (size_t)b * (size_t)LL;
         uint16_t* cidx = a.cidx + (size_t)b * (size_t)LL;

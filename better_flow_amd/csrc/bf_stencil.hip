@@ -78,15 +78,6 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
     BinGrid g = a.g;   // (the fields the slab addresses use come from the preloaded arguments)
     g.D = pre.D; g.lg = pre.lg; g.nbc = pre.nbc; g.nbr = pre.nbr; g.LR = pre.LR; g.L = pre.L; g.TSR = pre.TSR; g.mul_r = pre.mul_r;
-#ifdef BF_CENSUS
-    if (a.tl && tid == 0 && !(a.check_done && hs.done)) {   // debug: work-groups resident per CU (third block of the timeline buffer: counts, then maxima)
-        const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(6164);
-        const uint32_t key = (xcc & 7u) * 128u + ((hw >> 8) & 127u);
-        unsigned long long* cen = a.tl + 2 * 64 * 2 * 16;
-        const unsigned long long n = atomicAdd(&cen[key], 1ull) + 1ull;
-        atomicMax(&cen[1024 + key], n);
-    }
-#endif
     const int bt = hs.bin_tbits;
     const unsigned long long bm = (1ull << bt) - 1ull;
     // (static indices only: a runtime index would push the HotState copy into scratch memory)
@@ -110,40 +101,57 @@ __device__ __forceinline__ void stencil_binned_body(const StencilArgs& a, const 
         // flattened entry number, the element offset of its list and the position of its LDS-tile origin in the tile's
         // time-pixel coordinates; then thread t takes entries t, t + 256, ...: all 256 threads share the gather evenly
         // whatever the bins' sizes, and it costs two memory round trips (counts, entries) like any gather.
+        // With column zones (BinGrid::zw; the scatter kernel sorted a bin's entries by (zone, row)) the unit is a SEGMENT = one
+        // zone of one bin, rows clipped as before, and only the segments whose columns can reach the tile's boxes are taken:
+        // of a neighbouring bin column the one zone that faces the tile.  A candidate per lane (<= 3 bin rows x 3 bin columns
+        // x 3 zones), the kept ones compacted by a ballot.
         constexpr int kMaxBins = 32;
         __shared__ uint32_t s_eoff[kMaxBins + 1];
-        __shared__ int2 s_ebin[kMaxBins];   // x: element offset of the bin's list minus its first flattened entry number; y: oy << 16 | ox & 0xffff
+        __shared__ int2 s_ebin[kMaxBins];   // x: element offset of the segment's entries minus its first flattened entry number; y: oy << 16 | ox & 0xffff
+        __shared__ int s_nseg;
         const int ncol = bc_hi - bc_lo + 1;
-        const int nbin_ = min((br_hi - br_lo + 1) * ncol, kMaxBins);
+        const int zw = g.zw, nz = zw ? 3 : 1;
+        const int ncand = min((br_hi - br_lo + 1) * ncol * nz, 64);
         if (tid < 64) {
             uint32_t n = 0;
             int bin = 0, r = 0, cc = 0;
             uint32_t first = 0;
-            if (tid < nbin_) {   // the bin's entries in the tile rows that can reach this stencil tile
-                r = tid / ncol; cc = tid - r * ncol;
+            bool keep = false;
+            if (tid < ncand) {   // the segment's entries in the tile rows that can reach this stencil tile
+                const int bi = tid / nz, z = tid - bi * nz;
+                r = bi / ncol; cc = bi - r * ncol;
                 bin = (br_lo + r) * g.nbc + bc_lo + cc;
                 const int top = (br_lo + r) * g.TSR - g.D;   // image row of tile row 0
                 const int lo = min(max(r0 - 1 - HS - top, 0), g.LR), hi = min(max(r0 + TR + HS + 1 - top, 0), g.LR);
-                const uint32_t* crow = a.chdr + (size_t)bin * (size_t)(g.LR + 1);
-                // (a list holds LL entries: the surplus of a fuller bin went down the overflow path)
-                first = min(crow[lo], (uint32_t)LLi);
-                n = min(crow[hi], (uint32_t)LLi) - first;
+                // image columns of the zone [z_lo, z_hi) against the columns whose boxes touch the tile's time pixels
+                const int left = ((bc_lo + cc) << g.lg) - g.D;
+                const int z_lo = left + (z == 0 ? 0 : (z == 1 ? zw : g.L - zw)), z_hi = left + (nz == 1 ? g.L : (z == 0 ? zw : (z == 1 ? g.L - zw : g.L)));
+                keep = z_hi > c0 - 1 - HS && z_lo <= c0 + TC + HS;
+                if (keep) {
+                    const uint32_t* crow = a.chdr + (size_t)bin * (size_t)(nz * g.LR + 1) + z * g.LR;
+                    // (a list holds LL entries: the surplus of a fuller bin went down the overflow path)
+                    first = min(crow[lo], (uint32_t)LLi);
+                    n = min(crow[hi], (uint32_t)LLi) - first;
+                }
             }
             uint32_t incl = n;
 #pragma unroll
-            for (int o = 1; o < kMaxBins; o <<= 1) {
+            for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t v = __shfl_up(incl, o, 64);
                 if (tid >= o) incl += v;
             }
-            if (tid < nbin_) {
-                s_eoff[tid + 1] = incl;
+            const unsigned long long kept = __ballot(keep);
+            const int pos = __popcll(kept & ((1ull << tid) - 1ull));
+            if (keep && pos < kMaxBins) {
+                s_eoff[pos + 1] = incl;
                 const int oy_ = (br_lo + r) * g.TSR - g.D - (r0 - 1), ox_ = ((bc_lo + cc) << g.lg) - g.D - (c0 - 1);   // (|.| < 2^15)
-                s_ebin[tid] = make_int2(bin * LLi + (int)first - (int)(incl - n), (int)(((uint32_t)oy_ << 16) | ((uint32_t)ox_ & 0xffffu)));
+                s_ebin[pos] = make_int2(bin * LLi + (int)first - (int)(incl - n), (int)(((uint32_t)oy_ << 16) | ((uint32_t)ox_ & 0xffffu)));
             }
-            if (tid == 0) s_eoff[0] = 0;
+            if (tid == 0) { s_eoff[0] = 0; s_nseg = min(__popcll(kept), kMaxBins); }
         }
         if (a.check_done && hs.done) return;   // (uniform; before the first barrier)
         __syncthreads();   // (the box plane is zero, the bin table is in place)
+        const int nbin_ = __builtin_amdgcn_readfirstlane(s_nseg);
         const uint32_t E = s_eoff[nbin_];
         for (uint32_t e = tid; e < E; e += NT) {
             // which bin's list holds entry e: the number of bins whose first entry number is <= e (a compare and an add per

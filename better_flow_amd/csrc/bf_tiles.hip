@@ -373,7 +373,7 @@ void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm
 
 int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s) {
     const size_t lds = (size_t)a.max_px * (8 + 4 + 4);
-    static const int threads = getenv("BF_TILE_THREADS") ? atoi(getenv("BF_TILE_THREADS")) : 256;
+    constexpr int threads = 256;   // (512 / 1024 threads per tile optimizer: measured, no gain -- experiments/rounds_1_to_3.md)
     const int hs = a.scale / 2;
 #define BF_TILE(T_)                                                                       \
     do {                                                                                  \

@@ -7,10 +7,7 @@ one shared counter (`SliceQueue`: a lock in one process, `TCPStore.add` of the g
 11 doubles per slice.  Slices differ widely (config 5 on one GPU: 6 437 iterations per slice on average, up to 33 410), so
 the static round robin `i % world` this replaces left ranks idle behind one long slice; with known costs the queue hands
 slices out longest first.  No RCCL collective is on the data path."""
-import itertools
 import threading
-
-_generation = itertools.count()   # every rank calls run_farm / SliceQueue the same number of times: a common name for the counter
 
 
 def shard(n_slices, rank, world):
@@ -26,7 +23,14 @@ class SliceQueue:
     order: index order, or -- when `costs` (any monotone estimate of a slice's work: event count x expected iterations, a
     previous run's milliseconds) are given -- longest first, ties by index; every rank computes the same order.  The counter is
     a lock-protected integer in one process and one key of the process group's TCPStore across ranks (`dist`: an initialised
-    torch.distributed; `store.add` is atomic and returns the new value)."""
+    torch.distributed; `store.add` is atomic and returns the new value).
+
+    Which key: the ranks agree on it THROUGH the store -- every store-backed construction of a queue called `name` takes a
+    ticket from "bf_farm/<name>/ctor", and tickets world*g .. world*g + world - 1 are generation g -- so a rank that built
+    other queues on the side (process-local ones, or ones under another name) still lands on the same counter as its
+    peers.  What the ranks must share is only the number of store-backed queues of that NAME they have built (they build
+    them collectively: run_farm does); `world` ranks that disagree about n_slices or the order are caught by `gather`
+    (a slice processed twice raises)."""
 
     def __init__(self, n_slices, costs=None, dist=None, name=None):
         if costs is not None:
@@ -38,11 +42,14 @@ class SliceQueue:
         self._lock = threading.Lock()
         self._next = 0
         self._store = None
-        gen = next(_generation)
+        self.world = 1
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             from torch.distributed import distributed_c10d
             self._store = distributed_c10d._get_default_store()
-            self._key = "bf_farm/%s/%d" % (name or "queue", gen)
+            self.world = dist.get_world_size()
+            name = name or "queue"
+            gen = (int(self._store.add("bf_farm/%s/ctor" % name, 1)) - 1) // self.world
+            self._key = "bf_farm/%s/%d" % (name, gen)
 
     def claim(self):
         if self._store is not None:
@@ -53,10 +60,23 @@ class SliceQueue:
                 self._next += 1
         return self.order[k] if k < len(self.order) else None
 
+    def remaining(self):
+        """Slices nobody has claimed yet (a snapshot: other lanes and ranks keep claiming)."""
+        if self._store is not None:
+            k = int(self._store.add(self._key, 0))
+        else:
+            with self._lock:
+                k = self._next
+        return max(0, len(self.order) - k)
 
-def run_queue(queue, process_slice, lanes=1):
+
+def run_queue(queue, process_slice, lanes=1, dist=None, rank=0):
     """`lanes` threads of this rank claim slices from `queue` and run process_slice(i) -> dict; returns {i: result} with the
-    lane and the claim / completion times (seconds since this call) added as "lane", "t0", "t1"."""
+    lane and the claim / completion times (seconds since this call) added as "lane", "t0", "t1".
+
+    With `dist` (an initialised torch.distributed) the records of ALL ranks are gathered and returned on every rank, and an
+    exception in any lane of any rank is raised on EVERY rank after that gather -- a failing rank must not leave its peers
+    waiting in a collective it never joins (the same contract as run_farm).  Without `dist` the first error is raised here."""
     import time
     results, errors = {}, []
     lock = threading.Lock()
@@ -81,9 +101,24 @@ def run_queue(queue, process_slice, lanes=1):
         t.start()
     for t in th:
         t.join()
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if errors:
+            raise errors[0]
+        return results
+    for r in results.values():
+        r.setdefault("rank", rank)
+    for n, e in enumerate(errors):   # (travels with the records)
+        results[("error", rank, n)] = {"error": "%s: %s" % (type(e).__name__, e), "rank": rank, "slice": None}
+    merged = gather(results, dist)
+    _raise_lane_errors(merged)
+    return merged
+
+
+def _raise_lane_errors(merged):
+    errors = [v for k, v in merged.items() if isinstance(k, tuple)]
     if errors:
-        raise errors[0]
-    return results
+        raise RuntimeError("slice farm: %d lane(s) failed; first: rank %s, slice %s: %s" %
+                           (len(errors), errors[0]["rank"], errors[0]["slice"], errors[0]["error"]))
 
 
 def balance(merged, world):
@@ -221,6 +256,17 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
     from . import accel
     by_index = {s.index: s for s in specs}
     ids = sorted(by_index)
+    if not static and world > 1:
+        # The shared queue lives in the process group's store.  A caller that says world > 1 without an initialised group of
+        # that size would get a process-local counter on every rank -- every rank solving EVERY slice, unmerged results, a
+        # throughput figure `world` times too high -- so it gets the round robin instead (what this function did before it
+        # had a queue), and is told.
+        ok = dist is not None and dist.is_initialized() and dist.get_world_size() == world
+        if not ok:
+            import warnings
+            warnings.warn("run_farm: world=%d but no initialised torch.distributed group of that size: static sharding "
+                          "(slice i -> rank i %% world), results NOT gathered across ranks" % world, RuntimeWarning, stacklevel=2)
+            static = True
     if static:
         mine = [i for i in ids if i % world == rank]
         work = SliceQueue(len(mine), costs=None, dist=None)
@@ -270,6 +316,11 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
 
                 k = 0
                 nxt = put(0)
+                # Near the end of the batch a lane stops claiming AHEAD: a slice prefetched by a lane that sits in a long solve
+                # (33 000 iterations against a mean of 6 400 at config 5) could not be taken by the lanes and ranks that have
+                # gone idle meanwhile.  Once fewer slices are left than there are lanes in the job, the next one is claimed
+                # when this lane is free for it (its upload then is not hidden: 0.3 ms against seconds of solve).
+                drain_at = max(1, concurrent) * (1 if static else max(1, world))
                 while nxt is not None:
                     cur, n, t0 = nxt
                     t_solve = time.perf_counter()
@@ -278,7 +329,8 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
                     else:
                         a.upload_events(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
                     k ^= 1
-                    nxt = put(k)          # the next slice's DMA overlaps this slice's solve
+                    ahead = work.remaining() >= drain_at
+                    nxt = put(k) if ahead else None          # the next slice's DMA overlaps this slice's solve
                     o.res_x, o.res_y, o.max_iter, o.want_uv = cur.height, cur.width, max_iter, 1 if want_flow_digest else 0
                     a.set_cloud(scale, cur.height, cur.width)
                     rc, m, info = a.run(o)
@@ -296,6 +348,8 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
                     with lock:
                         results[cur.index] = rec
                     cur = None
+                    if not ahead:
+                        nxt = put(k)
             except Exception as e:   # noqa: BLE001 -- travels with the records, raised after the gather
                 with lock:
                     results[("error", rank, threading.get_ident())] = {"error": "%s: %s" % (type(e).__name__, e),
@@ -312,9 +366,98 @@ def run_farm(specs, rank=0, world=1, device=0, concurrent=4, scale=3, max_iter=-
             t.start()
         for t in threads:
             t.join()
-    merged = gather(results, dist)
-    errors = [v for k, v in merged.items() if isinstance(k, tuple)]
-    if errors:
-        raise RuntimeError("slice farm: %d lane(s) failed; first: rank %s, slice %s: %s" %
-                           (len(errors), errors[0]["rank"], errors[0]["slice"], errors[0]["error"]))
+    merged = gather(results, None if static and not (dist is not None and dist.is_initialized()) else dist)
+    _raise_lane_errors(merged)
     return merged
+
+
+def spawn_local_ranks(n, script, argv, env_extra=None, poll_s=0.05, pids_out=None):
+    """One process per rank on this node without a launcher: run `n` copies of `python script argv...`, rank r with RANK /
+    LOCAL_RANK = r, WORLD_SIZE = n and a fresh MASTER_ADDR=127.0.0.1 / MASTER_PORT in its environment -- exactly what the
+    ranks find under `python -m torch.distributed.run` -- and wait for all of them.  Rank 0 writes to the inherited stdout.
+
+    A rank that fails takes the job down: the moment any rank exits non-zero the others (which may be waiting for it in a
+    barrier or a gather) are terminated by PID -- killed if they ignore that for 5 s -- and the return value is the FIRST
+    failing rank's exit code (a signal's negative code as 128 + signal).  Returns 0 only if every rank did.  No process of
+    the job outlives this call."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BF_BENCH_SPAWNED="1")
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+        if pids_out is not None:
+            pids_out.append(procs[-1].pid)
+    rc = 0
+    live = list(procs)
+    deadline = None
+    try:
+        while live:
+            time.sleep(poll_s)
+            for p_ in list(live):
+                code = p_.poll()
+                if code is None:
+                    continue
+                live.remove(p_)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    for q_ in live:   # (exact PIDs of our own children)
+                        q_.terminate()
+                    deadline = time.monotonic() + 5.0
+            if deadline is not None and live and time.monotonic() > deadline:
+                for q_ in live:
+                    q_.kill()
+                deadline = None
+    finally:
+        for p_ in procs:   # (an exception in here -- KeyboardInterrupt -- must not leave ranks behind either)
+            if p_.poll() is None:
+                p_.kill()
+                p_.wait()
+    return rc
+
+
+def make_share_dir(n_bytes, tag="farm"):
+    """A fresh directory every rank of this node can reach for the slices the ranks exchange (prepare()): under /dev/shm if
+    it has `n_bytes` + 10 % free, else under the temporary directory, else an error that says how much was needed -- a
+    512-slice batch of 1M events is 8 GB, more than a container's default tmpfs.  The caller removes it (try / finally)."""
+    import os
+    import shutil
+    import tempfile
+    need = int(n_bytes * 1.1) + (1 << 20)
+    for base in ("/dev/shm", tempfile.gettempdir()):
+        if os.path.isdir(base) and os.access(base, os.W_OK) and shutil.disk_usage(base).free >= need:
+            return tempfile.mkdtemp(prefix="bf_%s_" % tag, dir=base)
+    raise RuntimeError("slice exchange needs %.1f GB; neither /dev/shm nor %s has that much free" %
+                       (need / 1e9, tempfile.gettempdir()))
+
+
+def exit_with(main):
+    """Run a rank's main() and leave the process with an exit code that means something: 0, the code of a SystemExit, or 1
+    after any other exception (traceback on stderr) -- through os._exit, because a rank that unwinds normally with its
+    process group still alive is aborted by the group's watchdog threads ("terminate called without an active exception",
+    exit code 134), which would hide the failing rank's own code from the launcher."""
+    import os
+    import sys
+    import traceback
+    code = 0
+    try:
+        main()
+    except SystemExit as e:
+        code = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+        if code and not isinstance(e.code, int):
+            print(e.code, file=sys.stderr)
+    except BaseException:   # noqa: BLE001
+        traceback.print_exc()
+        code = 1
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)

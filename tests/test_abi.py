@@ -59,3 +59,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "bf_oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_release_library_reads_no_debug_hooks():
+    """The BF_DEBUG_* / BF_HOST_TIMING / BF_TIMELINE environment hooks exist only in the test build
+    (better_flow_amd/debug/libbf_accel.so, `make debug`) and the timeline build: a stray variable in a host's environment
+    must not be able to change the release library's margins or make its persistent kernel give up."""
+    from better_flow_amd import accel
+    blob = open(accel.LIB_PATH, "rb").read()
+    for name in (b"BF_DEBUG_", b"BF_HOST_TIMING", b"BF_TIMELINE", b"BF_TILE_THREADS", b"BF_EXP_"):
+        assert name not in blob, name
+    assert os.path.exists(accel.DEBUG_LIB_PATH), "build first (make -C better_flow_amd/csrc debug)"
+    assert b"BF_DEBUG_MARGIN" in open(accel.DEBUG_LIB_PATH, "rb").read()
+    # ... and no experiment switch is left in the product's sources
+    src = os.path.join(ROOT, "better_flow_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".cpp", ".hip", ".h")):
+            txt = open(os.path.join(src, f)).read()
+            assert "BF_PROTO_" not in txt and "BF_CENSUS" not in txt, f

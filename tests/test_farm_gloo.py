@@ -199,3 +199,67 @@ def test_numa_binding_is_safe_everywhere():
     else:
         assert out["node0"] == 0 and out["aff"] == before
     assert os.sched_getaffinity(0) == before   # (the binding is the calling thread's, not the process's)
+
+
+# ---- eight ranks: the target world size of BASELINE config 5, on CPU (no 8-GPU node has ever run this job) -------------------
+
+def _run_eight(tmp_path, n_slices, extra=()):
+    sys.path.insert(0, ROOT)
+    import json
+    import time
+    from better_flow_amd import farm
+    share = farm.make_share_dir(n_slices * 6000 * 16, tag="test8")
+    out = str(tmp_path / "merged.json")
+    try:
+        t0 = time.time()
+        pids = []
+        rc = farm.spawn_local_ranks(8, os.path.join(ROOT, "tests", "farm_rank_main.py"), [out, str(n_slices), share] + list(extra),
+                                    pids_out=pids)
+        wall = time.time() - t0
+        assert len(pids) == 8
+        for pid in pids:   # no rank outlives the launcher's return
+            with pytest.raises(ProcessLookupError):
+                os.kill(pid, 0)
+        merged = json.load(open(out)) if os.path.exists(out) else None
+    finally:
+        import shutil
+        shutil.rmtree(share, ignore_errors=True)
+    return rc, merged, wall
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_one_queue_shared_slices(tmp_path):
+    """World size 8 through the launcher `bench.py --gpus 8` uses (farm.spawn_local_ranks): slices generated by their round-
+    robin owners and exchanged through a shared directory, claimed from ONE queue longest first, gathered on every rank.
+    Every slice exactly once, the bits of a single process, every rank took work, nobody holds the job up."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from better_flow_amd import farm
+    import farm_rank_main as frm
+    n = 40
+    rc, merged, wall = _run_eight(tmp_path, n)
+    assert rc == 0
+    assert sorted(int(k) for k in merged) == list(range(n))      # (gather raises on a slice processed twice)
+    for i in range(n):
+        single = frm.solve(frm.spec_of(farm, i), 1)
+        for k in ("rc", "iters", "model", "events"):
+            assert merged[str(i)][k] == single[k], (i, k)
+    ranks = [merged[str(i)]["rank"] for i in range(n)]
+    assert sorted(set(ranks)) == list(range(8)), ranks           # every rank claimed something
+    first = sorted(range(n), key=lambda i: merged[str(i)]["t0"])[:8]
+    assert all(i % 5 == 0 for i in first), first                 # longest first: the eight heavy slices are the first claims
+    bal = farm.balance({i: merged[str(i)] for i in range(n)}, 8)
+    print("8 ranks: slices per rank %s, busy %s s, imbalance %.2f, wall %.1f s" %
+          (bal["slices"], ["%.2f" % b for b in bal["busy_s"]], bal["imbalance"], wall))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode,code", [("raise", 1), ("exit:7", 7)], ids=["exception", "rank_dies"])
+def test_eight_ranks_a_failing_rank_takes_the_job_down(tmp_path, mode, code):
+    """The rank that claims slice 20 (a light one: the eight heavy slices are out first, everybody is busy) fails on it -- by an exception inside its worker (then EVERY rank raises after the gather: nobody
+    waits in a collective the failing rank never joins), or by dying outright with exit code 7 (then the launcher terminates
+    the ranks that wait for it).  The job ends promptly, with the failing rank's exit code, and leaves no process behind."""
+    rc, merged, wall = _run_eight(tmp_path, 40, ["--fail-slice", "20", "--fail-mode", mode])
+    assert rc == code, rc
+    assert merged is None                                          # rank 0 never got to write a result
+    assert wall < 120, wall                                        # (no gloo timeout was waited for: that is 30 minutes)

@@ -97,16 +97,11 @@ def test_persistent_kernel_that_gives_up_undoes_itself(accel_mod):
     iteration from where that launch started.  BF_DEBUG_PERSIST_ABORT=<pass> makes every work-group "time out" at that pass:
     the results must be the bits of the other loops -- for single-pass lists (events in registers) and multi-pass lists
     (private product arrays), cold and warm, giving up in the first launch and in a later one."""
-    import os
     for (n, H, W, s, seed) in ((50000, 180, 240, 3, 4), (300000, 260, 346, 3, 6)):
         sl = synth.make_slice(n, H, W, 0.03, seed=seed)
         ref = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 0})
         for at in (0, 3, 17):
-            os.environ["BF_DEBUG_PERSIST_ABORT"] = str(at)
-            try:
-                got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2})
-            finally:
-                del os.environ["BF_DEBUG_PERSIST_ABORT"]
+            got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2, "BF_DEBUG_PERSIST_ABORT": str(at)})   # (test build: tests/helpers.py)
             assert got["persistent"] == 1
             assert got["launches"] > ref["it"][0] // 2, "the fall-back (one launch per iteration) must have run"
             for key in ("rc", "it", "model", "trace", "flow"):
@@ -115,11 +110,7 @@ def test_persistent_kernel_that_gives_up_undoes_itself(accel_mod):
         # its records from that pass on, as if it had lost its CU).  Only the reducer in charge of its records times out; it
         # must not publish its partial total -- the others would take it for the sum -- and the whole launch gives up.
         for at in (0, 5):
-            os.environ["BF_DEBUG_PERSIST_MUTE"] = str(at)
-            try:
-                got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2})
-            finally:
-                del os.environ["BF_DEBUG_PERSIST_MUTE"]
+            got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2, "BF_DEBUG_PERSIST_MUTE": str(at)})   # (test build: tests/helpers.py)
             assert got["launches"] > ref["it"][0] // 2, "the fall-back (one launch per iteration) must have run"
             assert got["giveups"] >= 1
             for key in ("rc", "it", "model", "trace", "flow"):
@@ -130,11 +121,7 @@ def test_persistent_kernel_that_gives_up_undoes_itself(accel_mod):
         # undoes, the fall-back runs.  Late (~100 us): the others have committed, the straggler reads the reduced records
         # again and leaves with them -- no give-up, and no work-group that silently kept its pre-launch products.
         for spec, undone in (("7", True), ("7,late", False), ("0,late", False)):
-            os.environ["BF_DEBUG_PERSIST_SPLIT"] = spec
-            try:
-                got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2})
-            finally:
-                del os.environ["BF_DEBUG_PERSIST_SPLIT"]
+            got = run(accel_mod, sl, H, W, s, {"binned": 2, "fused": 2, "persist": 2, "BF_DEBUG_PERSIST_SPLIT": spec})
             assert got["persistent"] == 1
             if undone:
                 assert got["giveups"] >= 1 and got["launches"] > ref["it"][0] // 2, (spec, got["giveups"], got["launches"])

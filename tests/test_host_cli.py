@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from better_flow_amd import synth  # noqa: E402
+from helpers import debug_cli_env  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -641,8 +642,9 @@ def test_cli_reference_ring_same_bytes_on_every_device_loop(tmp_path):
         out, log = str(tmp_path / (tag + ".txt")), str(tmp_path / (tag + ".log"))
         env = dict(os.environ)
         env["BF_ACCEL_OPTIONS"] = options
-        if margin is not None:
-            env["BF_DEBUG_MARGIN"] = str(margin)   # the library's test hook: a 1-pixel margin makes events outrun their bins
+        if margin is not None:   # the TEST build's hook (tests/helpers.py): a 1-pixel margin makes events outrun their bins
+            env = debug_cli_env(env)
+            env["BF_DEBUG_MARGIN"] = str(margin)
         r = subprocess.run([gpu_cli, "--quiet", "--res-x=180", "--res-y=240", "-o", out, "--slice-log=" + log] + list(extra) + [path],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]

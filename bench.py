@@ -155,6 +155,21 @@ def main():
         raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible (one rank per GPU; --oversubscribe "
                          "shares devices, for tests)" % (world, ndev))
     device = local_rank % ndev
+    # Host-core budget (SURVEY 8(e)'s caveat: feeding must not serialise).  A rank's slice contexts poll their loops from host
+    # threads: measured 0.7 - 0.85 busy cores per rank with four contexts in flight (config.host_cores_busy_per_rank), less
+    # with fewer.  More ranks than the cores this job may use would time the host, not the GPUs: refuse, loudly, unless the
+    # caller says the ranks share on purpose (--oversubscribe: tests).
+    cores_avail = host_cores()
+    cores_needed = world * min(1.0, 0.25 + 0.15 * max(1, args.concurrent))
+    host_budget = {"ranks": world, "slice_contexts_per_rank": max(1, args.concurrent), "polling_cores_needed": round(cores_needed, 2),
+                   "host_cores_available": cores_avail, "ok": cores_needed <= cores_avail}
+    if rank == 0:
+        print("bench.py: host-core budget: %d rank(s) x %d slice context(s) need ~%.1f polling cores, %d available%s"
+              % (world, max(1, args.concurrent), cores_needed, cores_avail, "" if host_budget["ok"] else " -- OVER BUDGET"), file=sys.stderr)
+    if not host_budget["ok"] and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks need ~%.1f host cores for polling but this job may use %d (cpu affinity / cgroup quota): "
+                         "the result would time the host; give the job more cores, lower --concurrent, or pass --oversubscribe"
+                         % (world, cores_needed, cores_avail))
     # this rank next to its GPU: the CPUs (and preferred memory) of the device's host NUMA node -- every thread started from here
     # inherits the binding, every pinned buffer allocated from here on is first touched there (SURVEY 8(e)'s caveat)
     affinity_at_start = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
@@ -214,7 +229,7 @@ def main():
             its = [merged[i]["iterations"] for i in range(args.farm_slices)]
             bal = farm.balance(merged, world)
             line = json.dumps({
-                "metric": METRIC, "value": ev / elapsed / 1e6, "unit": "Mevents/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                "metric": METRIC, "value": ev / elapsed / 1e6, "value_definition": "host_to_host", "unit": "Mevents/s", "n_gpus": world, "steps": 1, "warmup": 0,
                 "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "BASELINE config 5: batch of %d independent %d-event 30 ms slices at %dx%d, scale %d, "
@@ -230,6 +245,7 @@ def main():
                            # per rank: seconds from the start to its last slice, slices taken; imbalance = slowest rank / mean
                            "ranks": {"busy_s": bal["busy_s"], "slices": bal["slices"], "imbalance": bal["imbalance"],
                                      "numa_node_of_rank0": numa_node},
+                           "host_budget": host_budget,
                            # ms: upload issue (under the lane's previous solve) -> model; solve_ms: the lane's own time for the slice
                            "per_slice": {"iterations": its, "ms": [round(merged[i]["ms"], 3) for i in range(args.farm_slices)],
                                          "solve_ms": [round(merged[i]["solve_ms"], 3) for i in range(args.farm_slices)],
@@ -317,6 +333,22 @@ def main():
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(elapsed, 1e-9)
+    # The CPU baseline (one host core, ~10 s to the loop's own termination) starts NOW, in a side process, and runs under the
+    # GPU legs that follow (regimes, roofline, other geometries: several seconds of kernels) instead of after them: the
+    # headline above was timed without it, and whoever samples the GPU's activity during this run sees it busy.
+    cpu_side = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import subprocess
+        cpu_side = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--events", str(args.events),
+                                     "--height", str(H), "--width", str(W), "--scale", str(s), "--cpu-iters", str(args.cpu_iters),
+                                     "--cpu-worker-seed", "1"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        if affinity_at_start is not None:   # (any core the job was given: not pinned to this GPU's NUMA node)
+            try:
+                os.sched_setaffinity(cpu_side.pid, affinity_at_start)
+            except OSError:
+                pass
+        assert cpu_side.stdout.readline().strip() == "ready"
+        cpu_side.stdin.write("go\n"); cpu_side.stdin.flush()
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -595,6 +627,22 @@ def main():
                         "frac": K1_BYTES_PER_EVENT_ITER * n2 / k1 / 1e9 / HBM_PEAK_GBPS,
                         "iteration_frac": (K1_BYTES_PER_EVENT_ITER * n2 + 24.0 * px2) / ((p2.warp_scatter_ms + p2.stencil_ms) * 1e-3 / it2) / 1e9 / HBM_PEAK_GBPS,
                         "iterations": int(i2.iterations)})
+                    # The event-list stencil kernel moves ~0.2 x of its 24 B / pixel (the lists follow the events, not the
+                    # area): a byte fraction says nothing about it.  Its bound is the VECTOR UNIT: waves x vector instructions
+                    # per wave (rocprofv3 SQ_INSTS_VALU / SQ_WAVES of this build, profiles/r6_valu.json) over the chip's issue
+                    # rate -- 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz = 614 G wave-instructions/s.
+                    vj_ = os.path.join(ROOT, "profiles", "r6_valu.json")
+                    if fmt2 == 2 and os.path.exists(vj_):
+                        vk_ = [v_ for k_, v_ in json.load(open(vj_)).get("%dx%d" % (W2, H2), {}).items() if k_.startswith("k_stencil_binned")]
+                        if vk_:
+                            vpw_ = max(vk_, key=lambda v_: v_["launches"])["valu_per_wave"]
+                            waves_ = ((w2.scale_img_x + 15) // 16) * ((w2.scale_img_y + 63) // 64) * 4
+                            issue_ = 256 * 4 * 2.4e9 / 4
+                            bound_us_ = waves_ * vpw_ / issue_ * 1e6
+                            other_geo[-1]["stencil_compute_bound"] = {
+                                "bound": "valu", "valu_per_wave": vpw_, "waves_per_launch": waves_, "issue_rate_wave_insts_per_s": issue_,
+                                "bound_us": bound_us_, "achieved_frac": bound_us_ / (1e3 * p2.stencil_ms / it2),
+                                "source": "profiles/r6_valu.json (the co-scheduled build of the kernel; this run is the head-update form)"}
                 except Exception as e:   # (a measurement beside the contract's: never the reason a bench line is missing)
                     other_geo.append({"geometry": "%dx%d" % (W2, H2), "error": str(e)[:200]})
         # The two loop kernels with the CHIP FULL of their own work-groups: one context solving eight config-2 slices side by
@@ -654,6 +702,30 @@ def main():
             "traffic": stencil_traffic,
             "note": "bound by dependent latency and instruction issue (its waves wait ~55 % of their cycles), not by bandwidth: see DESIGN.md section 4 and profiles/*pmc_sq_issue.txt",
         }
+        # The same two fractions from the COMMITTED rocprofv3 summary of the same solo run (profiles/r6_solo_tail_kernel_stats.csv,
+        # `rocprofv3 --kernel-trace --stats -- python scripts/run_once.py 3 co_schedule=1`: scripts/profile_r6.sh): the average
+        # duration rocprofv3 reports for the kernel, early-exit launches included, so that the line can be re-derived from
+        # profiles/ alone.  null when the file is absent, or when this is not the workload it was taken on.
+        def rocprof_of(prefix, alg_bytes):
+            path = os.path.join(ROOT, "profiles", "r6_solo_tail_kernel_stats.csv" if B > 1 else "r6_solo_kernel_stats.csv")
+            if not (os.path.exists(path) and args.events == 1000000 and (H, W, s) == (260, 346, 3) and not args.opt):
+                return None
+            import csv
+            best = None
+            for r_ in csv.DictReader(open(path)):
+                nm = r_["Name"].replace("void ", "")
+                if nm.startswith("bf::" + prefix) and (best is None or float(r_["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                    best = r_
+            if best is None:
+                return None
+            us = float(best["AverageNs"]) * 1e-3
+            return {"source": "profiles/" + os.path.basename(path), "kernel": best["Name"].split("(")[0].replace("void ", ""),
+                    "calls": int(best["Calls"]), "avg_launch_us": us, "achieved": alg_bytes / us / 1e3,
+                    "frac": alg_bytes / us / 1e3 / HBM_PEAK_GBPS}
+        k1_obj["rocprof"] = rocprof_of("k_bin_warp_scatter", K1_BYTES_PER_EVENT_ITER * ev_per_launch)
+        k3_obj["rocprof"] = rocprof_of("k_stencil_binned", 24.0 * img_px)
+        for o_ in (k1_obj, k3_obj):
+            o_["frac_rocprof"] = o_["rocprof"]["frac"] if o_["rocprof"] else None
         dom_is_k3 = p.stencil_ms > p.warp_scatter_ms
         dom = k3_obj if dom_is_k3 else k1_obj
         roofline = {
@@ -677,7 +749,7 @@ def main():
                                   ((alone_form[0].warp_scatter_ms + alone_form[0].stencil_ms) * 1e-3 / max(1, alone_form[1])) / 1e9 / HBM_PEAK_GBPS,
             },
             "achieved": dom["achieved"],
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["frac"], "frac_rocprof": dom["frac_rocprof"], "traffic": dom["traffic"],
             "avg_launch_us": dom["avg_launch_us"], "launches": int(live), "launches_incl_early_exit": int(p.warp_scatter_launches),
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
             "measured_copy_ceiling_gbps": copy_gbps,
@@ -694,21 +766,20 @@ def main():
             },
             "note": "durations are the kernels' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events on the "
                     "ctx stream), summed over every loop launch and divided by the launches that did work; "
-                    "rocprofv3's view of the same solo runs: profiles/r5_solo_tail_kernel_stats.csv (these variants: lean 512-thread "
-                    "scatter kernel, update in the stencil tail) and r5_solo_kernel_stats.csv (update at the head, 1024 threads)",
+                    "rocprofv3's view of the same solo runs: profiles/r6_solo_tail_kernel_stats.csv (these variants: lean 512-thread "
+                    "scatter kernel, update in the stencil tail; `frac_rocprof` is computed from it) and r6_solo_kernel_stats.csv "
+                    "(update at the head, 1024 threads)",
         }
 
     # ---- CPU baseline: the oracle (port of the reference path), rank 0 at N = 1 only -------
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
+    if cpu_side is not None:
+        import collections
         sl = slices[0]
-        oc = oracle.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
-        ow = oc.set_cloud(s, H, W)
-        om = oracle.Model()
-        tc = time.perf_counter()
-        orc_, oloop, _ = oc.run(ow, om, max_iter=(args.cpu_iters - 1) if args.cpu_iters > 0 else -1, res_x=H, res_y=W)
-        dtc = time.perf_counter() - tc
+        n_cpu, it_cpu, dtc = (float(x) for x in cpu_side.stdout.readline().split())   # (the side process started above)
+        cpu_side.wait()
+        assert int(n_cpu) == len(sl["t"])
+        oloop = collections.namedtuple("Loop", "itercount")(int(it_cpu))
         per_iter = dtc / max(1, oloop.itercount)
         full_iters = iters / max(1, args.steps * B)      # the GPU run's iterations per slice
         if args.cpu_iters > 0:
@@ -820,6 +891,9 @@ def main():
         out = {
             "metric": METRIC,
             "value": events_all / elapsed / 1e6,
+            # which definition `value` uses, machine readable: inputs resident in HBM when the timed region starts (the bench
+            # contract of this build's task statement); SURVEY 8(d)'s host-to-host form is value_host_to_host
+            "value_definition": "hbm_resident",
             "unit": "Mevents/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -843,6 +917,7 @@ def main():
                                "no collectives" % (world, B),
                 "host_cores_busy_per_rank": host_cores_busy,
                 "host_cores_available": host_cores(),
+                "host_budget": host_budget,
             },
             # SURVEY 8(d)'s own definition of the metric (host arrays -> model on the host, H2D included), cold regime:
             # the number next to `value`, which keeps the inputs resident in HBM as the bench contract prescribes

@@ -110,7 +110,7 @@ EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
     "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_get_stat", "bf_upload_events", "bf_upload_events_device",
     "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
-    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_many", "bf_run_tiles", "bf_get_trace",
+    "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_many", "bf_run_tiles", "bf_run_tiles_many", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
@@ -159,6 +159,22 @@ def run_many(accels, opts=None):
         bad = next((a for a, i in zip(accels, infos) if i.rc < 0), accels[0])
         raise BfError(rc, L.bf_last_error(bad.h).decode())
     return [(infos[i].rc, models[i], infos[i]) for i in range(n)]
+
+
+def run_tiles_many(accels, grid_rows, grid_cols, scale, sensor_res, guard_res, min_events, max_iter=-1, hard_iter_cap=20000):
+    """bf_run_tiles_many: the tile grids of the slices uploaded on `accels` in one launch.  Returns [(models, infos)] per slice."""
+    n = len(accels)
+    L = accels[0].L
+    o = TileOpts(grid_rows, grid_cols, scale, sensor_res[0], sensor_res[1], guard_res[0], guard_res[1], min_events, max_iter,
+                 hard_iter_cap)
+    nt = grid_rows * grid_cols
+    hs = (C.c_void_p * n)(*[a.h for a in accels])
+    models = (Model * (n * nt))()
+    infos = (RunInfo * (n * nt))()
+    rc = L.bf_run_tiles_many(hs, n, C.byref(o), models, infos)
+    if rc < 0:
+        raise BfError(rc, L.bf_last_error(accels[0].h).decode())
+    return [(list(models[i * nt:(i + 1) * nt]), list(infos[i * nt:(i + 1) * nt])) for i in range(n)]
 
 
 class BfError(RuntimeError):
@@ -215,6 +231,7 @@ def load(path=None):
         L.bf_set_model.argtypes = [C.c_void_p, C.POINTER(Model)]
         L.bf_run.argtypes = [C.c_void_p, C.POINTER(RunOpts), C.POINTER(Model), C.POINTER(RunInfo)]
         L.bf_run_tiles.argtypes = [C.c_void_p, C.POINTER(TileOpts), C.c_void_p, C.c_void_p]
+        L.bf_run_tiles_many.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TileOpts), C.c_void_p, C.c_void_p]
         L.bf_run_many.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RunOpts), C.c_void_p, C.c_void_p]
         L.bf_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.bf_profile_enable.argtypes = [C.c_void_p, C.c_int32]
@@ -455,14 +472,24 @@ class Accel:
         self._chk(fn(self.h, _ptr(fr_x), _ptr(fr_y), _ptr(t_ns), int(n)))
         self._pending_n = getattr(self, "_pending_n", []) + [int(n)]
 
-    def upload_ring_async(self, ring_x, ring_y, ring_ts, first, n, t0, ring_noise=None):
+    def upload_ring_async(self, ring_x, ring_y, ring_ts, first, n, t0, ring_noise=None, span_ns=None):
         """Slice = n events from ring index `first` (wrapping) of row / column / uint64 timestamp ring arrays (pinned for
         a true DMA; pageable arrays work too); times become ts - t0 on the device.  int32 addresses go through
-        bf_upload_ring_async, uint16 addresses through bf_upload_ring16_async; ring_noise: optional uint8 Event::noise ring."""
+        bf_upload_ring_async, uint16 addresses through bf_upload_ring16_async; ring_noise: optional uint8 Event::noise ring.
+
+        A uint32 `ring_ts` holds the LOW 32 bits of the timestamps (bf_upload_ring16t32_async, 8 bytes per event): the device
+        can only form (int32)(ts32 - (uint32)t0), which is the true difference while |ts - t0| < 2^31 ns (2.1 s) and a
+        plausible-looking WRONG time beyond -- the 64-bit forms mark such an event and bf_set_cloud reports it, this form
+        cannot.  So the caller, who has the full timestamps, must state the slice's span: `span_ns` = max |ts - t0| over the
+        slice (required with uint32 timestamps); 2^31 or more is refused here."""
         assert ring_x.dtype == ring_y.dtype and ring_x.dtype in (np.int32, np.uint16) and ring_ts.dtype in (np.uint64, np.uint32)
         assert ring_noise is None or ring_noise.dtype == np.uint8
         if ring_ts.dtype == np.uint32:   # the low 32 bits of the timestamps: 8 bytes per event (bf_upload_ring16t32_async)
             assert ring_x.dtype == np.uint16
+            if span_ns is None:
+                raise ValueError("uint32 timestamps: pass span_ns = max |timestamp - t0| of the slice (from the full timestamps)")
+            if not (0 <= int(span_ns) < (1 << 31)):
+                raise BfError(BF_ERR_ARG, "a slice that reaches %d ns from its start does not fit 32-bit local times (limit 2^31 ns)" % int(span_ns))
             fn = self.L.bf_upload_ring16t32_async
         else:
             fn = self.L.bf_upload_ring_async if ring_x.dtype == np.int32 else self.L.bf_upload_ring16_async

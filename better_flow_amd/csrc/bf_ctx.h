@@ -124,6 +124,9 @@ struct bf_ctx {
     uint32_t *d_tile_hist = nullptr, *d_tile_start = nullptr, *d_tile_cursor = nullptr;
     DevState* d_tile_states = nullptr;
     int tiles_alloc = 0;
+    void* d_many_args = nullptr;     // bf_run_tiles_many (lead context): the slices' launch arguments + the claim counter
+    void* h_many_args = nullptr;     // ... and their pinned staging copy
+    int many_alloc = 0;
     int32_t *d_in_x = nullptr, *d_in_y = nullptr, *d_in_t = nullptr;
     // streaming: a second staging slot, a copy stream and one event per slot
     int32_t* d_in2[3] = {nullptr, nullptr, nullptr};

@@ -4,8 +4,11 @@
 
 extern "C" {
 
-int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_info* infos_out) {
-    if (!c || !o) return BF_ERR_ARG;
+namespace {
+
+// Everything of bf_run_tiles ahead of the optimizer launch, on stream `s` (the context's own, or the batch's): buffers, the
+// tiles' zero-model states, the counting sort of the slice's events by sensor tile.  Fills the launch's arguments.
+int tiles_prepare(bf_ctx* c, const bf_tile_opts* o, hipStream_t s, TileArgs& a) {
     if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_run_tiles before bf_upload_events");
     if (o->grid_rows < 1 || o->grid_cols < 1 || (long long)o->grid_rows * o->grid_cols > 16384)
         return fail(c, BF_ERR_ARG, "bad tile grid %d x %d", o->grid_rows, o->grid_cols);
@@ -31,7 +34,7 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
         HIP_TRY(c, hipMalloc(&c->d_tile_start, (size_t)(nt + 1) * 4));
         HIP_TRY(c, hipMalloc(&c->d_tile_cursor, (size_t)(nt + 1) * 4));
         HIP_TRY(c, hipMalloc(&c->d_tile_states, (size_t)nt * sizeof(DevState)));
-        HIP_TRY(c, hipMemsetAsync(c->d_tile_hist, 0, (size_t)(nt + 1) * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_hist, 0, (size_t)(nt + 1) * 4, s));
         c->tiles_alloc = nt;
     }
     // LDS image capacity: the largest window a tile can have
@@ -48,7 +51,7 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     tmpl.max_iter = o->max_iter;
     tmpl.hard_cap = o->hard_iter_cap;
     tmpl.hot.wp = identity_warp();
-    launch_fill_states(c->d_tile_states, tmpl, nt, c->stream);
+    launch_fill_states(c->d_tile_states, tmpl, nt, s);
 
     TileGrid g;
     g.rows = o->grid_rows; g.cols = o->grid_cols; g.res_x = o->sensor_res_x; g.res_y = o->sensor_res_y;
@@ -57,11 +60,10 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     {
         ProfScope ps(c, 3);
         launch_tile_sort(src.xy, src.t, c->has_perm ? src.perm : nullptr, c->n, g, c->d_tile_hist, c->d_tile_start,
-                         c->d_tile_cursor, dst.xy, dst.t, dst.p, dst.perm, c->stream);
+                         c->d_tile_cursor, dst.xy, dst.t, dst.p, dst.perm, s);
     }
     c->cs ^= 1;
     c->has_perm = true;
-    TileArgs a;
     a.xy = dst.xy; a.t = dst.t; a.p = dst.p; a.perm = dst.perm;
     a.nxny = c->d_nxny;
     a.tile_start = c->d_tile_start;
@@ -71,14 +73,11 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     a.guard_res_x = o->guard_res_x; a.guard_res_y = o->guard_res_y;
     a.min_events = o->min_events;
     a.max_px = (int32_t)max_px;
-    {
-        ProfScope ps(c, 0, c->n);
-        if (launch_tile_optimizer(a, nt, c->stream) != 0) return fail(c, BF_ERR_HIP, "cannot configure the tile kernel");
-    }
-    HIP_TRY(c, hipGetLastError());
-    std::vector<DevState> st((size_t)nt);
-    HIP_TRY(c, hipMemcpyAsync(st.data(), c->d_tile_states, (size_t)nt * sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+// The tiles' final states (already on the host) into the caller's arrays, and the context's flags after a tile run.
+void tiles_collect(bf_ctx* c, const std::vector<DevState>& st, int nt, bf_model* models_out, bf_run_info* infos_out) {
     for (int i = 0; i < nt; ++i) {
         if (models_out) models_out[i] = st[(size_t)i].model;
         if (infos_out) {
@@ -100,6 +99,89 @@ int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_
     c->degenerate = false;
     c->use_binned = false;    // the events are now sorted by sensor tile, not by image tile
     c->fused_ok = false;
+}
+
+}  // namespace
+
+int bf_run_tiles(bf_ctx* c, const bf_tile_opts* o, bf_model* models_out, bf_run_info* infos_out) {
+    if (!c || !o) return BF_ERR_ARG;
+    TileArgs a;
+    int rc = tiles_prepare(c, o, c->stream, a);
+    if (rc != BF_OK) return rc;
+    const int nt = o->grid_rows * o->grid_cols;
+    {
+        ProfScope ps(c, 0, c->n);
+        if (launch_tile_optimizer(a, nt, c->stream) != 0) return fail(c, BF_ERR_HIP, "cannot configure the tile kernel");
+    }
+    HIP_TRY(c, hipGetLastError());
+    std::vector<DevState> st((size_t)nt);
+    HIP_TRY(c, hipMemcpyAsync(st.data(), c->d_tile_states, (size_t)nt * sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tiles_collect(c, st, nt, models_out, infos_out);
+    return BF_OK;
+}
+
+// The tile grids of n slices -- one per context, each uploaded -- in ONE launch on the first context's stream
+// (k_tile_optimizer_many): work-groups claim (slice, tile) pairs from a device counter, so the straggler tiles of the first
+// slices run under the bulk of the later ones without a stream (and a hardware queue) per slice.
+int bf_run_tiles_many(bf_ctx* const* ctxs, int32_t n, const bf_tile_opts* o, bf_model* models_out, bf_run_info* infos_out) {
+    if (!ctxs || n < 1 || !o || !ctxs[0]) return BF_ERR_ARG;
+    bf_ctx* lead = ctxs[0];
+    if (n > 4096) return fail(lead, BF_ERR_ARG, "at most 4096 slices per call (got %d)", n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(lead, BF_ERR_ARG, "context %d is NULL", i);
+        if (ctxs[i]->device != lead->device) return fail(lead, BF_ERR_ARG, "context %d lives on another device", i);
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(lead, BF_ERR_ARG, "context %d appears twice (one slice per context)", i);
+    }
+    HIP_TRY(lead, hipSetDevice(lead->device));
+    const int nt = o->grid_rows * o->grid_cols;
+    if (n > lead->many_alloc) {
+        if (lead->d_many_args) HIP_TRY(lead, hipFree(lead->d_many_args));
+        if (lead->h_many_args) HIP_TRY(lead, hipHostFree(lead->h_many_args));
+        lead->d_many_args = nullptr; lead->h_many_args = nullptr; lead->many_alloc = 0;
+        HIP_TRY(lead, hipMalloc(&lead->d_many_args, (size_t)n * sizeof(TileArgs) + 64));
+        HIP_TRY(lead, hipHostMalloc(&lead->h_many_args, (size_t)n * sizeof(TileArgs), hipHostMallocDefault));
+        lead->many_alloc = n;
+    }
+    TileArgs* host_args = static_cast<TileArgs*>(lead->h_many_args);
+    TileArgs* dev_args = static_cast<TileArgs*>(lead->d_many_args);
+    uint32_t* counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lead->d_many_args) + (size_t)lead->many_alloc * sizeof(TileArgs));
+    // every slice's preparation on the lead's stream, behind whatever its own context's stream still holds for it
+    for (int i = 0; i < n; ++i) {
+        bf_ctx* c = ctxs[i];
+        if (c != lead) {
+            HIP_TRY(c, hipEventRecord(c->poll_ev[0], c->stream));
+            HIP_TRY(lead, hipStreamWaitEvent(lead->stream, c->poll_ev[0], 0));
+        }
+        TileArgs a;
+        const int rc = tiles_prepare(c, o, lead->stream, a);
+        if (rc != BF_OK) {
+            if (c != lead) fail(lead, rc, "slice %d: %s", i, c->err);
+            (void)hipStreamSynchronize(lead->stream);
+            return rc;
+        }
+        host_args[i] = a;
+    }
+    HIP_TRY(lead, hipMemcpyAsync(dev_args, host_args, (size_t)n * sizeof(TileArgs), hipMemcpyHostToDevice, lead->stream));
+    HIP_TRY(lead, hipMemsetAsync(counter, 0, sizeof(uint32_t), lead->stream));
+    {
+        long long ev = 0;
+        for (int i = 0; i < n; ++i) ev += ctxs[i]->n;
+        ProfScope ps(lead, 0, ev);
+        if (launch_tile_optimizer_many(dev_args, n, nt, o->scale, host_args[0].max_px, counter, lead->n_cus, lead->stream) != 0)
+            return fail(lead, BF_ERR_HIP, "cannot configure the tile kernel");
+    }
+    HIP_TRY(lead, hipGetLastError());
+    std::vector<DevState> st((size_t)n * (size_t)nt);
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(lead, hipMemcpyAsync(st.data() + (size_t)i * nt, ctxs[i]->d_tile_states, (size_t)nt * sizeof(DevState),
+                                     hipMemcpyDeviceToHost, lead->stream));
+    HIP_TRY(lead, hipStreamSynchronize(lead->stream));   // (everything of every slice is complete: the other contexts' streams need no event)
+    for (int i = 0; i < n; ++i) {
+        std::vector<DevState> one(st.begin() + (size_t)i * nt, st.begin() + (size_t)(i + 1) * nt);
+        tiles_collect(ctxs[i], one, nt, models_out ? models_out + (size_t)i * nt : nullptr, infos_out ? infos_out + (size_t)i * nt : nullptr);
+    }
     return BF_OK;
 }
 

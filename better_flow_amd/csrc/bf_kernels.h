@@ -141,6 +141,8 @@ void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm
                       uint32_t* hist, uint32_t* start, uint32_t* cursor, uint32_t* oxy, int32_t* ot, float2* op,
                       uint32_t* operm, hipStream_t s);
 int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s);
+int launch_tile_optimizer_many(const TileArgs* slices, int nslices, int ntiles, int scale, int max_px, uint32_t* counter, int n_cus,
+                               hipStream_t s);
 void launch_fill_states(DevState* states, const DevState& tmpl, int nt, hipStream_t s);
 
 // bf_rebin.hip / bf_scatter.hip / bf_stencil.hip / bf_fused.hip (the tile-binned loops)

@@ -246,9 +246,7 @@ int bf_set_cloud(bf_ctx* c, int32_t scale, int32_t res_x, int32_t res_y, bf_wind
             // row), so that a stencil tile gathers from the bins beside its own only the zone that faces it (bf_scatter.hip,
             // "event lists").  zw: the columns of a bin's tile a box sum of the neighbouring stencil tile can reach.
             c->grid.zw = 0;
-#ifndef BF_EXP_NOZONES
             if (c->fmt == 2 && g.TS == 64 && g.L >= 2 * (g.D + scale / 2 + 1)) c->grid.zw = g.D + scale / 2 + 1;
-#endif
         }
         h.t_span = (c->n > 0) ? (long long)s.tmax - (long long)s.tmin : 0;
         h.t_abs_max = (c->n > 0) ? std::fmax(std::fabs((double)s.tmin), std::fabs((double)s.tmax)) : 0.0;

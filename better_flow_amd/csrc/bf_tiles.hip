@@ -116,12 +116,10 @@ __global__ __launch_bounds__(kThreads) void k_tile_scatter(const uint32_t* __res
 // HS: scale / 2 when it is 0, 1 or 2 (the box sum's eighteen LDS reads per pixel are then issued together instead of one
 // by one from a loop with run-time bounds: 4.1 -> us of a 7.8 us iteration), -1: any scale.
 template <int THREADS, int HS>
-__global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
-    extern __shared__ unsigned long long s_dyn[];
+__device__ __forceinline__ void tile_optimizer_body(const TileArgs& a, const int tile, unsigned long long* s_dyn) {
     __shared__ DevState s_st;
     __shared__ int s_box[4];
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
     const uint32_t beg = a.tile_start[tile], end = a.tile_start[tile + 1];
     const int n = (int)(end - beg);
     unsigned long long* s_ts = s_dyn;                                         // sum of t (i64 as u64)
@@ -346,6 +344,37 @@ __global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
     if (tid == 0) a.states[tile] = s_st;
 }
 
+template <int THREADS, int HS>
+__global__ __launch_bounds__(THREADS) void k_tile_optimizer(TileArgs a) {
+    extern __shared__ unsigned long long s_dyn[];
+    tile_optimizer_body<THREADS, HS>(a, blockIdx.x, s_dyn);
+}
+
+// The tile grids of SEVERAL slices in one launch (bf_run_tiles_many): a grid of resident work-groups, each claiming
+// (slice, tile) pairs from one device counter until none are left.  A slice's grid alone lasts as long as its slowest tile
+// (3047 iterations against a mean of 91 on the config-4 slice) while its bulk is done in under a millisecond; here the
+// stragglers of slices 0 .. k run under the bulk of slices k + 1 ..., in ONE stream -- no extra hardware queues, no
+// environment variable (a grid per slice context needed GPU_MAX_HW_QUEUES=16 before the first HIP call to get past four
+// grids in flight).  Items are claimed slice by slice, a slice's tiles in index order; an item is the same computation as
+// a work-group of k_tile_optimizer -- the same function, the same bits.
+template <int THREADS, int HS>
+__global__ __launch_bounds__(THREADS) void k_tile_optimizer_many(const TileArgs* __restrict__ slices, int nslices, int ntiles,
+                                                                 uint32_t* __restrict__ counter) {
+    extern __shared__ unsigned long long s_dyn[];
+    __shared__ uint32_t s_item;
+    const uint32_t total = (uint32_t)nslices * (uint32_t)ntiles;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(counter, 1u);
+        __syncthreads();
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (item >= total) return;
+        const uint32_t sl = item / (uint32_t)ntiles;
+        const TileArgs a = slices[sl];   // (uniform index: scalar loads)
+        tile_optimizer_body<THREADS, HS>(a, (int)(item - sl * (uint32_t)ntiles), s_dyn);
+        __syncthreads();   // (the item's LDS -- state, planes, s_item -- is free again)
+    }
+}
+
 __global__ void k_fill_states(DevState* states, DevState tmpl, int nt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nt) states[i] = tmpl;
@@ -371,22 +400,46 @@ void launch_tile_sort(const uint32_t* xy, const int32_t* t, const uint32_t* perm
     }
 }
 
+// (256 threads per tile optimizer; 512 / 1024: measured, no gain -- experiments/rounds_1_to_3.md)
+constexpr int kTileThreads = 256;
+
+template <class K>
+static int tile_kernel_lds(K k) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k)) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - (int)at.sharedSizeBytes) != hipSuccess) return -1;
+    return 0;
+}
+
 int launch_tile_optimizer(const TileArgs& a, int ntiles, hipStream_t s) {
     const size_t lds = (size_t)a.max_px * (8 + 4 + 4);
-    constexpr int threads = 256;   // (512 / 1024 threads per tile optimizer: measured, no gain -- experiments/rounds_1_to_3.md)
     const int hs = a.scale / 2;
-#define BF_TILE(T_)                                                                       \
-    do {                                                                                  \
-        void (*k)(TileArgs) = hs == 0 ? k_tile_optimizer<T_, 0> : (hs == 1 ? k_tile_optimizer<T_, 1> : (hs == 2 ? k_tile_optimizer<T_, 2> : k_tile_optimizer<T_, -1>)); \
-        hipFuncAttributes at;                                                             \
-        if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k)) != hipSuccess) return -1; \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes) != hipSuccess) return -1; \
-        hipLaunchKernelGGL(k, dim3(ntiles), dim3(T_), lds, s, a);                         \
-    } while (0)
-    if (threads >= 1024) BF_TILE(1024);
-    else if (threads >= 512) BF_TILE(512);
-    else BF_TILE(256);
-#undef BF_TILE
+    void (*k)(TileArgs) = hs == 0 ? k_tile_optimizer<kTileThreads, 0>
+                        : (hs == 1 ? k_tile_optimizer<kTileThreads, 1> : (hs == 2 ? k_tile_optimizer<kTileThreads, 2> : k_tile_optimizer<kTileThreads, -1>));
+    if (tile_kernel_lds(k) != 0) return -1;
+    hipLaunchKernelGGL(k, dim3(ntiles), dim3(kTileThreads), lds, s, a);
+    return 0;
+}
+
+// `slices`: nslices TileArgs in DEVICE memory (same scale and max_px in all); `counter`: one zeroed word.
+int launch_tile_optimizer_many(const TileArgs* slices, int nslices, int ntiles, int scale, int max_px, uint32_t* counter, int n_cus,
+                               hipStream_t s) {
+    const size_t lds = (size_t)max_px * (8 + 4 + 4);
+    const int hs = scale / 2;
+    void (*k)(const TileArgs*, int, int, uint32_t*) =
+        hs == 0 ? k_tile_optimizer_many<kTileThreads, 0>
+                : (hs == 1 ? k_tile_optimizer_many<kTileThreads, 1> : (hs == 2 ? k_tile_optimizer_many<kTileThreads, 2> : k_tile_optimizer_many<kTileThreads, -1>));
+    if (tile_kernel_lds(k) != 0) return -1;
+    // as many work-groups as the device holds at once (more would only queue and find the counter exhausted)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), kTileThreads, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    long long grid = (long long)per_cu * (n_cus > 0 ? n_cus : 256);
+    const long long items = (long long)nslices * ntiles;
+    if (grid > items) grid = items;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kTileThreads), lds, s, slices, nslices, ntiles, counter);
     return 0;
 }
 

@@ -332,6 +332,18 @@ typedef struct bf_tile_opts {
 } bf_tile_opts;
 int bf_run_tiles(bf_ctx *ctx, const bf_tile_opts *opts, bf_model *models_out, bf_run_info *infos_out);
 
+/* The tile grids of n slices in ONE launch: the reference's queue of (events, model) tasks (dvs_flow.h:200-231) holding the
+ * tiles of several slices at once.  ctxs: n DISTINCT contexts of one device, each holding its own uploaded slice; opts: the
+ * grid, shared by all.  One resident grid of work-groups on ctxs[0]'s stream claims (slice, tile) pairs from a device
+ * counter -- slice by slice, a slice's tiles in index order -- so the straggler tiles of the first slices (a grid alone
+ * lasts as long as its slowest tile: thousands of iterations against a mean of ~90) run under the bulk of the later ones.
+ * No stream and no hardware queue per slice: the sustained rate does not depend on the host process's GPU_MAX_HW_QUEUES
+ * (a grid per context in flight needs 16 queues to pass ~180 Mevents/s; the runtime's default is 4).  Every (slice, tile)
+ * is the computation of bf_run_tiles -- the same bits.  models_out / infos_out: n * grid_rows * grid_cols entries, slice
+ * major (either may be NULL).  Afterwards every context is in the state bf_run_tiles leaves it in (bf_compute_uv etc.
+ * read its per-event results).  Blocking; returns the first error (its text on ctxs[0]). */
+int bf_run_tiles_many(bf_ctx *const *ctxs, int32_t n, const bf_tile_opts *opts, bf_model *models_out, bf_run_info *infos_out);
+
 /* A batch of independent slices -- the reference's queue of (events, model) tasks (dvs_flow.h:200-231, executed there
  * one after the other) -- solved together: bf_run on each of the n contexts, all in flight at once (one host thread per
  * context inside the library; the contexts' streams share the GPU, set "co_schedule" on them when n > 1).  Every

@@ -11,8 +11,12 @@ reference would queue these (events, model) tasks one after the other (dvs_flow.
 A grid's launch lasts as long as its slowest tile (~21 ms) while its bulk is done in under a millisecond, so the sustained rate
 is "grids in flight / 21 ms" until the GPU's slots are full -- and the HIP runtime gives a process FOUR hardware queues
 (GPU_MAX_HW_QUEUES, default 4): the streams of a fifth grid queue behind another grid's straggler.  With the variable at 16
-(set here before the first HIP call unless the caller set it) and 16 grids in flight: 189 -> 510 Mevents/s (24 / 32: 450 /
-382).  The opposite of the iteration loop's dependent 10 us kernels, where more than four queues lose (EXPERIMENTS.md)."""
+(--hw-queues 16: set here before the first HIP call) and 16 grids in flight: 189 -> 510 Mevents/s (24 / 32: 450 /
+382).  The opposite of the iteration loop's dependent 10 us kernels, where more than four queues lose (EXPERIMENTS.md).
+
+--many K (round 6): bf_run_tiles_many -- K slices' grids in ONE launch, work-groups claiming (slice, tile) pairs from a device
+counter, batches issued from --many-lanes host threads (2: the next batch's sort and bulk run under the previous batch's
+stragglers).  Needs no environment variable: the default leaves GPU_MAX_HW_QUEUES alone."""
 import argparse
 import json
 import os
@@ -20,13 +24,8 @@ import sys
 import threading
 import time
 
-if "--grids" in sys.argv:   # (before the HIP runtime starts: it reads the variable once)
-    try:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, int(sys.argv[sys.argv.index("--grids") + 1])))))
-    except (ValueError, IndexError):
-        pass
-else:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+if "--hw-queues" in sys.argv:   # (before the HIP runtime starts: it reads the variable once)
+    os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[sys.argv.index("--hw-queues") + 1]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -42,6 +41,10 @@ def main():
     ap.add_argument("--grids", type=int, default=16, help="tile grids (slice contexts) in flight for the sustained figure")
     ap.add_argument("--reps", type=int, default=6, help="slices per context in the sustained run")
     ap.add_argument("--slices", type=int, default=4, help="distinct slices")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0: leave the environment alone)")
+    ap.add_argument("--many", type=int, default=32, help="slices per bf_run_tiles_many call (0: skip that measurement)")
+    ap.add_argument("--many-lanes", type=int, default=2, help="host threads issuing bf_run_tiles_many batches")
+    ap.add_argument("--many-reps", type=int, default=4, help="batches per lane")
     a_ = ap.parse_args()
     guard = (max(1, H // G), max(1, W // G))
     slices = [synth.make_slice(N, H, W, 0.030, seed=1 + k) for k in range(a_.slices)]
@@ -92,6 +95,53 @@ def main():
     for c in accs:
         c.close()
     ev_s, it_s = sum(x[0] for x in tot), sum(x[1] for x in tot)
+    many = None
+    if a_.many > 0:
+        K, LN = a_.many, max(1, a_.many_lanes)
+        sets = [[accel.Accel(max_events=nmax, max_rows=s * H + s, max_cols=s * W + s) for _ in range(K)] for _ in range(LN)]
+
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=a_.grids)   # the uploads of a batch side by side, as the grids-in-flight form has them
+        t_up, t_run = [0.0], [0.0]
+
+        def batch(ln, r):
+            def up(k):
+                sl_ = slices[(k + r + ln) % len(slices)]
+                sets[ln][k].upload_events(sl_["fr_x"], sl_["fr_y"], sl_["t"])
+                return len(sl_["t"])
+            t0_ = time.perf_counter()
+            ev = sum(pool.map(up, range(K)))
+            t1_ = time.perf_counter()
+            out_ = accel.run_tiles_many(sets[ln], G, G, s, (H, W), guard, min_events=a_.min_events, hard_iter_cap=20000)
+            t_up[0], t_run[0] = t1_ - t0_, time.perf_counter() - t1_
+            return ev, int(sum(i.iterations for _, inf in out_ for i in inf))
+        for ln in range(LN):
+            batch(ln, 0)       # warm: allocations, code objects
+        t0 = time.perf_counter()
+        one_ev, _ = batch(0, 1)
+        one_dt = time.perf_counter() - t0
+        up_ms, run_ms = t_up[0], t_run[0]
+        totm = [[0, 0] for _ in range(LN)]
+
+        def mlane(ln):
+            for r in range(a_.many_reps):
+                e_, i_ = batch(ln, r)
+                totm[ln][0] += e_; totm[ln][1] += i_
+        th = [threading.Thread(target=mlane, args=(ln,)) for ln in range(LN)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dtm = time.perf_counter() - t0
+        for st_ in sets:
+            for c in st_:
+                c.close()
+        many = {"slices_per_launch": K, "host_lanes": LN, "batches": LN * a_.many_reps, "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES", "unset"),
+                "one_batch_ms": 1e3 * one_dt, "one_batch_upload_ms": 1e3 * up_ms, "one_batch_run_tiles_many_ms": 1e3 * run_ms,
+                "one_batch_mevents_per_s": one_ev / one_dt / 1e6,
+                "seconds": dtm, "mevents_per_s": sum(x[0] for x in totm) / dtm / 1e6, "tile_iterations_per_s": sum(x[1] for x in totm) / dtm,
+                "ms_per_slice": 1e3 * dtm / (LN * a_.many_reps * K), "uploads": "included (blocking bf_upload_events per slice)"}
     per_iter_us = 1e6 * best / max(1, it.max())
     out = {"config": "4: %dx%d tiles over %d-event %dx%d slices, scale %d, guards: min_events=%d, RES=%dx%d" %
                      (G, G, n, W, H, s, a_.min_events, guard[1], guard[0]),
@@ -100,7 +150,8 @@ def main():
                            "iterations_max": int(it.max()), "tile_iterations_per_s": float(it.sum() / best),
                            "floor": "the slowest tile's %d iterations x %.2f us per iteration of one work-group = %.1f ms: a grid cannot "
                                     "finish before its slowest tile" % (int(it.max()), per_iter_us, 1e-3 * it.max() * per_iter_us)},
-           "sustained": {"grids_in_flight": a_.grids, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "slices": a_.grids * a_.reps, "seconds": dts, "mevents_per_s": ev_s / dts / 1e6,
+           "many_slices_per_launch": many,
+           "sustained": {"grids_in_flight": a_.grids, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default: 4)"), "slices": a_.grids * a_.reps, "seconds": dts, "mevents_per_s": ev_s / dts / 1e6,
                          "tile_iterations_per_s": it_s / dts, "ms_per_slice": 1e3 * dts / (a_.grids * a_.reps)},
            "flow_median_px_s": [float(np.median(u[np.abs(u) > 0])) if (np.abs(u) > 0).any() else 0.0,
                                 float(np.median(v[np.abs(v) > 0])) if (np.abs(v) > 0).any() else 0.0],

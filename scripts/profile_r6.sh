@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-5 rocprofv3 passes (run on the GPU box via gpurun; outputs under gpurun_out/prof_r5, then
-# `python scripts/collect_r5.py` here copies the summaries into profiles/r5_*):
+# Round-6 rocprofv3 passes (run on the GPU box via gpurun; outputs under gpurun_out/prof_r6, then
+# `python scripts/collect_r6.py` here copies the summaries into profiles/r6_*):
 #   solo_head / solo_tail : --kernel-trace --stats over ONE slice context (update at the scatter head, 1024-thread scatter
 #                           work-groups / lean 512-thread scatter kernel + update in the stencil tail: the headline regime's variants)
 #   bench                 : --kernel-trace --stats over the default bench.py command (4 contexts in flight)
@@ -11,7 +11,7 @@
 #   sq_346 / sq_720       : SQ issue / wait counters
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/prof_r5
+O=$R/gpurun_out/prof_r6
 rm -rf $O; mkdir -p $O
 KS="--kernel-trace --stats --output-format csv"
 timeout 300 rocprofv3 $KS -d $O/solo_head -o s -- python $R/scripts/run_once.py 3 > $O/solo_head.log 2>&1

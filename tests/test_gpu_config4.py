@@ -118,3 +118,43 @@ def test_config4_full_size_every_tile_against_its_oracle(oracle_lib, accel_mod):
     assert it_g.max() > 1000, "the straggler regime (one tile far above the mean) must be part of the test"
     # (13 of 957 need the second bar today; bounded at 2 %, not at a comfortable multiple)
     assert second_bar <= ran // 50, second_bar
+
+
+def test_config4_many_slices_in_one_launch_same_bits(accel_mod):
+    """bf_run_tiles_many: K = 4 slices' 32 x 32 grids in ONE launch (work-groups claim (slice, tile) pairs from a device
+    counter).  Every tile of every slice must be the bits of bf_run_tiles on that slice alone -- return code, iteration
+    count, dividers, model, per-event flow -- and slice 0 is the slice the test above holds to the oracle tile by tile.
+    Twice in a row on the same contexts (the claim counter and the tiles' states are re-armed), and with the contexts in
+    another order."""
+    K = 4
+    slices = [synth.make_slice(1000000, H, W, 0.030, seed=1 + k) for k in range(K)]
+    nmax = max(len(sl["t"]) for sl in slices)
+
+    def canon(models, infos):
+        return [(i.rc, i.iterations, i.x_divider, i.y_divider, i.rot_divider, i.div_divider,
+                 tuple(np.float64(getattr(m, f)).tobytes() for f, _ in m._fields_ if f != "_pad")) for m, i in zip(models, infos)]
+    single = []
+    for sl in slices:
+        acc = accel_mod.Accel(max_events=nmax, max_rows=S * H + S, max_cols=S * W + S)
+        acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        models, infos = acc.run_tiles(G, G, S, (H, W), GUARD, min_events=MIN_EVENTS, hard_iter_cap=HARD_CAP)
+        u, v = acc.compute_uv()
+        single.append((canon(models, infos), u.tobytes(), v.tobytes()))
+        acc.close()
+    assert max(i[1] for i in single[0][0]) > 1000, "the straggler regime must be part of the test"
+    accs = [accel_mod.Accel(max_events=nmax, max_rows=S * H + S, max_cols=S * W + S) for _ in range(K)]
+    for order in (list(range(K)), list(range(K)), [2, 0, 3, 1]):
+        for k in order:
+            sl = slices[k]
+            accs[k].upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        out = accel_mod.run_tiles_many([accs[k] for k in order], G, G, S, (H, W), GUARD, min_events=MIN_EVENTS, hard_iter_cap=HARD_CAP)
+        for pos, k in enumerate(order):
+            models, infos = out[pos]
+            assert canon(models, infos) == single[k][0], (order, k)
+            u, v = accs[k].compute_uv()
+            assert u.tobytes() == single[k][1] and v.tobytes() == single[k][2], (order, k)
+    # errors are loud: a context twice, an empty list
+    with pytest.raises(accel_mod.BfError):
+        accel_mod.run_tiles_many([accs[0], accs[0]], G, G, S, (H, W), GUARD, min_events=MIN_EVENTS)
+    for a in accs:
+        a.close()

@@ -1181,15 +1181,22 @@ def test_ring16_hand_off_with_noise_and_flow_ring(oracle_lib, accel_mod):
     for t0b in (t0, (7 << 32) - 12_345_678, (1 << 32) - 1, 3 * (1 << 32) + 5):
         ts_b = np.zeros(cap, np.uint64)
         ts_b[idx] = sl["t"].astype(np.uint64) + np.uint64(t0b)
-        acc.upload_ring_async(ring_row, ring_col, (ts_b & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0b, ring_noise)
+        acc.upload_ring_async(ring_row, ring_col, (ts_b & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0b, ring_noise,
+                              span_ns=int(sl["t"].max()))
         acc.commit_upload()
         got = solve(acc)
         assert np.array_equal(got[0], want[0]) and got[1:] == want[1:], t0b
     shift = 9_000_000                                               # the slice start in the middle of the slice: t in [-9 ms, 31 ms)
     acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"] - shift, noise)
     want_neg = solve(acc)
-    acc.upload_ring_async(ring_row, ring_col, (ring_ts & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0 + shift, ring_noise)
+    acc.upload_ring_async(ring_row, ring_col, (ring_ts & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0 + shift, ring_noise,
+                          span_ns=max(shift, int(sl["t"].max()) - shift))
     acc.commit_upload()
+    # the contract of the 32-bit form is the caller's to state: no span, or a span of 2^31 ns and more, is refused
+    with pytest.raises(ValueError):
+        acc.upload_ring_async(ring_row, ring_col, (ring_ts & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0, ring_noise)
+    with pytest.raises(accel_mod.BfError):
+        acc.upload_ring_async(ring_row, ring_col, (ring_ts & np.uint64(0xffffffff)).astype(np.uint32), first, n, t0, ring_noise, span_ns=1 << 31)
     got = solve(acc)
     assert np.array_equal(got[0], want_neg[0]) and got[1:] == want_neg[1:]
     # ... and a linear slice with 16-bit addresses and its own int32 times (bf_upload_events16_async), both staging slots

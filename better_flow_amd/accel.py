@@ -503,6 +503,10 @@ class Accel:
         assert uv_ring.dtype == np.float64 and uv_ring.size % 2 == 0
         self._chk(self.L.bf_compute_uv_ring(self.h, _ptr(uv_ring), int(uv_ring.size // 2), int(first)))
 
+    def wait_uploads(self):
+        """Block until every asynchronous upload issued so far has been copied (bf_wait_uploads)."""
+        self._chk(self.L.bf_wait_uploads(self.h))
+
     def commit_upload(self):
         self._chk(self.L.bf_commit_upload(self.h))
         self.n = self._pending_n.pop(0)

@@ -91,7 +91,10 @@ int bf_create(int32_t device, int64_t max_events, int32_t max_rows, int32_t max_
         HIP_TRY(c, hipMalloc(&c->d_ticket, 16 * 64 * sizeof(unsigned int)));   // 1 + 32 counters, 64 B apart
         HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, 16 * 64 * sizeof(unsigned int), c->stream));
 
-        HIP_TRY(c, hipHostMalloc(&c->h_state, 2 * sizeof(DevState), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(&c->h_state, 2 * sizeof(DevState) + 64, hipHostMallocDefault));
+        // (behind the two snapshots: the sequence word a warm start's k_finish_update stores AFTER its snapshot -- bf_run.cpp)
+        c->h_seq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_state) + 2 * sizeof(DevState));
+        *c->h_seq = 0ull;
         for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
         HIP_TRY(c, hipHostMalloc(&c->h_stats, kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
         c->d_stats = c->h_stats;   // k_prepare writes its per-work-group records straight into pinned host memory: no copy command
@@ -184,6 +187,14 @@ void bf_destroy(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
     for (int i = 0; i < 2; ++i) if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
     for (int i = 0; i < 2; ++i) if (c->staged[i]) (void)hipEventDestroy(c->staged[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (c->prepared[i]) (void)hipEventDestroy(c->prepared[i]);
+        if (c->inc_free[i]) (void)hipEventDestroy(c->inc_free[i]);
+        if (c->inc[i].xy) (void)hipFree(c->inc[i].xy);
+        if (c->inc[i].t) (void)hipFree(c->inc[i].t);
+        if (c->inc[i].p) (void)hipFree(c->inc[i].p);
+        if (c->h_stats_slot[i]) (void)hipHostFree(c->h_stats_slot[i]);
+    }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; ++i) if (c->d_in2[i]) (void)hipFree(c->d_in2[i]);
     for (int i = 0; i < 2; ++i) if (c->d_in_ts[i]) (void)hipFree(c->d_in_ts[i]);
@@ -270,6 +281,14 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
             if (!c->d_in16[slot]) HIP_TRY(c, hipMalloc(&c->d_in16[slot], (size_t)c->cap_events * 2 * sizeof(uint16_t)));
             if (!c->d_in_noise[slot]) HIP_TRY(c, hipMalloc(&c->d_in_noise[slot], (size_t)c->cap_events));   // (else: first use, possibly in the middle of a solve)
         }
+        return BF_OK;
+    }
+    if (!strcmp(key, "defer_uploads")) {
+        if (!value) {   // (what was recorded goes out before the mode ends)
+            const int rc = issue_deferred_uploads(c);
+            if (rc != BF_OK) return rc;
+        }
+        c->opt_defer_uploads = value != 0;
         return BF_OK;
     }
     if (!strcmp(key, "watchdog_ms")) {

@@ -3,6 +3,7 @@
 // kernel-argument builders, buffer management).  Nothing here is part of the ABI (include/bf_accel.h).
 #pragma once
 #pragma clang diagnostic ignored "-Wunused-function"   // (every file uses its own subset of the helpers below)
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -144,6 +145,25 @@ struct bf_ctx {
     unsigned long long pending_t0[2] = {0, 0};
     unsigned long long* d_in_ts[2] = {nullptr, nullptr};
     int pend_head = 0, pend_count = 0;   // FIFO of pending async uploads (slot = index & 1)
+    // Early staging (round 6): an asynchronous upload WITHOUT a noise ring runs its staging kernels (widening, k_prepare)
+    // on the COPY stream, right behind its copies, into the slot's own event arrays and its own pinned statistics record --
+    // under the previous slice's solve.  bf_commit_upload then only swaps those arrays with set[0]'s (pointers) and makes the
+    // compute stream wait for the slot's `prepared` event: no staging kernel and no statistics round trip are left on a
+    // warm-started chain's critical path (~35 us of a ~230 us slice at 346x260).
+    EvSet inc[2];                                 // xy, t, p of the slice staged in slot i
+    SliceStats* h_stats_slot[2] = {nullptr, nullptr};   // pinned: k_prepare's per-work-group records of slot i
+    hipEvent_t prepared[2] = {nullptr, nullptr};  // slot i's staging kernels have run (copy stream)
+    hipEvent_t inc_free[2] = {nullptr, nullptr};  // the arrays swapped INTO inc[i] at a commit are free (compute stream is past that commit)
+    bool inc_free_valid[2] = {false, false};
+    bool pending_early[2] = {false, false};
+    // "defer_uploads": an asynchronous upload only takes its slot and remembers what to copy; its HIP calls (three copies, the
+    // staging kernels, the events: ~25 us of host time) are issued by the next bf_run once that run's first batch of kernels is in
+    // the queue -- or by whoever needs the slot sooner (bf_commit_upload, bf_wait_uploads).  For a single-threaded caller
+    // driving one warm-started chain those 25 us otherwise sit between two runs, with the GPU idle.
+    bool opt_defer_uploads = false;
+    std::function<int()> deferred[2];
+    const SliceStats* stats_src = nullptr;        // where fold_stats reads (h_stats, or the committed slot's record)
+    hipEvent_t stats_event = nullptr;             // ... once this event has completed (null: the compute stream)
     double2 *d_nxny = nullptr, *d_uv = nullptr;
     unsigned long long* d_plane[2] = {nullptr, nullptr};
     uint32_t* d_cplane[2] = {nullptr, nullptr};
@@ -177,6 +197,8 @@ struct bf_ctx {
     bool stats_valid = false;
 
     DevState* h_state = nullptr;     // pinned, D2H target only: 2 slots (pipelined polling)
+    unsigned long long* h_seq = nullptr;   // pinned: "snapshot complete" sequence number of a warm start's batch (k_finish_update)
+    unsigned long long seq_counter = 0;
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     double opt_watchdog_s = 40.0;    // a cold run whose device iteration counter stands still this long is declared hung
     SliceStats* h_stats = nullptr;   // pinned, D2H target only
@@ -547,10 +569,14 @@ int wait_event_sleeping(bf_ctx* c, hipEvent_t ev) {
 // device-to-host copy per slice, cached).
 int fold_stats(bf_ctx* c) {
     if (c->stats_valid) return BF_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (the records are in pinned host memory once k_prepare has completed)
-    SliceStats s = c->h_stats[0];
+    // (the records are in pinned host memory once k_prepare has completed: on the compute stream, or -- early staging -- on the
+    // copy stream, usually long ago)
+    if (c->stats_event) HIP_TRY(c, hipEventSynchronize(c->stats_event));
+    else HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const SliceStats* src = c->stats_src ? c->stats_src : c->h_stats;
+    SliceStats s = src[0];
     for (int k = 1; k < kPrepBlocks; ++k) {
-        const SliceStats& q = c->h_stats[k];
+        const SliceStats& q = src[k];
         if (q.xmin < s.xmin) s.xmin = q.xmin;
         if (q.xmax > s.xmax) s.xmax = q.xmax;
         if (q.ymin < s.ymin) s.ymin = q.ymin;
@@ -579,6 +605,20 @@ int after_upload(bf_ctx* c, long long n) {
     return BF_OK;
 }
 
+// the HIP side of uploads that were only recorded ("defer_uploads"), oldest first
+int issue_deferred_uploads(bf_ctx* c) {
+    for (int k = 0; k < c->pend_count; ++k) {
+        const int slot = (c->pend_head + k) & 1;
+        if (c->deferred[slot]) {
+            std::function<int()> f;
+            f.swap(c->deferred[slot]);
+            const int rc = f();
+            if (rc != BF_OK) return rc;
+        }
+    }
+    return BF_OK;
+}
+
 // copy stream, its events and the second staging slot of the asynchronous uploads (created on first use)
 int streaming_setup(bf_ctx* c) {
     if (c->copy_stream) return BF_OK;
@@ -586,6 +626,14 @@ int streaming_setup(bf_ctx* c) {
     for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->staged[i], hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) HIP_TRY(c, hipMalloc(&c->d_in2[i], (size_t)c->cap_events * sizeof(int32_t)));
+    for (int i = 0; i < 2; ++i) {   // early staging: the slots' own event arrays, statistics records and events
+        HIP_TRY(c, hipEventCreateWithFlags(&c->prepared[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->inc_free[i], hipEventDisableTiming));
+        HIP_TRY(c, hipMalloc(&c->inc[i].xy, (size_t)c->cap_events * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->inc[i].t, (size_t)c->cap_events * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->inc[i].p, (size_t)c->cap_events * sizeof(float2)));
+        HIP_TRY(c, hipHostMalloc(&c->h_stats_slot[i], kPrepBlocks * sizeof(SliceStats), hipHostMallocDefault));
+    }
     return BF_OK;
 }
 

@@ -116,8 +116,10 @@ void launch_local_time16(const unsigned long long* ts, bool ts32, const uint16_t
 void stencil_grid(int R, int C, int* gx, int* gy);
 void launch_stencil(const StencilArgs& a, int src, hipStream_t s, int n_cus = 0);   // n_cus: lets the tile-binned form pick its build by how often the grid fills the GPU
 // applies a pending update (sums in `acc`) to `st` in place: the tile-binned loop's update outside a warp+scatter launch
+// (snap_seq / seq: after the snapshot has been stored and fenced, `seq` goes to the pinned word the host spins on)
 void launch_finish_update(DevState* st, MomentAcc* acc, const uint32_t* ovf_prev, int j, int cur_prev, bf_trace_rec* trace,
-                          DevState* snap, hipStream_t s, const uint32_t* lost = nullptr);
+                          DevState* snap, hipStream_t s, const uint32_t* lost = nullptr, unsigned long long* snap_seq = nullptr,
+                          unsigned long long seq = 0);
 void launch_compute_uv(const double2* nxny, double2* uv, long long n, hipStream_t s);
 void launch_unpermute(const double2* src, const uint32_t* perm, double2* dst, long long n, hipStream_t s);
 void launch_expand_pr(const uint32_t* xy, const float2* p, const uint32_t* perm, double2* pr, long long n,

@@ -229,6 +229,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     auto ht_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double ht_mark = host_timing ? ht_now() : 0;
     bool prewarp_done = false, persist_gave_up = false;
+    unsigned long long seq_wait = 0;   // sequence number the current quick-warm batch's k_finish_update will publish (0: none)
     for (int batch = 0; persist; ++batch) {
         // One round: the (device-gated) re-bin, the loop kernel -- which returns when the loop is over, when a re-bin is due
         // or after max_passes iterations --, the final warp gated on `done`, and the state for the host.  A round ends with
@@ -275,6 +276,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipEventRecord(c->poll_ev[batch & 1], c->stream));
+        if (batch == 0) {   // ("defer_uploads": the next slice's copies and staging go out now, under this round)
+            const int rcd = issue_deferred_uploads(c);
+            if (rcd != BF_OK) return rcd;
+        }
         if (warm_start) {
             HIP_TRY(c, hipEventSynchronize(c->poll_ev[batch & 1]));
         } else {
@@ -338,10 +343,16 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         // A warm start (bf_set_model) converges in a handful of iterations: its first batch is short and is
         // polled at once, so that ~20 no-op launches and a second poll are not queued behind it.
         int batch_len = o.poll_interval;
-        if (quick_warm) {   // one more iteration than the previous warm start needed, then two at a time
-            batch_len = batch == 0 ? c->warm_iters_hint + 1 : 2;
+        if (quick_warm) {
+            // One more iteration than the previous warm start needed, then two at a time -- and, where the previous one needed
+            // seven or more (a 640x480 stream: 5 .. 14 per slice), two more and then four at a time: a launch that finds the loop
+            // over costs ~2 us, a second look at the batch ~28 us (blocking poll, follow-up launches, another gated final warp).
+            // The first batch may be two polling intervals long (it was capped at one -- 8 -- which sent every slice of 9+
+            // iterations through extra polls: config 3 averaged 2.2 looks per slice).
+            const bool longish = c->warm_iters_hint >= 7;
+            batch_len = batch == 0 ? c->warm_iters_hint + (longish ? 2 : 1) : (longish ? 4 : 2);
             if (batch_len < 2) batch_len = 2;
-            if (batch_len > o.poll_interval) batch_len = o.poll_interval;
+            if (batch_len > 2 * o.poll_interval) batch_len = 2 * o.poll_interval;
         }
         for (int k = 0; k < batch_len; ++k) {
             const bool warp = first ? first_warp : true;
@@ -440,8 +451,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // set on the device: when the batch was enough -- the usual case -- nothing is left to launch
             // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
             if (head_update) {   // `done` of the batch's last iteration: apply its update now (normally the next launch would)
+                seq_wait = ++c->seq_counter;
                 launch_finish_update(state_of(launched_iters), acc_of(launched_iters - 1), ovf_of(launched_iters - 1),
-                                     launched_iters, buf ^ 1, trace, &c->h_state[batch & 1], c->stream, fused ? lost_flag(c) + (launched_iters + 2) % 3 : nullptr);
+                                     launched_iters, buf ^ 1, trace, &c->h_state[batch & 1], c->stream, fused ? lost_flag(c) + (launched_iters + 2) % 3 : nullptr,
+                                     c->h_seq, seq_wait);
                 inf.launches++;
             }
             ProfScope ps(c, 3);
@@ -452,6 +465,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             if (o.want_uv) fa.uv = c->d_uv;
             launch_final_warp(fa, c->stream);
             inf.launches++;
+        }
+        if (batch == 0) {   // ("defer_uploads": the next slice's copies and staging go out now, under this batch)
+            const int rcd = issue_deferred_uploads(c);
+            if (rcd != BF_OK) return rcd;
         }
         HIP_TRY(c, hipGetLastError());
         if (snap_polled) {
@@ -519,7 +536,23 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
         HIP_TRY(c, hipEventRecord(pev[batch & 1], c->stream));
         if (batch == 0 && !quick_warm) continue;
         if (quick_warm) {   // look at this batch straight away
-            HIP_TRY(c, hipEventSynchronize(pev[batch & 1]));
+            // Update at the scatter head: k_finish_update has stored the state in the pinned snapshot itself and, behind a
+            // system-scope fence, this batch's sequence number -- the host spins on that word and has the model while the final
+            // warp (whose results stay on the device) is still running.  A bounded spin: past 2 ms the event decides.
+            bool seen = false;
+            if (seq_wait) {
+                const volatile unsigned long long* sp = c->h_seq;
+                const auto t_spin = std::chrono::steady_clock::now();
+                for (unsigned spins = 0; !seen; ++spins) {
+                    if (*sp == seq_wait) { seen = true; break; }
+#if !defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("pause" ::: "memory");
+#endif
+                    if ((spins & 4095u) == 4095u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 2e-3) break;
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
+            if (!seen) HIP_TRY(c, hipEventSynchronize(pev[batch & 1]));
             inf.polls++;
             const DevState& ws = c->h_state[batch & 1];
             if (ws.hot.done) {
@@ -585,7 +618,9 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     c->uv_valid = o.want_uv != 0;
     c->out_sorted = true;
     HIP_TRY(c, hipGetLastError());
-    if (o.want_uv) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (want_uv: the final warp writes the per-event flow into d_uv; whoever reads it -- bf_compute_uv, bf_compute_uv_ring, the
+    // writers -- does so on this stream, behind it: the run does not wait for it.  It used to drain the stream here, which kept a
+    // warm-started slice's ~15 MB of flow output on the chain's critical path.)
 
     const DevState d = fin;
     h = d;   // model, dividers, warp parameters, plane-buffer dirtiness

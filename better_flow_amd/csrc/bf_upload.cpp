@@ -1,6 +1,10 @@
 // bf_upload.cpp -- C-ABI: staging a slice on the device (AccelLib::init_gpu, accel_lib.h:71-115), blocking, from device arrays, and
 // asynchronously on the copy stream from pinned arrays or from a structure-of-arrays event ring (DVS_flow::recompute hand-off).
+#include <utility>
+
 #include "bf_ctx.h"
+
+static int stage_early(bf_ctx* c, int slot);
 
 // The slice hand-off of DVS_flow::recompute (dvs_flow.h:185-216) for a structure-of-arrays ring in pinned
 // memory: up to two contiguous pieces per array, no repacking on the host.  ADDR is int32_t (bf_upload_ring_async) or
@@ -20,6 +24,7 @@ static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const 
         if (rc != BF_OK) return rc;
     }
     const int slot = (c->pend_head + c->pend_count) & 1;
+    auto body = [=]() -> int {
     if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
     if (!c->d_in_ts[slot]) HIP_TRY(c, hipMalloc(&c->d_in_ts[slot], (size_t)c->cap_events * sizeof(unsigned long long)));
     const bool narrow = sizeof(ADDR) == 2;
@@ -47,7 +52,52 @@ static int upload_ring(bf_ctx* c, const ADDR* ring_x, const ADDR* ring_y, const 
     c->pending_addr16[slot] = narrow;
     c->pending_noise[slot] = ring_noise != nullptr;
     c->pending_t0[slot] = t0;
+    c->pending_early[slot] = false;
+    // (a noise ring goes through d_noise, which the running slice may still read: staged at the commit.  And only a context that
+    // has the GPU to itself stages early: kernels on the copy stream need a hardware queue of their own, and the runtime gives a
+    // process four -- with four "co_schedule"d chains in flight, eight kernel-carrying streams shared them and the warm regime
+    // fell from 5.3 to 3.2 Gevents/s.)
+    if (!ring_noise && !c->opt_co_schedule) {
+        const int rc = stage_early(c, slot);
+        if (rc != BF_OK) return rc;
+    }
+    return BF_OK;
+    };
     c->pend_count++;
+    if (c->opt_defer_uploads) { c->deferred[slot] = body; return BF_OK; }
+    const int rc = body();
+    if (rc != BF_OK) c->pend_count--;
+    return rc;
+}
+
+// Early staging of the slice just copied into `slot` (no noise ring): its widening kernel and k_prepare on the COPY stream,
+// behind the copies, into the slot's own event arrays (inc[slot]) and pinned statistics record.  The arrays may have been
+// swapped out of set[0] at an earlier commit: the compute stream must be past that commit first (inc_free).
+static int stage_early(bf_ctx* c, int slot) {
+    // (the committed slice's statistics may still sit, unread, in this slot's record -- a caller that uploads two slices ahead
+    // before bf_set_cloud: read them before k_prepare overwrites the record)
+    if (c->uploaded && !c->stats_valid && c->stats_src == c->h_stats_slot[slot]) {
+        const int rc = fold_stats(c);
+        if (rc != BF_OK) return rc;
+    }
+    if (c->inc_free_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->inc_free[slot], 0));
+    int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
+    int32_t* dy = slot ? c->d_in2[1] : c->d_in_y;
+    int32_t* dt = slot ? c->d_in2[2] : c->d_in_t;
+    const long long n = c->pending_n[slot];
+    if (c->pending_ts64[slot]) {
+        if (c->pending_addr16[slot])
+            launch_local_time16(c->d_in_ts[slot], c->pending_ts32[slot], c->d_in16[slot], c->d_in16[slot] + c->cap_events, c->pending_t0[slot],
+                                dx, dy, dt, n, c->copy_stream);
+        else
+            launch_local_time(c->d_in_ts[slot], c->pending_t0[slot], dt, n, c->copy_stream);
+    }
+    const long long gran = (long long)kThreads * kEvPerThread;
+    const long long n_pad = (n + gran - 1) / gran * gran;
+    launch_prepare(dx, dy, dt, c->inc[slot].xy, c->inc[slot].t, c->inc[slot].p, n, n_pad, c->h_stats_slot[slot], c->copy_stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->prepared[slot], c->copy_stream));
+    c->pending_early[slot] = true;
     return BF_OK;
 }
 
@@ -64,6 +114,8 @@ static int stage_common(bf_ctx* c, const int32_t* dx, const int32_t* dy, const i
                        c->stream);
         c->cs = 0;
         c->has_perm = false;
+        c->stats_src = c->h_stats;
+        c->stats_event = nullptr;
     }
     HIP_TRY(c, hipGetLastError());
     return after_upload(c, n);
@@ -123,6 +175,7 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
         if (rc != BF_OK) return rc;
     }
     const int slot = (c->pend_head + c->pend_count) & 1;
+    auto body = [=]() -> int {
     // the slot's previous content may still be waiting for its staging kernel on the compute stream
     if (c->staged_valid[slot]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->staged[slot], 0));
     int32_t* dx = slot ? c->d_in2[0] : c->d_in_x;
@@ -135,8 +188,14 @@ int bf_upload_events_async(bf_ctx* c, const int32_t* fr_x, const int32_t* fr_y, 
     HIP_TRY(c, hipEventRecord(c->copy_done[slot], c->copy_stream));
     c->pending_n[slot] = n;
     c->pending_ts64[slot] = false;
+    c->pending_early[slot] = false;
+    return c->opt_co_schedule ? BF_OK : stage_early(c, slot);
+    };
     c->pend_count++;
-    return BF_OK;
+    if (c->opt_defer_uploads) { c->deferred[slot] = body; return BF_OK; }
+    const int rc = body();
+    if (rc != BF_OK) c->pend_count--;
+    return rc;
 }
 
 int bf_upload_ring_async(bf_ctx* c, const int32_t* ring_x, const int32_t* ring_y, const uint64_t* ring_ts, const uint8_t* ring_noise,
@@ -162,6 +221,10 @@ int bf_upload_events16_async(bf_ctx* c, const uint16_t* fr_x, const uint16_t* fr
 int bf_wait_uploads(bf_ctx* c) {
     if (!c) return BF_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    {
+        const int rc = issue_deferred_uploads(c);
+        if (rc != BF_OK) return rc;
+    }
     if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     return BF_OK;
 }
@@ -170,7 +233,35 @@ int bf_commit_upload(bf_ctx* c) {
     if (!c) return BF_ERR_ARG;
     if (c->pend_count == 0) return fail(c, BF_ERR_STATE, "no upload is pending");
     HIP_TRY(c, hipSetDevice(c->device));
+    {   // ("defer_uploads": whatever is still only recorded goes out now, oldest first)
+        const int rc = issue_deferred_uploads(c);
+        if (rc != BF_OK) return rc;
+    }
     const int slot = c->pend_head & 1;
+    if (c->pending_early[slot]) {
+        // Staged already (copy stream): the compute stream waits for that, set[0] takes the slot's arrays -- a pointer swap; the
+        // arrays that leave set[0] may still be in use by what the compute stream holds (the previous slice's last kernels), so
+        // the next staging into them waits for this point of the compute stream -- and the statistics are the slot's record.
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->prepared[slot], 0));
+        std::swap(c->set[0].xy, c->inc[slot].xy);
+        std::swap(c->set[0].t, c->inc[slot].t);
+        std::swap(c->set[0].p, c->inc[slot].p);
+        HIP_TRY(c, hipEventRecord(c->inc_free[slot], c->stream));
+        c->inc_free_valid[slot] = true;
+        c->has_noise = false;
+        const long long gran = (long long)kThreads * kEvPerThread;
+        c->n_pad = (c->pending_n[slot] + gran - 1) / gran * gran;
+        c->cs = 0;
+        c->has_perm = false;
+        c->stats_src = c->h_stats_slot[slot];
+        c->stats_event = c->prepared[slot];
+        c->pending_early[slot] = false;
+        c->staged_valid[slot] = false;   // (the copy stream itself orders the slot's next copies behind its staging kernels)
+        const int rc = after_upload(c, c->pending_n[slot]);
+        c->pend_head++;
+        c->pend_count--;
+        return rc;
+    }
     // the staging kernel (compute stream) waits for the copy; nothing blocks on the host
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done[slot], 0));
     c->has_noise = false;

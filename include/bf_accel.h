@@ -179,6 +179,14 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "stream_prealloc"  1: create now what the asynchronous uploads (bf_upload_events_async / bf_upload_ring*_async) create
  *                  on first use -- the copy stream, its events, both staging slots -- so that the first slice of a stream
  *                  does not pay ~20 ms of allocations.
+ *   "defer_uploads"  1: an asynchronous upload (bf_upload_events_async / bf_upload_events16_async / bf_upload_ring*_async) only takes
+ *                  its staging slot and remembers its arguments; the HIP calls behind it -- three copies, the staging kernels, the
+ *                  events: ~25 us of host time -- are issued by the next bf_run as soon as that run's first batch of kernels is
+ *                  queued (or by bf_commit_upload / bf_wait_uploads, whichever needs the slot first).  For a caller that drives
+ *                  ONE warm-started chain from ONE thread (dvs_flow.h:218-224) -- commit k, upload k + 1, set_cloud, run -- that
+ *                  host time otherwise falls between two runs with the GPU idle.  The host arrays must stay valid until the
+ *                  slice is committed (the asynchronous uploads' contract already).  Not for callers that upload from a second
+ *                  thread.  Default 0.
  *   "watchdog_ms"  a cold bf_run whose device iteration counter has not advanced for this long (wall clock, default
  *                  40000) stops with BF_ERR_HIP "device loop makes no progress" instead of waiting for ever.
  *   "bin_predict"  1 (default): re-bin as soon as the model has moved events by 0.6 x the bins' margin (8 scaled pixels;

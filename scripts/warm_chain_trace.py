@@ -11,6 +11,7 @@ NS = int(sys.argv[3]) if len(sys.argv) > 3 and "=" not in sys.argv[3] else 24
 OPTS = dict(a.split("=") for a in sys.argv[3:] if "=" in a)
 B8 = int(OPTS.pop("bytes", 12)) == 8
 _UP = int(OPTS.pop("uploader", 0))
+AHEAD = int(OPTS.pop("ahead", 1))   # uploads kept in flight ahead of the slice being solved (the context has two staging slots)
 N, s, D = 1000000, 3, 6
 slices = [synth.make_slice(N, H, W, 0.030, seed=100 + i) for i in range(D)]
 nmax = max(len(sl["t"]) for sl in slices)
@@ -48,16 +49,17 @@ for rep in range(2):
     ph.clear()
     prev, its, launches, polls = None, [], 0, 0
     rows = []
-    put(0)
+    for j in range(AHEAD):
+        put(j)
     acc.synchronize()
     t_all = time.perf_counter()
     for i in range(NS):
         if UPLOADER and i > 0:
             timed("wait_uploader", _done.get)
         timed("commit_upload", acc.commit_upload)
-        if i + 1 < NS:
-            if UPLOADER: _q.put(i + 1)
-            else: timed("upload_async", put, i + 1)
+        if i + AHEAD < NS:
+            if UPLOADER: _q.put(i + AHEAD)
+            else: timed("upload_async", put, i + AHEAD)
         timed("set_cloud", acc.set_cloud, s, H, W)
         if prev is not None:
             timed("set_model", acc.set_model, prev)

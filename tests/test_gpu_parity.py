@@ -589,6 +589,48 @@ def test_streaming_upload_matches_blocking(accel_mod):
     assert got == ref
     with pytest.raises(accel_mod.BfError):
         acc.commit_upload()                       # nothing pending
+    # ... TWO uploads ahead of the slice being solved (the staging kernels of slice i + 1 run on the copy stream, into the slot's own
+    # event arrays, while slice i is solved; the commit swaps pointers), plain and with "defer_uploads" (the uploads' HIP calls are
+    # issued by bf_run behind its first batch, or by the commit that needs the slot), 12 and 8 bytes per event, and a per-event
+    # read-back (which follows the swapped arrays) per slice
+    pin4 = [[acc.pinned_int32(nmax) for _ in range(3)] for _ in range(4)]
+    pin16 = [[acc.pinned_array(nmax, np.uint16), acc.pinned_array(nmax, np.uint16), acc.pinned_int32(nmax)] for _ in range(4)]
+    want_uv = []
+    for sl in sls:
+        acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        acc.set_cloud(s, H, W)
+        acc.run()
+        want_uv.append(tuple(a.tobytes() for a in acc.compute_uv()))
+    for defer in (0, 1):
+        for pins in (pin4, pin16):
+            acc.set_option("defer_uploads", defer)
+
+            def put2(i):
+                sl, n = sls[i], len(sls[i]["t"])
+                pins[i][0][:n], pins[i][1][:n], pins[i][2][:n] = sl["fr_x"], sl["fr_y"], sl["t"]
+                acc.upload_events_async(pins[i][0], pins[i][1], pins[i][2], n)
+            put2(0); put2(1)
+
+            def up2(i, sl):
+                acc.commit_upload()
+                if i + 2 < len(sls):
+                    put2(i + 2)
+            assert chain(up2) == ref, (defer, pins is pin16)
+            # cold slices with a per-event read-back each, same pattern
+            put2(0); put2(1)
+            for i in range(len(sls)):
+                up2(i, sls[i])
+                acc.set_cloud(s, H, W)
+                acc.run()
+                assert tuple(a.tobytes() for a in acc.compute_uv()) == want_uv[i], (defer, i)
+    acc.set_option("defer_uploads", 1)
+    put2(0)                                        # recorded only ...
+    acc.set_option("defer_uploads", 0)             # ... goes out when the mode ends
+    acc.wait_uploads()
+    acc.commit_upload()
+    acc.set_cloud(s, H, W)
+    rc, m0, info0 = acc.run()
+    assert (rc, info0.iterations) == ref[0][:2]
     acc.close()
 
 

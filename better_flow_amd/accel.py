@@ -105,6 +105,14 @@ class LocalState(C.Structure):
     ]
 
 
+class LocalTileOpts(C.Structure):
+    _fields_ = [
+        ("grid_rows", C.c_int32), ("grid_cols", C.c_int32), ("scale", C.c_int32), ("wsz", C.c_int32),
+        ("sensor_res_x", C.c_int32), ("sensor_res_y", C.c_int32), ("guard_res_x", C.c_int32), ("guard_res_y", C.c_int32),
+        ("max_evaluations", C.c_int64),
+    ]
+
+
 # every symbol include/bf_accel.h declares
 EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
@@ -114,7 +122,7 @@ EXPORTS = [
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
     "bf_host_alloc", "bf_host_free", "bf_upload_events_async", "bf_commit_upload",
-    "bf_local_set_window", "bf_local_iteration_step", "bf_local_run",
+    "bf_local_set_window", "bf_local_iteration_step", "bf_local_run", "bf_local_run_tiles",
     "bf_upload_ring_async", "bf_upload_ring16_async", "bf_upload_ring16t32_async", "bf_upload_events16_async", "bf_compute_uv_ring", "bf_wait_uploads", "bf_projection_img",
     "bf_color_time_img", "bf_eval_sincos", "bf_device_numa_node", "bf_bind_thread_to_numa_node", "bf_bind_thread_to_device_numa",
 ]
@@ -213,6 +221,7 @@ def load(path=None):
                                           C.POINTER(LocalWindow)]
         L.bf_local_iteration_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p]
         L.bf_local_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(LocalState)]
+        L.bf_local_run_tiles.argtypes = [C.c_void_p, C.POINTER(LocalTileOpts), C.c_void_p, C.c_void_p]
         L.bf_projection_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.bf_color_time_img.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.bf_upload_ring_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
@@ -403,6 +412,16 @@ class Accel:
         if rc < 0:
             self._chk(rc)
         return rc, st
+
+    def local_run_tiles(self, grid_rows, grid_cols, scale, wsz, sensor_res, guard_res, max_evaluations=100000):
+        """A grid of OptimizerLocal windows, one per sensor tile on the tile's own events (bf_local_run_tiles);
+        returns ([LocalState], [rc])."""
+        o = LocalTileOpts(grid_rows, grid_cols, scale, wsz, sensor_res[0], sensor_res[1], guard_res[0], guard_res[1], max_evaluations)
+        nt = grid_rows * grid_cols
+        st = (LocalState * nt)()
+        rcs = (C.c_int32 * nt)()
+        self._chk(self.L.bf_local_run_tiles(self.h, C.byref(o), st, rcs))
+        return list(st), list(rcs)
 
     def default_opts(self):
         o = RunOpts()

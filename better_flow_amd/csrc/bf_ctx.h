@@ -125,6 +125,8 @@ struct bf_ctx {
     uint32_t *d_tile_hist = nullptr, *d_tile_start = nullptr, *d_tile_cursor = nullptr;
     DevState* d_tile_states = nullptr;
     int tiles_alloc = 0;
+    void* d_ltile = nullptr;         // bf_local_run_tiles: the windows' states, then their return codes
+    int ltile_alloc = 0;
     void* d_many_args = nullptr;     // bf_run_tiles_many (lead context): the slices' launch arguments + the claim counter
     void* h_many_args = nullptr;     // ... and their pinned staging copy
     int many_alloc = 0;

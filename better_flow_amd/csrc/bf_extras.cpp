@@ -8,7 +8,7 @@ namespace {
 
 // Everything of bf_run_tiles ahead of the optimizer launch, on stream `s` (the context's own, or the batch's): buffers, the
 // tiles' zero-model states, the counting sort of the slice's events by sensor tile.  Fills the launch's arguments.
-int tiles_prepare(bf_ctx* c, const bf_tile_opts* o, hipStream_t s, TileArgs& a) {
+int tiles_prepare(bf_ctx* c, const bf_tile_opts* o, hipStream_t s, TileArgs& a, bool rolling = true) {
     if (!c->uploaded) return fail(c, BF_ERR_STATE, "bf_run_tiles before bf_upload_events");
     if (o->grid_rows < 1 || o->grid_cols < 1 || (long long)o->grid_rows * o->grid_cols > 16384)
         return fail(c, BF_ERR_ARG, "bad tile grid %d x %d", o->grid_rows, o->grid_cols);
@@ -41,7 +41,7 @@ int tiles_prepare(bf_ctx* c, const bf_tile_opts* o, hipStream_t s, TileArgs& a) 
     const int tr = (o->sensor_res_x + o->grid_rows - 1) / o->grid_rows + 1;
     const int tc = (o->sensor_res_y + o->grid_cols - 1) / o->grid_cols + 1;
     const long long max_px = (long long)(o->scale * tr + o->scale) * (o->scale * tc + o->scale);
-    if (max_px * 16 > 156 * 1024)
+    if (rolling && max_px * 16 > 156 * 1024)   // (the rolling optimizer's planes; bf_local_run_tiles sizes its own window)
         return fail(c, BF_ERR_CAPACITY, "a tile window of up to %lld pixels does not fit the LDS", max_px);
 
     DevState tmpl;
@@ -182,6 +182,60 @@ int bf_run_tiles_many(bf_ctx* const* ctxs, int32_t n, const bf_tile_opts* o, bf_
         std::vector<DevState> one(st.begin() + (size_t)i * nt, st.begin() + (size_t)(i + 1) * nt);
         tiles_collect(ctxs[i], one, nt, models_out ? models_out + (size_t)i * nt : nullptr, infos_out ? infos_out + (size_t)i * nt : nullptr);
     }
+    return BF_OK;
+}
+
+// A grid of OptimizerLocal windows, one per sensor tile, each on the tile's own events (k_local_tile_optimizer, bf_local.hip).
+int bf_local_run_tiles(bf_ctx* c, const bf_local_tile_opts* o, bf_local_state* states_out, int32_t* rc_out) {
+    if (!c || !o) return BF_ERR_ARG;
+    if (o->wsz < 1) return fail(c, BF_ERR_ARG, "wsz must be >= 1");
+    if (o->scale < 1 || o->scale % 2 == 0 || o->scale > 7)   // optimizer_sampler.cpp:206 (odd); the Gaussian is stated to 7
+        return fail(c, BF_ERR_ARG, "scale must be odd and <= 7 (got %d)", o->scale);
+    bf_tile_opts to;
+    memset(&to, 0, sizeof(to));
+    to.grid_rows = o->grid_rows; to.grid_cols = o->grid_cols; to.scale = o->scale;
+    to.sensor_res_x = o->sensor_res_x; to.sensor_res_y = o->sensor_res_y;
+    to.guard_res_x = o->guard_res_x; to.guard_res_y = o->guard_res_y;
+    TileArgs ta;
+    int rc = tiles_prepare(c, &to, c->stream, ta, false);   // (the counting sort by sensor tile; the rolling optimizers' states are not used)
+    if (rc != BF_OK) return rc;
+    const int nt = o->grid_rows * o->grid_cols;
+    if (nt > c->ltile_alloc) {
+        if (c->d_ltile) HIP_TRY(c, hipFree(c->d_ltile));
+        c->d_ltile = nullptr; c->ltile_alloc = 0;
+        HIP_TRY(c, hipMalloc(&c->d_ltile, (size_t)nt * (sizeof(bf_local_state) + sizeof(int32_t))));
+        c->ltile_alloc = nt;
+    }
+    bf_local_state* d_states = static_cast<bf_local_state*>(c->d_ltile);
+    int32_t* d_rcs = reinterpret_cast<int32_t*>(d_states + c->ltile_alloc);
+    TileGrid g;
+    g.rows = o->grid_rows; g.cols = o->grid_cols; g.res_x = o->sensor_res_x; g.res_y = o->sensor_res_y;
+    {
+        ProfScope ps(c, 0, c->n);
+        const int lr = launch_local_tile_optimizer(ta.xy, ta.t, ta.tile_start, d_states, d_rcs, g, o->scale, o->wsz, o->guard_res_x,
+                                                   o->guard_res_y, (long long)o->max_evaluations, c->stream);
+        if (lr == -3) return fail(c, BF_ERR_CAPACITY, "a window of %d x %d pixels does not fit the LDS", o->scale * o->wsz + o->scale, o->scale * o->wsz + o->scale);
+        if (lr != 0) return fail(c, BF_ERR_HIP, "cannot configure the window kernel");
+    }
+    HIP_TRY(c, hipGetLastError());
+    std::vector<bf_local_state> st((size_t)nt);
+    std::vector<int32_t> rcs((size_t)nt);
+    HIP_TRY(c, hipMemcpyAsync(st.data(), d_states, (size_t)nt * sizeof(bf_local_state), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rcs.data(), d_rcs, (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nt; ++i) {
+        if (states_out) states_out[i] = st[(size_t)i];
+        if (rc_out) rc_out[i] = rcs[(size_t)i];
+    }
+    // the events are now sorted by sensor tile (reset products, permutation kept); no per-event result was written
+    c->p_clean = true;
+    c->n_valid = false;
+    c->uv_valid = false;
+    c->out_sorted = false;
+    c->pending_warp = false;
+    c->use_binned = false;
+    c->fused_ok = false;
+    c->have_lwin = false;
     return BF_OK;
 }
 

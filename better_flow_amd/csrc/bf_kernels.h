@@ -252,6 +252,11 @@ void launch_local_project_count(const uint32_t* xy, const int32_t* t, long long 
 int launch_local_blur_score(const uint32_t* plane, uint32_t* zero_plane, const LocalGeom& g, unsigned long long* score,
                             uint8_t* img_out, hipStream_t s);
 
+// a grid of OptimizerLocal windows, one work-group each (bf_local.hip); < 0: scale above 7 / kernel attributes / window too large for the LDS
+int launch_local_tile_optimizer(const uint32_t* xy, const int32_t* t, const uint32_t* tile_start, bf_local_state* states, int32_t* rcs,
+                                const TileGrid& g, int scale, int wsz, int guard_res_x, int guard_res_y, long long max_evaluations,
+                                hipStream_t s);
+
 void launch_proj_count(const uint32_t* xy, const float2* p, const uint8_t* noise, long long n, int scale, int res_x,
                        int res_y, int show_final, uint32_t* plane, hipStream_t s);
 void launch_proj_scale(uint8_t* img, long long n, const unsigned long long* score, hipStream_t s);

@@ -126,6 +126,178 @@ __global__ __launch_bounds__(kThreads) void k_local_blur_score(const uint32_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// A GRID of OptimizerLocal windows (bf_local_run_tiles): the window-centred constructor (optimizer_sampler.h:31-34) once per
+// sensor tile, each with the tile's own events as its cloud, and the WHOLE run() (optimizer_sampler.cpp:4-38: coordinate descent
+// on (nx, ny), step halved and reversed whenever the contrast score does not rise) by ONE work-group per window, on chip: the
+// tile's events in registers, the point plane and the saturated count image in LDS, every evaluation the arithmetic of
+// k_local_project_count + k_local_blur_score above -- Event::project, the saturating s x s splat as a box sum of points, this
+// build's 8-bit Gaussian, the non-zero average as an exact integer ratio -- and the step logic of compute_new_nx / compute_new_ny
+// (:90-117) on one lane.  No launch and no host round trip per evaluation (a window of 1M events alone costs 81 us per
+// evaluation through bf_local_run; a ~1000-event tile here a few microseconds).  Every quantity is an integer or one IEEE
+// operation of the reference's own expression: the states come out bit for bit as the oracle's.
+// ---------------------------------------------------------------------------------------
+struct LocalTileArgs {
+    const uint32_t* xy;
+    const int32_t* t;
+    const uint32_t* tile_start;
+    bf_local_state* states;   // one per tile (out)
+    int32_t* rcs;             // 0 ran, 1 window guard (optimizer_sampler.cpp:9-13), BF_ERR_NOCONV evaluation cap
+    TileGrid g;
+    int32_t scale, wsz, guard_res_x, guard_res_y;
+    long long max_evaluations;
+};
+
+template <int HS>
+__global__ __launch_bounds__(kThreads) void k_local_tile_optimizer(LocalTileArgs a) {
+    extern __shared__ uint32_t s_loc[];
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int s = a.scale;
+    const int ws = s * a.wsz, R = ws + s, P = R * R;   // metric_wsize, scale_img (square window, optimizer_sampler.h:32)
+    uint32_t* s_pts = s_loc;                                       // points (the splat's centres)
+    uint16_t* s_cnt = reinterpret_cast<uint16_t*>(s_loc + P);      // saturated counts
+    __shared__ unsigned long long s_red[2 * (kThreads / 64)];
+    __shared__ double s_nxny[2];
+    __shared__ int s_go;
+    const uint32_t beg = a.tile_start[tile], end = a.tile_start[tile + 1];
+    // the window's centre event: the middle of the tile's rows / columns (tile (tr, tc) holds fr_x * rows / res_x == tr), t = 0
+    const int tr = tile / a.g.cols, tc = tile - tr * a.g.cols;
+    const int x_lo = (tr * a.g.res_x + a.g.rows - 1) / a.g.rows, x_hi = ((tr + 1) * a.g.res_x + a.g.rows - 1) / a.g.rows - 1;
+    const int y_lo = (tc * a.g.res_y + a.g.cols - 1) / a.g.cols, y_hi = ((tc + 1) * a.g.res_y + a.g.cols - 1) / a.g.cols - 1;
+    const int c_fr_x = (x_lo + x_hi) / 2, c_fr_y = (y_lo + y_hi) / 2;
+    // events in registers (a fuller tile streams the rest)
+    constexpr int kUR = 8;
+    uint32_t rxy[kUR];
+    int32_t rt[kUR];
+#pragma unroll
+    for (int k = 0; k < kUR; ++k) {
+        const uint32_t i = beg + (uint32_t)(k * kThreads + tid);
+        rxy[k] = i < end ? a.xy[i] : 0u;
+        rt[k] = i < end ? a.t[i] : 0;
+    }
+    const uint32_t stream_beg = beg + (uint32_t)(kUR * kThreads);
+    // run(): optimizer_sampler.cpp:4-38 (state on lane 0 of wave 0, published through LDS)
+    bf_local_state st;
+    st.nx = 0; st.ny = 0; st.last_score = 0; st.dnx = 0.01; st.dny = 0.01; st.evaluations = 0;
+    st.dn_th = (127 * 1 * 1000.0) / (double)(10ull * (unsigned long long)s * 100000000ull);
+    int rc = 0;
+    if ((R < s * a.guard_res_x / 15) && (R < s * a.guard_res_y / 15)) {   // :9-13
+        if (tid == 0) { a.states[tile] = st; a.rcs[tile] = 1; }
+        return;
+    }
+    int phase = 0;   // 0: the first evaluation (:16), 1: compute_new_nx, 2: compute_new_ny
+    double ex = 0.0, ey = 0.0;   // the (nx, ny) being evaluated
+    for (;;) {
+        // ---- iteration_step(ex, ey), :120-153 ----
+        for (int i = tid; i < P; i += kThreads) s_pts[i] = 0u;
+        const float kx = (float)((double)(float)ex / 127.0), ky = (float)((double)(float)ey / 127.0);   // event.h:164-165
+        const double cpx = pr_from_p((uint32_t)c_fr_x, kx * 0.0f), cpy = pr_from_p((uint32_t)c_fr_y, ky * 0.0f);   // event_c.project, t = 0
+        const double x_shift = -cpx * (double)s + (double)ws / 2.0, y_shift = -cpy * (double)s + (double)ws / 2.0;   // :126-127
+        __syncthreads();
+        auto one = [&](uint32_t v, int32_t ti) {
+            const float ft = (float)ti;
+            const double pr_x = pr_from_p(v & 0xffffu, kx * ft), pr_y = pr_from_p(v >> 16, ky * ft);
+            int X = trunc_x86(pr_x * (double)s + x_shift), Y = trunc_x86(pr_y * (double)s + y_shift);   // :130-131
+            if ((X >= ws) || (X < 0) || (Y >= ws) || (Y < 0)) return;   // :133
+            atomicAdd(&s_pts[(X + s / 2) * R + (Y + s / 2)], 1u);
+        };
+#pragma unroll
+        for (int k = 0; k < kUR; ++k)
+            if (beg + (uint32_t)(k * kThreads + tid) < end) one(rxy[k], rt[k]);
+        for (uint32_t i = stream_beg + tid; i < end; i += kThreads) one(a.xy[i], a.t[i]);
+        __syncthreads();
+        // the saturating splat (:137-146) == min(255, box sum of the points)
+        for (int i = tid; i < P; i += kThreads) {
+            const int r = i / R, c = i - r * R;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int da = -HS; da <= HS; ++da)
+#pragma unroll
+                for (int db = -HS; db <= HS; ++db) {
+                    const int rr = r + da, cc = c + db;
+                    if (rr >= 0 && rr < R && cc >= 0 && cc < R) acc += s_pts[rr * R + cc];
+                }
+            s_cnt[i] = (uint16_t)(acc < 255u ? acc : 255u);
+        }
+        __syncthreads();
+        // this build's 8-bit Gaussian (ksize = scale, BORDER_REFLECT_101; k_local_blur_score) and get_event_score (:192-205)
+        constexpr int kTap[4][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0}, {1, 4, 6, 4, 1, 0, 0}, {2, 7, 14, 18, 14, 7, 2}};
+        constexpr int kNorm[4] = {1, 4, 16, 64};
+        constexpr int n2 = kNorm[HS] * kNorm[HS];
+        unsigned long long nz_sum = 0, nz_cnt = 0;
+        for (int i = tid; i < P; i += kThreads) {
+            const int r = i / R, c = i - r * R;
+            int acc = 0;
+#pragma unroll
+            for (int da = -HS; da <= HS; ++da) {
+                const int rr = reflect101(r + da, R);
+                int row = 0;
+#pragma unroll
+                for (int db = -HS; db <= HS; ++db) row += kTap[HS][db + HS] * (int)s_cnt[rr * R + reflect101(c + db, R)];
+                acc += kTap[HS][da + HS] * row;
+            }
+            const uint32_t v = (uint32_t)((acc + n2 / 2) / n2);
+            if (v) { nz_sum += v; nz_cnt += 1; }
+        }
+        nz_sum = (unsigned long long)wave_total_dpp((long long)nz_sum);
+        nz_cnt = (unsigned long long)wave_total_dpp((long long)nz_cnt);
+        if ((tid & 63) == 63) { s_red[2 * (tid >> 6)] = nz_sum; s_red[2 * (tid >> 6) + 1] = nz_cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long sa = 0, sb = 0;
+            for (int w = 0; w < kThreads / 64; ++w) { sa += s_red[2 * w]; sb += s_red[2 * w + 1]; }
+            const double score = sb == 0 ? 0.0 : (double)sa / (double)sb;
+            st.evaluations += 1;
+            int go = 1;
+            if (phase == 0) {
+                st.last_score = score;   // :16
+            } else if (phase == 1) {     // compute_new_nx, :90-102
+                const double dscore = score - st.last_score;
+                st.last_score = score;
+                if (dscore <= 0) st.dnx = -st.dnx / 2.0;
+                st.nx = ex;
+            } else {                     // compute_new_ny, :105-117
+                const double dscore = score - st.last_score;
+                st.last_score = score;
+                if (dscore <= 0) st.dny = -st.dny / 2.0;
+                st.ny = ey;
+                if (a.max_evaluations > 0 && st.evaluations >= a.max_evaluations) { rc = BF_ERR_NOCONV; go = 0; }
+            }
+            // the next evaluation: after the first one and after every ny step the loop condition (:20) decides
+            if (go && phase != 1 && !(hypot(st.dnx, st.dny) > st.dn_th)) go = 0;
+            if (go) {
+                if (phase == 1) { s_nxny[0] = st.nx; s_nxny[1] = st.ny + st.dny; }
+                else { s_nxny[0] = st.nx + st.dnx; s_nxny[1] = st.ny; }
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) break;
+        ex = s_nxny[0]; ey = s_nxny[1];
+        phase = phase == 1 ? 2 : 1;
+    }
+    if (tid == 0) { a.states[tile] = st; a.rcs[tile] = rc; }
+}
+
+int launch_local_tile_optimizer(const uint32_t* xy, const int32_t* t, const uint32_t* tile_start, bf_local_state* states, int32_t* rcs,
+                                const TileGrid& g, int scale, int wsz, int guard_res_x, int guard_res_y, long long max_evaluations,
+                                hipStream_t s) {
+    LocalTileArgs a;
+    a.xy = xy; a.t = t; a.tile_start = tile_start; a.states = states; a.rcs = rcs; a.g = g;
+    a.scale = scale; a.wsz = wsz; a.guard_res_x = guard_res_x; a.guard_res_y = guard_res_y; a.max_evaluations = max_evaluations;
+    const int R = scale * wsz + scale;
+    const size_t lds = (size_t)R * R * (4 + 2) + 16;
+    void (*k)(LocalTileArgs) = scale / 2 == 0 ? k_local_tile_optimizer<0> : (scale / 2 == 1 ? k_local_tile_optimizer<1>
+                              : (scale / 2 == 2 ? k_local_tile_optimizer<2> : k_local_tile_optimizer<3>));
+    if (scale / 2 > 3) return -1;
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(k)) != hipSuccess) return -2;
+    if (lds + at.sharedSizeBytes > 160 * 1024) return -3;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)at.sharedSizeBytes) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k, dim3(g.rows * g.cols), dim3(kThreads), lds, s, a);
+    return 0;
+}
+
 void launch_local_project_count(const uint32_t* xy, const int32_t* t, long long n, const LocalGeom& g, uint32_t* plane,
                                 hipStream_t s) {
     if (n <= 0) return;

@@ -473,6 +473,26 @@ int bf_local_iteration_step(bf_ctx *ctx, double nx, double ny, double *score, ui
  * reached (the reference has no cap). */
 int bf_local_run(bf_ctx *ctx, int32_t res_x, int32_t res_y, int64_t max_evaluations, bf_local_state *out);
 
+/* A GRID of OptimizerLocal windows over the uploaded slice -- SURVEY f1's formulation of BASELINE config 4 (per-tile local flow):
+ * the sensor is cut into grid_rows x grid_cols tiles (an event belongs to tile (fr_x * grid_rows / sensor_res_x, fr_y *
+ * grid_cols / sensor_res_y), as in bf_run_tiles); every tile gets OptimizerLocal(events of the tile, e, scale, wsz)
+ * (optimizer_sampler.h:31-34) with the centre event e = (middle row of the tile, middle column of the tile, t = 0) -- "middle"
+ * = (first + last) / 2 of the tile's rows / columns, integer division -- and its run() (optimizer_sampler.cpp:4-38): coordinate
+ * descent on (nx, ny) for the largest contrast score.  One work-group per window runs the whole descent on chip.  The window
+ * guard (:9-13) uses guard_res_x / guard_res_y as RES; max_evaluations > 0 caps a window's iteration_step calls (checked after
+ * each ny step, as bf_local_run does).  states_out / rc_out: grid_rows * grid_cols entries (either may be NULL); rc_out[k] is 0,
+ * BF_SKIPPED or BF_ERR_NOCONV.  The blur is this build's stated 8-bit Gaussian (above).  Afterwards the slice's events are
+ * sorted by tile (as after bf_run_tiles) and hold no per-event result. */
+typedef struct bf_local_tile_opts {
+    int32_t grid_rows, grid_cols;
+    int32_t scale;                        /* odd, <= 7 */
+    int32_t wsz;                          /* window side in sensor pixels: metric_wsize = scale * wsz (optimizer_sampler.h:32) */
+    int32_t sensor_res_x, sensor_res_y;   /* sensor rows / columns */
+    int32_t guard_res_x, guard_res_y;     /* RES_X / RES_Y of the window guard */
+    int64_t max_evaluations;              /* <= 0: unlimited */
+} bf_local_tile_opts;
+int bf_local_run_tiles(bf_ctx *ctx, const bf_local_tile_opts *opts, bf_local_state *states_out, int32_t *rc_out);
+
 /* NUMA placement of a feeder thread (no reference counterpart: the reference is single-threaded, SURVEY 8(b) "Threading"; the
  * 8-GPU farm of SURVEY 8(e) wants one feeder thread per GPU with NUMA-local pinned buffers).
  *   bf_device_numa_node          host NUMA node of HIP device `device` (sysfs numa_node of its PCI function); -1: unknown.

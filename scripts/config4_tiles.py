@@ -142,6 +142,28 @@ def main():
                 "one_batch_mevents_per_s": one_ev / one_dt / 1e6,
                 "seconds": dtm, "mevents_per_s": sum(x[0] for x in totm) / dtm / 1e6, "tile_iterations_per_s": sum(x[1] for x in totm) / dtm,
                 "ms_per_slice": 1e3 * dtm / (LN * a_.many_reps * K), "uploads": "included (blocking bf_upload_events per slice)"}
+    # ---- the same grid as OptimizerLocal windows (bf_local_run_tiles: SURVEY f1's formulation of this config) ----
+    accl = accel.Accel(max_events=nmax, max_rows=s * H + s, max_cols=s * W + s)
+    wsz = max((H + G - 1) // G, (W + G - 1) // G)
+    bestl = None
+    for rep in range(4):
+        accl.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        accl.synchronize()
+        t0 = time.perf_counter()
+        lst, lrc = accl.local_run_tiles(G, G, s, wsz, (H, W), guard, max_evaluations=4000)
+        dtl = time.perf_counter() - t0
+        bestl = dtl if bestl is None else min(bestl, dtl)
+    accl.close()
+    lnx = np.array([t_.nx for t_, r_ in zip(lst, lrc) if r_ == 0]); lny = np.array([t_.ny for t_, r_ in zip(lst, lrc) if r_ == 0])
+    lev = np.array([t_.evaluations for t_, r_ in zip(lst, lrc) if r_ == 0])
+    local = {"what": "bf_local_run_tiles: %dx%d OptimizerLocal windows of %d sensor pixels (scale %d), each on its tile's events, the whole "
+                     "coordinate descent on chip" % (G, G, wsz, s),
+             "ms": 1e3 * bestl, "mevents_per_s": n / bestl / 1e6, "windows_run": int(len(lev)), "evaluations_mean": float(lev.mean()),
+             "evaluations_max": int(lev.max()), "window_evaluations_per_s": float(lev.sum() / bestl),
+             # Event::project: pr = fr - (n / 127) t / 10000, t in ns: a flow of v px/s is compensated by n = 127e-5 v
+             "flow_median_px_s": [float(np.median(lnx)) / 127e-5, float(np.median(lny)) / 127e-5],
+             "flow_within_20pct_of_injected": float(np.mean((np.abs(lnx / 127e-5 - sl["velocity"][0]) < 0.2 * abs(sl["velocity"][0])) &
+                                                            (np.abs(lny / 127e-5 - sl["velocity"][1]) < 0.2 * abs(sl["velocity"][1]))))}
     per_iter_us = 1e6 * best / max(1, it.max())
     out = {"config": "4: %dx%d tiles over %d-event %dx%d slices, scale %d, guards: min_events=%d, RES=%dx%d" %
                      (G, G, n, W, H, s, a_.min_events, guard[1], guard[0]),
@@ -150,6 +172,7 @@ def main():
                            "iterations_max": int(it.max()), "tile_iterations_per_s": float(it.sum() / best),
                            "floor": "the slowest tile's %d iterations x %.2f us per iteration of one work-group = %.1f ms: a grid cannot "
                                     "finish before its slowest tile" % (int(it.max()), per_iter_us, 1e-3 * it.max() * per_iter_us)},
+           "local_windows": local,
            "many_slices_per_launch": many,
            "sustained": {"grids_in_flight": a_.grids, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default: 4)"), "slices": a_.grids * a_.reps, "seconds": dts, "mevents_per_s": ev_s / dts / 1e6,
                          "tile_iterations_per_s": it_s / dts, "ms_per_slice": 1e3 * dts / (a_.grids * a_.reps)},

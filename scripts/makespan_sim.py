@@ -5,7 +5,7 @@ iteration counts: "when iteration counts are known")?  List scheduling with the 
 taken with `lanes` contexts sharing one GPU, exactly what every simulated rank runs.  No 8-GPU node was available to this
 build: this is the evidence VERDICT r4 item 2 asks for, not a measurement.
 
-    python scripts/makespan_sim.py profiles/r5_config5_512slices_1gpu.json [profiles/r5_config5_makespan.json]
+    python scripts/makespan_sim.py profiles/r6_config5_512slices_1gpu.json [profiles/r6_config5_makespan.json]
 """
 import json
 import os
@@ -18,7 +18,7 @@ from better_flow_amd import farm
 
 def main():
     src = sys.argv[1]
-    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r5_config5_makespan.json")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r6_config5_makespan.json")
     rec = json.loads(open(src).read().strip().splitlines()[-1])
     per = rec["config"]["per_slice"]
     ms, its = per["solve_ms"], per["iterations"]   # (a lane's own time per slice; "ms" also counts the wait under its previous solve)

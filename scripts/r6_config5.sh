@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the whole config-5 batch on one GPU with per-slice records; the box's NUMA topology; 2-rank farm test on one GPU
+# round 6: the whole config-5 batch on one GPU with per-slice records; the box's NUMA topology; 2-rank farm test on one GPU
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 { echo "== numa =="; lscpu | grep -i -E "numa|socket|^CPU\(s\)|model name"; ls /sys/devices/system/node/ | head; for d in /sys/class/drm/card*/device; do echo "$d $(cat $d/numa_node 2>/dev/null)"; done; nproc; cat /sys/fs/cgroup/cpu.max; } > gpurun_out/r6_numa.txt 2>&1

@@ -158,3 +158,58 @@ def test_config4_many_slices_in_one_launch_same_bits(accel_mod):
         accel_mod.run_tiles_many([accs[0], accs[0]], G, G, S, (H, W), GUARD, min_events=MIN_EVENTS)
     for a in accs:
         a.close()
+
+
+def _tile_bounds(res, grid, k):
+    lo = (k * res + grid - 1) // grid
+    hi = ((k + 1) * res + grid - 1) // grid - 1
+    return lo, hi
+
+
+@pytest.mark.parametrize("case", [(200000, 180, 240, 3, 8, 8, 30, 31), (1000000, 260, 346, 3, 32, 32, 11, 1), (60000, 180, 240, 5, 4, 6, 24, 7),
+                                  (50000, 180, 240, 1, 6, 6, 40, 9)],
+                         ids=["8x8_s3", "config4_32x32_s3", "4x6_s5", "6x6_s1"])
+def test_local_window_grid_every_window_equals_its_oracle_run(oracle_lib, accel_mod, case):
+    """bf_local_run_tiles -- SURVEY f1's formulation of config 4: a grid of OptimizerLocal windows (optimizer_sampler.h:31-34), each
+    on its tile's events, the whole coordinate descent of run() (optimizer_sampler.cpp:4-38) on chip.  Every window's final state
+    -- nx, ny, last score, both steps, the evaluation count -- and return code must EQUAL the oracle's run on the tile's events
+    with the window the entry point documents (centre = middle of the tile, t = 0): integers and single IEEE operations only."""
+    n, Hh, Ww, s, gr, gc, wsz, seed = case
+    sl = synth.make_slice(n, Hh, Ww, 0.030, seed=seed)
+    acc = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * Hh + s, max_cols=s * Ww + s)
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    guard = (max(1, Hh // gr), max(1, Ww // gc))
+    states, rcs = acc.local_run_tiles(gr, gc, s, wsz, (Hh, Ww), guard, max_evaluations=4000)
+    tr = np.minimum(sl["fr_x"].astype(np.int64) * gr // Hh, gr - 1)
+    tc = np.minimum(sl["fr_y"].astype(np.int64) * gc // Ww, gc - 1)
+    tid = tr * gc + tc
+    order = np.argsort(tid, kind="stable")
+    bounds = np.searchsorted(tid[order], np.arange(gr * gc + 1))
+    evals = []
+    # (every window of the small grids; of the 32 x 32 grid every third one -- the oracle is the slow side)
+    for k in range(0, gr * gc, 3 if gr * gc > 500 else 1):
+        sel = order[bounds[k]:bounds[k + 1]]
+        xl, xh = _tile_bounds(Hh, gr, k // gc)
+        yl, yh = _tile_bounds(Ww, gc, k % gc)
+        oc = oracle_lib.Cloud(sl["fr_x"][sel], sl["fr_y"][sel], sl["t"][sel])
+        ow = oc.local_window(s, center=((xl + xh) // 2, (yl + yh) // 2, 0), wsz=wsz)
+        orc, ost, _ = oc.local_run(ow, res_x=guard[0], res_y=guard[1], max_evaluations=4000)
+        orc = accel_mod.BF_ERR_NOCONV if orc < 0 else orc
+        g = states[k]
+        assert rcs[k] == orc, (k, rcs[k], orc)
+        for f in ("nx", "ny", "last_score", "dnx", "dny", "dn_th", "evaluations"):
+            assert getattr(g, f) == getattr(ost, f), (k, f, getattr(g, f), getattr(ost, f), len(sel))
+        evals.append(g.evaluations)
+    nx = np.array([st.nx for st, r in zip(states, rcs) if r == 0])
+    ny = np.array([st.ny for st, r in zip(states, rcs) if r == 0])
+    # Event::project: pr = fr - (n / 127) t / 10000 with t in ns -- a flow of v px/s is compensated by n = 127e-5 v
+    print("%s: %d windows, evaluations mean %.1f max %d; median (nx, ny) = (%.3f, %.3f), the injected flow corresponds to (%.3f, %.3f)"
+          % (case, len(states), np.mean(evals), max(evals), np.median(nx), np.median(ny), 127e-5 * sl["velocity"][0], 127e-5 * sl["velocity"][1]))
+    if s == 3:
+        assert max(evals) > 19                               # (some window does more than halve its steps from the first evaluation on)
+    # the per-event state of the rolling optimizer is untouched territory afterwards: a fresh slice works as before
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    acc.set_cloud(s, Hh, Ww)
+    rc, m, info = acc.run()
+    assert rc == 0 and info.iterations > 10
+    acc.close()

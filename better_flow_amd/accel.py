@@ -117,7 +117,7 @@ class LocalTileOpts(C.Structure):
 EXPORTS = [
     "bf_device_count", "bf_create", "bf_destroy", "bf_last_error", "bf_version",
     "bf_run_opts_default", "bf_abi_struct_sizes", "bf_set_option", "bf_get_stat", "bf_upload_events", "bf_upload_events_device",
-    "bf_set_cloud", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
+    "bf_set_cloud", "bf_project_4param", "bf_project_4param_reinit", "bf_get_time_img", "bf_sobel", "bf_fast_model",
     "bf_writeout_events", "bf_compute_uv", "bf_set_model", "bf_run", "bf_run_many", "bf_run_tiles", "bf_run_tiles_many", "bf_get_trace",
     "bf_profile_enable", "bf_profile_reset", "bf_profile_get", "bf_synchronize",
     "bf_copy_bandwidth", "bf_device_malloc", "bf_device_free", "bf_memcpy_h2d",
@@ -232,6 +232,7 @@ def load(path=None):
         L.bf_compute_uv_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         L.bf_wait_uploads.argtypes = [C.c_void_p]
         L.bf_project_4param_reinit.argtypes = [C.c_void_p] + [C.c_double] * 6
+        L.bf_project_4param.argtypes = [C.c_void_p] + [C.c_double] * 6
         L.bf_get_time_img.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bf_sobel.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.bf_fast_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Model)]
@@ -340,6 +341,10 @@ class Accel:
 
     def project_4param_reinit(self, dnx, dny, cx, cy, div, crl):
         self._chk(self.L.bf_project_4param_reinit(self.h, dnx, dny, cx, cy, div, crl))
+
+    def project_4param(self, dnx, dny, cx, cy, div, crl):
+        """The incremental warp (AccelLib::project_4param, accel_lib.h:275-281): dn added to the events' (nx, ny)."""
+        self._chk(self.L.bf_project_4param(self.h, dnx, dny, cx, cy, div, crl))
 
     def get_time_img(self, want_time=True, want_count=True):
         R, Cc = self.window.scale_img_x, self.window.scale_img_y

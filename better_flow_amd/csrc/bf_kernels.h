@@ -102,6 +102,8 @@ static inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hip
 }
 
 void launch_set_state(DevState* st, const DevState& v, hipStream_t s);
+void launch_project_dn(const uint32_t* xy, const int32_t* t, float2* p, double2* nxny, const uint32_t* perm, int have_n,
+                       const DevState* st, long long n, hipStream_t s);
 // the run's final warp with compute_uv fused (outputs in slot order): one event per thread
 void launch_final_warp(const WarpScatterArgs& a, hipStream_t s);
 void launch_warp_scatter(const WarpScatterArgs& a, bool warp, bool scatter, bool write_n,

@@ -123,6 +123,40 @@ __global__ __launch_bounds__(kThreads) void k_warp_scatter(
     }
 }
 
+// AccelLib::project_4param (accel_lib.h:275-281) -> Event::project_4param (event.h:88-96): the INCREMENTAL warp -- the same dn as
+// project_4param_reinit from the previous pr, but ADDED to the event's (nx, ny) (Event::project_dn, event.h:72-76) before
+// apply_project.  Dead in the reference (its only call is commented out, optimizer_rolling.h:333-339); exported for signature
+// completeness.  nxny: the events' current (nx, ny), indexed by upload order (perm) -- zero when have_n == 0 (Event::reset).
+__global__ __launch_bounds__(kThreads) void k_project_dn(const uint32_t* __restrict__ xy, const int32_t* __restrict__ t, float2* __restrict__ p,
+                                                         double2* __restrict__ nxny, const uint32_t* __restrict__ perm, int have_n,
+                                                         const DevState* __restrict__ st, long long n) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const WarpParams wp = st->hot.wp;
+    const uint32_t v = xy[i];
+    float2 q = p[i];
+    const double pr_x = pr_from_p(v & 0xffffu, q.x), pr_y = pr_from_p(v >> 16, q.y);
+    const long long o = perm ? (long long)perm[i] : i;
+    const double2 old = have_n ? nxny[o] : make_double2(0.0, 0.0);
+    // event.h:89-95 (the expression of warp_products, the sum then ADDED: project_dn)
+    const double rx = pr_x - wp.cx, ry = pr_y - wp.cy;
+    const double qx = wp.c * rx - wp.s * ry;
+    const double qy = wp.s * rx + wp.c * ry;
+    const double nx = old.x + (((-qx) * wp.div + (qx - rx)) + wp.dnx);
+    const double ny = old.y + (((-qy) * wp.div + (qy - ry)) + wp.dny);
+    const float ft = (float)t[i];
+    q.x = div_127((float)nx) * ft;   // apply_project, event.h:164-168
+    q.y = div_127((float)ny) * ft;
+    p[i] = q;
+    nxny[o] = make_double2(nx, ny);
+}
+
+void launch_project_dn(const uint32_t* xy, const int32_t* t, float2* p, double2* nxny, const uint32_t* perm, int have_n,
+                       const DevState* st, long long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_project_dn, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, xy, t, p, nxny, perm, have_n, st, n);
+}
+
 // The last project_4param_reinit of a run (optimizer_rolling.h:340-344) with Event::compute_uv (event.h:135-142) fused:
 // n, (u, v) and the new products for every event, outputs in slot order.  ONE event per thread: the general kernel above
 // takes four consecutive events per thread (16-byte loads), which leaves 3900 waves for 1M events -- four per SIMD, each

@@ -292,6 +292,35 @@ int bf_project_4param_reinit(bf_ctx* c, double dnx_, double dny_, double cx, dou
     return BF_OK;
 }
 
+static int materialize_outputs(bf_ctx* c);
+
+int bf_project_4param(bf_ctx* c, double dnx_, double dny_, double cx, double cy, double div, double crl) {
+    if (!c) return BF_ERR_ARG;
+    if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_project_4param before bf_set_cloud");
+    if (c->degenerate) return fail(c, BF_ERR_STATE, "bf_project_4param on a degenerate (empty) window");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = flush_pending(c);
+    if (rc != BF_OK) return rc;
+    rc = materialize_outputs(c);   // (the events' (nx, ny) in upload order, whatever left them)
+    if (rc != BF_OK) return rc;
+    WarpParams& w = c->hst.hot.wp;
+    w.dnx = dnx_; w.dny = dny_; w.cx = cx; w.cy = cy; w.div = div;
+    w.c = std::cos(crl);   // event.h:91-92 evaluates std::cos / std::sin on the host
+    w.s = std::sin(crl);
+    launch_set_state(c->d_state, c->hst, c->stream);
+    const bf_ctx::EvSet& e = c->set[c->cs];
+    {
+        ProfScope ps(c, 0, c->n);
+        launch_project_dn(e.xy, e.t, e.p, c->d_nxny, c->has_perm ? e.perm : nullptr, c->n_valid ? 1 : 0, c->d_state, c->n, c->stream);
+    }
+    c->p_clean = false;
+    c->n_valid = true;
+    c->uv_valid = false;
+    c->out_sorted = false;
+    HIP_TRY(c, hipGetLastError());
+    return BF_OK;
+}
+
 int bf_get_time_img(bf_ctx* c, float* time_out, uint32_t* count_out) {
     if (!c) return BF_ERR_ARG;
     if (!c->have_window) return fail(c, BF_ERR_STATE, "bf_get_time_img before bf_set_cloud");

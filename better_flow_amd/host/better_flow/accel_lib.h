@@ -150,6 +150,12 @@ public:
         return img;
     }
 
+    // accel_lib.h:275-281: the incremental form (its only call in the reference is commented out, optimizer_rolling.h:333-339)
+    template <class T>
+    inline void project_4param(T * /*events*/, double dnx_, double dny_, double cx, double cy, double div, double crl) {
+        check(bf_project_4param(ctx, dnx_, dny_, cx, cy, div, crl), "project_4param");
+    }
+
     // accel_lib.h:263-267
     template <class T>
     inline void project_4param_reinit(T * /*events*/, double dnx_, double dny_, double cx, double cy, double div,

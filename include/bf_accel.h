@@ -256,6 +256,12 @@ int bf_set_cloud(bf_ctx *ctx, int32_t scale, int32_t res_x, int32_t res_y, bf_wi
 
 /* ---- AccelLib operators -------------------------------------------------------- */
 
+/* AccelLib::project_4param (accel_lib.h:275-281; Event::project_4param, event.h:88-96; project_dn, event.h:72-76): the
+ * INCREMENTAL form -- dn from the previous pr as in the reinit form, ADDED to the event's (nx, ny), then apply_project.  The
+ * reference's only call is commented out (optimizer_rolling.h:333-339); exported so that every member of SURVEY 8(b)'s
+ * signature list exists.  (nx, ny) start at 0 after bf_set_cloud (Event::reset). */
+int bf_project_4param(bf_ctx *ctx, double dnx_, double dny_, double cx, double cy, double div, double crl);
+
 /* AccelLib::project_4param_reinit (accel_lib.h:263-267; Event::project_4param_reinit,
  * event.h:99-110; apply_project, event.h:164-168).  cos/sin of crl are evaluated on
  * the host with libm, as the reference does. */

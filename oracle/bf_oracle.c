@@ -70,6 +70,28 @@ void bfo_set_cloud(bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, b
                  + (double)w->metric_wsizey / 2.0 + (double)(scale / 2);
 }
 
+/* AccelLib::project_4param (accel_lib.h:275-281) applying Event::project_4param (event.h:88-96): the dn of the reinit form,
+ * ADDED to the event's (nx, ny) by project_dn (event.h:72-76), then apply_project (event.h:164-168). */
+void bfo_project_4param(bfo_cloud *ev, double dnx_, double dny_, double cx, double cy, double div, double crl) {
+    for (int64_t i = 0; i < ev->n; ++i) {
+        double rx = ev->pr_x[i] - cx;                      /* event.h:89 */
+        double ry = ev->pr_y[i] - cy;
+        double qx = cos(crl) * rx - sin(crl) * ry;         /* :91-92 */
+        double qy = sin(crl) * rx + cos(crl) * ry;
+        double dnx = (-qx) * div + (qx - rx);              /* :94 */
+        double dny = (-qy) * div + (qy - ry);
+        ev->nx[i] += dnx + dnx_;                           /* :95 -> project_dn, :73-74 */
+        ev->ny[i] += dny + dny_;
+        float kx = (float)((double)(float)ev->nx[i] / BFO_NZ);   /* apply_project, :164-168 */
+        float ky = (float)((double)(float)ev->ny[i] / BFO_NZ);
+        float ft = (float)ev->t[i];
+        float px = kx * ft;
+        float py = ky * ft;
+        ev->pr_x[i] = (double)(float)ev->fr_x[i] - (double)px / 10000.0;
+        ev->pr_y[i] = (double)(float)ev->fr_y[i] - (double)py / 10000.0;
+    }
+}
+
 /* AccelLib::project_4param_reinit (accel_lib.h:263-267) applying
  * Event::project_4param_reinit (event.h:99-110) and Event::apply_project
  * (event.h:164-168) to every event, noise or not. */

@@ -83,6 +83,7 @@ void bfo_set_local_time(const uint64_t *timestamp, int64_t n, uint64_t t0, int64
 void bfo_set_cloud(bfo_cloud *ev, int32_t scale, int32_t res_x, int32_t res_y, bfo_window *w);
 
 /* accel_lib.h:263-267 -> event.h:99-110,164-168 */
+void bfo_project_4param(bfo_cloud *ev, double dnx_, double dny_, double cx, double cy, double div, double crl);
 void bfo_project_4param_reinit(bfo_cloud *ev, double dnx_, double dny_, double cx, double cy,
                                double div, double crl);
 

@@ -128,6 +128,10 @@ class Cloud:
         return w
 
     # accel_lib.h:263-267
+    def project_4param(self, dnx, dny, cx, cy, div, crl):
+        lib().bfo_project_4param(C.byref(self.c), C.c_double(dnx), C.c_double(dny), C.c_double(cx), C.c_double(cy),
+                                 C.c_double(div), C.c_double(crl))
+
     def project_4param_reinit(self, dnx, dny, cx, cy, div, crl):
         lib().bfo_project_4param_reinit(C.byref(self.c), C.c_double(dnx), C.c_double(dny),
                                         C.c_double(cx), C.c_double(cy), C.c_double(div),

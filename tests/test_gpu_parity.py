@@ -72,6 +72,41 @@ def test_warp_state_bit_exact(oracle_lib, accel_mod):
     acc.close()
 
 
+def test_incremental_warp_bit_exact(oracle_lib, accel_mod):
+    """AccelLib::project_4param (accel_lib.h:275-281; Event::project_4param, event.h:88-96): the incremental form -- the reinit
+    form's dn ADDED to the event's (nx, ny).  Dead in the reference (its only call is commented out) and exported for signature
+    completeness: pr / nx / ny bit for bit as the oracle's, from reset, chained, mixed with the reinit form, after a run (whose
+    per-event outputs are tile-sorted on the device) and followed by the count image."""
+    sl = small_slice()
+    oc, ow, acc, gw = make_pair(oracle_lib, accel_mod, sl, 3)
+
+    def same():
+        pr_x, pr_y, nx, ny = acc.writeout_events()
+        assert np.array_equal(pr_x, oc.pr_x) and np.array_equal(pr_y, oc.pr_y)
+        assert np.array_equal(nx, oc.nx) and np.array_equal(ny, oc.ny)
+    for prm in PARAMS:                              # from reset: n == 0, then chained
+        oc.project_4param(*prm); acc.project_4param(*prm)
+        same()
+    oc.project_4param_reinit(*PARAMS[1]); acc.project_4param_reinit(*PARAMS[1])
+    oc.project_4param(*PARAMS[0]); acc.project_4param(*PARAMS[0])
+    same()
+    _, ocnt = oc.get_time_img(ow)
+    _, gcnt = acc.get_time_img(want_time=False)
+    assert np.array_equal(gcnt, ocnt.astype(np.uint32))
+    # after a run the device holds (nx, ny) in tile-sorted order: the incremental form must find each event's own
+    acc.upload_events(sl["fr_x"], sl["fr_y"], sl["t"]); acc.set_cloud(3, sl["height"], sl["width"])
+    o = acc.default_opts(); o.res_x, o.res_y, o.max_iter = sl["height"], sl["width"], 5
+    acc.run(o)
+    pr_x, pr_y, nx, ny = acc.writeout_events()
+    acc.project_4param(*PARAMS[2])
+    oc2 = oracle_lib.Cloud(sl["fr_x"], sl["fr_y"], sl["t"])
+    oc2.pr_x[:], oc2.pr_y[:], oc2.nx[:], oc2.ny[:] = pr_x, pr_y, nx, ny
+    oc2.project_4param(*PARAMS[2])
+    pr_x, pr_y, nx, ny = acc.writeout_events()
+    assert np.array_equal(pr_x, oc2.pr_x) and np.array_equal(pr_y, oc2.pr_y) and np.array_equal(nx, oc2.nx) and np.array_equal(ny, oc2.ny)
+    acc.close()
+
+
 @pytest.mark.parametrize("scale,split", [(1, False), (3, False), (3, True), (5, False)])
 def test_count_and_time_image(oracle_lib, accel_mod, scale, split):
     sl = small_slice()

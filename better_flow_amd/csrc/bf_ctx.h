@@ -164,6 +164,7 @@ struct bf_ctx {
     // driving one warm-started chain those 25 us otherwise sit between two runs, with the GPU idle.
     bool opt_defer_uploads = false;
     std::function<int()> deferred[2];
+    std::mutex stats_mu;                          // fold_stats: bf_set_cloud's thread and an uploading thread (stage_early's guard) may both fold
     const SliceStats* stats_src = nullptr;        // where fold_stats reads (h_stats, or the committed slot's record)
     hipEvent_t stats_event = nullptr;             // ... once this event has completed (null: the compute stream)
     double2 *d_nxny = nullptr, *d_uv = nullptr;
@@ -570,6 +571,9 @@ int wait_event_sleeping(bf_ctx* c, hipEvent_t ev) {
 // Folds the per-work-group min / max / sum records k_prepare wrote for the uploaded slice (one
 // device-to-host copy per slice, cached).
 int fold_stats(bf_ctx* c) {
+    // (one folder at a time: with early staging the thread that uploads the NEXT slice into this record's slot folds the current
+    // slice's statistics first if nobody has -- bf_upload.cpp: stage_early -- while bf_set_cloud may be doing the same)
+    std::lock_guard<std::mutex> lk(c->stats_mu);
     if (c->stats_valid) return BF_OK;
     // (the records are in pinned host memory once k_prepare has completed: on the compute stream, or -- early staging -- on the
     // copy stream, usually long ago)

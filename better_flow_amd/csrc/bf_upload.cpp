@@ -257,7 +257,10 @@ int bf_commit_upload(bf_ctx* c) {
         c->stats_event = c->prepared[slot];
         c->pending_early[slot] = false;
         c->staged_valid[slot] = false;   // (the copy stream itself orders the slot's next copies behind its staging kernels)
-        const int rc = after_upload(c, c->pending_n[slot]);
+        int rc = after_upload(c, c->pending_n[slot]);
+        // the statistics are usually there already (the staging ran under the previous slice's solve): read them now, so that
+        // the slot's record is free for the next upload whoever issues it, and bf_set_cloud has nothing to wait for
+        if (rc == BF_OK && hipEventQuery(c->prepared[slot]) == hipSuccess) rc = fold_stats(c);
         c->pend_head++;
         c->pend_count--;
         return rc;

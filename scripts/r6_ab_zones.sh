@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: event lists sorted by (column zone, row) against row only (libbf_accel_alt.so built -DBF_EXP_NOZONES): bits, both loop
+# round 6: event lists sorted by (column zone, row) against row only -- libbf_accel_alt.so = the same tree with `c->grid.zw` left 0 in
+# bf_set_cloud (bf_operators.cpp; a one-line switch that is not kept in the source): bits, both loop
 # kernels per geometry, the 16-slice config-5 batch; then the GPU suite on the new build.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r6_ab_zones; mkdir -p $O
 cd $R

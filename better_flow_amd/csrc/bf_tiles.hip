@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_scatter(const uint32_t* __res
 // THREADS: a tile is a few hundred to a few thousand events and ~1000 pixels, and the slice is done when
 // its SLOWEST tile is (3047 iterations against a mean of 91 on the config-4 slice): what counts is the latency of one
 // tile's iteration.  Measured: more waves per tile do not shorten it (256 / 512 / 1024 threads: 24.1 / 23.1 / 23.3 ms --
-// the reduction across sixteen waves eats what the shorter loops give), so 256 it is (BF_TILE_THREADS overrides).
+// the reduction across sixteen waves eats what the shorter loops give), so 256 it is.
 // HS: scale / 2 when it is 0, 1 or 2 (the box sum's eighteen LDS reads per pixel are then issued together instead of one
 // by one from a loop with run-time bounds: 4.1 -> us of a 7.8 us iteration), -1: any scale.
 template <int THREADS, int HS>

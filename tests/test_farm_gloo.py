@@ -263,3 +263,38 @@ def test_eight_ranks_a_failing_rank_takes_the_job_down(tmp_path, mode, code):
     assert rc == code, rc
     assert merged is None                                          # rank 0 never got to write a result
     assert wall < 120, wall                                        # (no gloo timeout was waited for: that is 30 minutes)
+
+
+def test_farm_helpers_on_cpu(tmp_path):
+    """The pieces of the farm that need neither a GPU nor a process group: the launcher's exit codes (first failing rank wins, a
+    signal becomes 128 + signal, nothing is left running), the slice-exchange directory (fresh, with room, or a clear error), and
+    run_farm's refusal to hand the whole batch to every rank when it is told `world > 1` without a process group of that size."""
+    sys.path.insert(0, ROOT)
+    import warnings
+    from better_flow_amd import farm
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time, signal\n"
+                      "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if mode == 'ok': sys.exit(0)\n"
+                      "if mode == 'code' and r == 1: time.sleep(0.2); sys.exit(5)\n"
+                      "if mode == 'signal' and r == 2: time.sleep(0.2); os.kill(os.getpid(), signal.SIGKILL)\n"
+                      "time.sleep(60)\n")
+    pids = []
+    assert farm.spawn_local_ranks(3, str(script), ["ok"], pids_out=pids) == 0 and len(pids) == 3
+    assert farm.spawn_local_ranks(3, str(script), ["code"]) == 5          # ranks 0 and 2 sat in their sleep: terminated
+    assert farm.spawn_local_ranks(3, str(script), ["signal"]) == 128 + 9
+    d = farm.make_share_dir(1 << 20, tag="unit")
+    try:
+        assert os.path.isdir(d) and os.listdir(d) == [] and d != farm.make_share_dir.__name__
+        d2 = farm.make_share_dir(1 << 20, tag="unit")
+        assert d2 != d                                                      # a fresh directory every time
+        os.rmdir(d2)
+    finally:
+        os.rmdir(d)
+    with pytest.raises(RuntimeError, match="GB"):
+        farm.make_share_dir(1 << 60)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert farm.run_farm([], rank=1, world=2, dist=None) == {}
+    assert any("static sharding" in str(x.message) for x in w)

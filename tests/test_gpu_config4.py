@@ -213,3 +213,44 @@ def test_local_window_grid_every_window_equals_its_oracle_run(oracle_lib, accel_
     rc, m, info = acc.run()
     assert rc == 0 and info.iterations > 10
     acc.close()
+
+
+def test_tile_grids_on_empty_and_tiny_slices(oracle_lib, accel_mod):
+    """Edge cases of the grid entry points: an EMPTY slice and a slice of a handful of events among the slices of one
+    bf_run_tiles_many launch (every tile of the empty one is skipped by the guard, the others are untouched by its presence),
+    and bf_local_run_tiles on them -- an OptimizerLocal on an empty cloud is not an error in the reference: every score is 0, every
+    step is halved until the threshold, and the oracle does exactly that."""
+    g = 8
+    full = synth.make_slice(120000, 180, 240, 0.030, seed=77)
+    tiny = {k: (v[:5].copy() if hasattr(v, "__len__") and not isinstance(v, tuple) else v) for k, v in full.items()}
+    empty = {"fr_x": np.zeros(0, np.int32), "fr_y": np.zeros(0, np.int32), "t": np.zeros(0, np.int64)}
+    guard = (180 // g, 240 // g)
+    ref = accel_mod.Accel(max_events=len(full["t"]), max_rows=3 * 180 + 3, max_cols=3 * 240 + 3)
+    ref.upload_events(full["fr_x"], full["fr_y"], full["t"])
+    rm, ri = ref.run_tiles(g, g, 3, (180, 240), guard, min_events=256, hard_iter_cap=20000)
+    ref.close()
+    accs = [accel_mod.Accel(max_events=len(full["t"]), max_rows=3 * 180 + 3, max_cols=3 * 240 + 3) for _ in range(3)]
+    for a, sl in zip(accs, (empty, full, tiny)):
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+    out = accel_mod.run_tiles_many(accs, g, g, 3, (180, 240), guard, min_events=256, hard_iter_cap=20000)
+    assert all(i.rc == 1 and i.iterations == 0 for i in out[0][1]) and all(i.rc == 1 for i in out[2][1])
+    assert [(i.rc, i.iterations) for i in out[1][1]] == [(i.rc, i.iterations) for i in ri]
+    assert [m.as_dict() for m in out[1][0]] == [m.as_dict() for m in rm]
+    assert any(i.rc == 0 for i in ri)
+    for a, sl in zip(accs, (empty, full, tiny)):
+        a.upload_events(sl["fr_x"], sl["fr_y"], sl["t"])
+        states, rcs = a.local_run_tiles(g, g, 3, 30, (180, 240), guard, max_evaluations=4000)
+        tr = np.minimum(sl["fr_x"].astype(np.int64) * g // 180, g - 1)
+        tc = np.minimum(sl["fr_y"].astype(np.int64) * g // 240, g - 1)
+        tid = tr * g + tc
+        for k in (0, 9, 27, 63):
+            sel = np.nonzero(tid == k)[0]
+            xl, xh = _tile_bounds(180, g, k // g)
+            yl, yh = _tile_bounds(240, g, k % g)
+            oc = oracle_lib.Cloud(sl["fr_x"][sel], sl["fr_y"][sel], sl["t"][sel])
+            ow = oc.local_window(3, center=((xl + xh) // 2, (yl + yh) // 2, 0), wsz=30)
+            orc, ost, _ = oc.local_run(ow, res_x=guard[0], res_y=guard[1], max_evaluations=4000)
+            assert rcs[k] == orc
+            for f in ("nx", "ny", "last_score", "dnx", "dny", "evaluations"):
+                assert getattr(states[k], f) == getattr(ost, f), (len(sl["t"]), k, f)
+        a.close()

@@ -303,7 +303,9 @@ int bf_set_model(bf_ctx *ctx, const bf_model *model);
  * poll of the `done` word every opts->poll_interval iterations.  The starting model is
  * the zero ObjectModel of a fresh optimizer (after bf_set_cloud) or what bf_set_model
  * was given; model_out receives get_model() (:285-287).  opts == NULL: defaults.
- * Returns info->rc.
+ * Returns info->rc.  When bf_run returns, the model and info are final; the last warp of the events (and, with want_uv, their
+ * per-event flow) may still be executing on the context's stream -- everything that reads per-event results (bf_compute_uv,
+ * bf_compute_uv_ring, bf_writeout_events, the renderers) and every later operation of the context runs on that stream, behind it.
  *
  * Tolerance contract.  The fused loop is NOT bit-identical to the reference's CPU path, and cannot be: (i) the time
  * image is the exact integer-nanosecond sum of a pixel's events rounded to f32 once, where the reference adds f32 seconds

@@ -283,6 +283,11 @@ int bf_set_option(bf_ctx* c, const char* key, int64_t value) {
         }
         return BF_OK;
     }
+    if (!strcmp(key, "sep_update")) {
+        if (value < 0 || value > 2) return fail(c, BF_ERR_ARG, "sep_update must be 0 (never), 1 (auto) or 2 (always)");
+        c->opt_sep_update = (int)value;
+        return BF_OK;
+    }
     if (!strcmp(key, "defer_uploads")) {
         if (!value) {   // (what was recorded goes out before the mode ends)
             const int rc = issue_deferred_uploads(c);

@@ -162,6 +162,7 @@ struct bf_ctx {
     // staging kernels, the events: ~25 us of host time) are issued by the next bf_run once that run's first batch of kernels is in
     // the queue -- or by whoever needs the slot sooner (bf_commit_upload, bf_wait_uploads).  For a single-threaded caller
     // driving one warm-started chain those 25 us otherwise sit between two runs, with the GPU idle.
+    int opt_sep_update = 1;          // co-scheduled contexts: the update as a kernel of its own -- 0 never, 1 for event lists, 2 always (bf_run.cpp)
     bool opt_defer_uploads = false;
     std::function<int()> deferred[2];
     std::mutex stats_mu;                          // fold_stats: bf_set_cloud's thread and an uploading thread (stage_early's guard) may both fold

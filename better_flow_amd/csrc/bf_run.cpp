@@ -121,7 +121,8 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // ping-pongs between two buffers (launch j reads [j & 1], writes [(j + 1) & 1]), the moment accumulators alternate
     // with the iteration's parity, and the overflow events of iteration j are counted in slot j % 3 (slot 2 stands
     // for "iteration -1": is plane buffer b0 ^ 1 still dirty from an earlier operator?).
-    auto state_of = [&](int j) { return c->d_state + (j & 1); };
+    bool sep_update = false;   // (decided below, with the update's home; then ONE state buffer)
+    auto state_of = [&](int j) { return c->d_state + (sep_update ? 0 : (j & 1)); };
     auto acc_of = [&](int j) { return c->d_acc + (size_t)(fused ? ((j % 3) + 3) % 3 : (j & 1)) * kAccGroups; };
     auto ovf_of = [&](int j) { return c->d_ovf + (((j % 3) + 3) % 3) * kOvfSlotWords; };
     // (one launch: the state, and the loop's counters / accumulators)
@@ -143,7 +144,18 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
     // work-group of the stencil kernel -- a serial tail on ONE CU that the other contexts' kernels fill, instead of
     // ~1.5 us on all 256 CUs.
     const bool head_update = fused || (binned && !c->opt_co_schedule);   // (the one-kernel loop has no other form)
-    if (head_update) c->acc_dirty = true;   // (the sums of the last iteration are consumed, not cleared)
+    // A third home ("sep_update", round 6): contexts that share the GPU run the lean scatter kernel and a stencil kernel that
+    // only ACCUMULATES (no drain of its atomics, no ticket, no serial tail), and the update is a kernel of its own
+    // (k_finish_update: one wave) ahead of every scatter launch, on ONE state buffer (nobody reads the state while that kernel
+    // writes it).  Bookkeeping -- accumulator parities, overflow slots, when a snapshot is behind a re-bin -- is the head
+    // form's.  A stencil work-group that has to see its fifteen atomics acknowledged and then wait for its ticket holds its LDS and a
+    // wave slot ~1 us longer -- 10 % of its life: with thousands of work-groups per launch (event lists: 8100 tiles at 1280x720)
+    // the third launch per iteration is the cheaper way (stencil kernel 42.7 -> 37.9 us under co_schedule, config 5's batch +2.7 %);
+    // with a few hundred (config 2: 752) the launch costs more than the tickets (bench 206.7 -> 200.9): "auto" takes it for event
+    // lists only.  Same bits either way.
+    sep_update = binned && !fused && !head_update && (c->opt_sep_update == 2 || (c->opt_sep_update == 1 && c->fmt == 2));
+    const bool head_like = head_update || sep_update;
+    if (head_like) c->acc_dirty = true;   // (the sums of the last iteration are consumed, not cleared)
     // events a scatter thread keeps in flight: one pass should cover a bin of 1.5 x the average size
     // (and its work-group size: 1024 threads for bins of thousands of events, 512 where a bin holds a few hundred --
     // large images --, so that twice as many bins are in flight per CU: 84 instead of 91 us per iteration at 1280x720)
@@ -379,6 +391,10 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                 inf.launches += 1;
                 continue;
             }
+            if (sep_update) {   // the pending update of iteration j - 1 (none at j = 0: the state's own counter says so)
+                launch_finish_update(state_of(j), acc_of(j - 1), ovf_of(j - 1), j, buf ^ 1, trace, quick_warm ? nullptr : &c->h_state[0], c->stream);
+                inf.launches++;
+            }
             if (binned) {
                 BinScatterArgs ba;
                 ba.sets = ev_sets(c);
@@ -412,7 +428,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
                     a.st = state_of(j + 1);
                     a.ovf_cur = ovf_of(j); a.ovf_prev = ovf_of(j - 1); a.ovf_next = ovf_of(j + 1);
                 }
-                if (head_update) {   // accumulate only: the update runs at the head of the next warp+scatter launch
+                if (head_like) {   // accumulate only: the update runs at the head of the next warp+scatter launch (or in its own kernel)
                     a.acc = acc_of(j); a.acc_zero = acc_of(j + 1);
                 } else if (binned) {   // "co_schedule": the last work-group of the stencil kernel updates
                     a.acc = c->d_acc;
@@ -450,7 +466,7 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // final warp rides along with every batch, gated on `done` (check_done 2) and picking the event
             // set on the device: when the batch was enough -- the usual case -- nothing is left to launch
             // after the poll (a blocking poll + launch costs ~20 us of idle GPU).
-            if (head_update) {   // `done` of the batch's last iteration: apply its update now (normally the next launch would)
+            if (head_like) {   // `done` of the batch's last iteration: apply its update now (normally the next launch would)
                 seq_wait = ++c->seq_counter;
                 launch_finish_update(state_of(launched_iters), acc_of(launched_iters - 1), ovf_of(launched_iters - 1),
                                      launched_iters, buf ^ 1, trace, &c->h_state[batch & 1], c->stream, fused ? lost_flag(c) + (launched_iters + 2) % 3 : nullptr,
@@ -521,12 +537,12 @@ int bf_run(bf_ctx* c, const bf_run_opts* opts_in, bf_model* model_out, bf_run_in
             // (a snapshot older than the last re-bin does not count.  With the update at the scatter head the snapshot of
             // iteration count L is written by launch L itself, behind a re-bin enqueued at L; with the update in the stencil
             // tail -- and in the one-kernel loop -- it is written by launch L - 1, ahead of that re-bin)
-            if (((fused || !head_update) ? gpu_it > last_rebin_at : gpu_it >= last_rebin_at) && gpu_it > 0 && *rebin_p) want_rebin = true;
+            if (((fused || !head_like) ? gpu_it > last_rebin_at : gpu_it >= last_rebin_at) && gpu_it > 0 && *rebin_p) want_rebin = true;
             if (launched_iters - stall_allowance > (o.hard_iter_cap > 0 ? o.hard_iter_cap : INT_MAX - 64) + 3 * o.poll_interval)
                 return fail(c, BF_ERR_NOCONV, "device loop did not terminate");
             continue;
         }
-        if (!(quick_warm && head_update))   // (there k_finish_update has written the state to the pinned copy itself)
+        if (!(quick_warm && head_like))   // (there k_finish_update has written the state to the pinned copy itself)
             HIP_TRY(c, hipMemcpyAsync(&c->h_state[batch & 1], state_of(binned ? launched_iters : 0), sizeof(DevState),
                                       hipMemcpyDeviceToHost, c->stream));
         // A cold run is polled one batch behind the launches, so its wait can sleep (the wake-up latency hides

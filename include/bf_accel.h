@@ -179,6 +179,12 @@ int bf_abi_struct_sizes(int32_t *out, int32_t n);
  *   "stream_prealloc"  1: create now what the asynchronous uploads (bf_upload_events_async / bf_upload_ring*_async) create
  *                  on first use -- the copy stream, its events, both staging slots -- so that the first slice of a stream
  *                  does not pay ~20 ms of allocations.
+ *   "sep_update"   where the model / loop update of a "co_schedule"d context's two-kernel loop runs: in the stencil kernel's last
+ *                  work-group (every work-group drains its accumulator atomics and takes a ticket), or as a one-wave kernel of
+ *                  its own ahead of every scatter launch (the stencil kernel then only accumulates).  0 the former, 2 the latter,
+ *                  1 (default): the latter for event lists -- thousands of stencil work-groups per launch, each holding its slot
+ *                  ~10 % longer for the ticket -- and the former for dense tiles (a few hundred work-groups: the extra launch costs
+ *                  more).  Bit-identical results.
  *   "defer_uploads"  1: an asynchronous upload (bf_upload_events_async / bf_upload_events16_async / bf_upload_ring*_async) only takes
  *                  its staging slot and remembers its arguments; the HIP calls behind it -- three copies, the staging kernels, the
  *                  events: ~25 us of host time -- are issued by the next bf_run as soon as that run's first batch of kernels is

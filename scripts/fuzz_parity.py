@@ -79,7 +79,8 @@ for ci in range(cases):
              ("margin", {"binned": 2, "debug_margin": int(rng.choice([4, 6, 12]))}),
              ("nopredict", {"binned": 2, "bin_predict": 0, "debug_margin": 2}),
              ("co", {"binned": 2, "co_schedule": 1}), ("compact", {"binned": 2, "bin_compact": 2}),
-             ("dense_co", {"binned": 2, "bin_compact": 0, "co_schedule": 1}), ("compact_co", {"binned": 2, "bin_compact": 2, "co_schedule": 1}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
+             ("dense_co", {"binned": 2, "bin_compact": 0, "co_schedule": 1}), ("compact_co", {"binned": 2, "bin_compact": 2, "co_schedule": 1}),
+             ("dense_co_sep", {"binned": 2, "bin_compact": 0, "co_schedule": 1, "sep_update": 2}), ("compact_co_tail", {"binned": 2, "bin_compact": 2, "co_schedule": 1, "sep_update": 0}), ("fallback", {"binned": 2, "bin_pack_limit": int(rng.choice([1, 20, 40]))}),
              ("split", {"binned": 2, "bin_compact": 0, "bin_split": 2, "debug_margin": int(rng.choice([2, 4, 8]))}),
              ("split_co", {"binned": 2, "bin_compact": 0, "bin_split": 2, "co_schedule": 1, "bin_predict": int(rng.integers(0, 2))}),
              ("fused", {"fused": 2, "persist": 0}), ("fused_tight", {"fused": 2, "persist": 0, "debug_margin": int(rng.choice([1, 2, 3])), "bin_predict": int(rng.integers(0, 2))}),

@@ -144,10 +144,10 @@ for step in range(steps):
         state["scale"] = int(rng.choice([1, 3, 3, 5, 7]))
         op = ("cloud", state["scale"]); state["cloud"] = True
     elif k == "opt":
-        name = str(rng.choice(["binned", "co_schedule", "bin_predict", "bin_pack_limit", "bin_compact", "bin_split", "fused", "persist"]))
+        name = str(rng.choice(["binned", "co_schedule", "co_schedule", "bin_predict", "bin_pack_limit", "bin_compact", "bin_split", "fused", "persist", "sep_update"]))
         val = {"persist": int(rng.integers(0, 3)), "fused": int(rng.integers(0, 3)), "binned": int(rng.integers(0, 3)),
                "co_schedule": int(rng.integers(0, 2)), "bin_compact": int(rng.integers(0, 3)), "bin_split": int(rng.integers(0, 3)), "bin_predict": int(rng.integers(0, 2)),
-               "bin_pack_limit": int(rng.choice([64, 64, 30, 1]))}[name]
+               "bin_pack_limit": int(rng.choice([64, 64, 30, 1])), "sep_update": int(rng.integers(0, 3))}[name]
         op = ("opt", name, val)
     elif k == "project":
         op = ("project", (rng.normal(0, .3), rng.normal(0, .3), rng.uniform(0, 100), rng.uniform(0, 100), rng.normal(0, 1e-4), rng.normal(0, 3e-5)))

@@ -37,7 +37,13 @@ FORMS = {
     "own pixels + margin plane, update in the stencil tail (bin_split=2, co_schedule)":
         (dict(binned=2, fused=0, bin_compact=0, bin_split=2, co_schedule=1), 3, 0),
     "dense slabs, update in the stencil tail": (dict(binned=2, fused=0, bin_compact=0, bin_split=0, co_schedule=1), 0, 0),
+    "own pixels + margin plane, co-scheduled, the update as a kernel of its own (sep_update=2)":
+        (dict(binned=2, fused=0, bin_compact=0, bin_split=2, co_schedule=1, sep_update=2), 3, 0),
     "event lists (bin_compact=2)": (dict(binned=2, fused=0, bin_compact=2), 2, 0),
+    "event lists, co-scheduled: the update as a kernel of its own (sep_update auto)": (dict(binned=2, fused=0, bin_compact=2, co_schedule=1), 2, 0),
+    "event lists, co-scheduled, update in the stencil tail (sep_update=0)": (dict(binned=2, fused=0, bin_compact=2, co_schedule=1, sep_update=0), 2, 0),
+    "dense slabs, co-scheduled, the update as a kernel of its own (sep_update=2)":
+        (dict(binned=2, fused=0, bin_compact=0, bin_split=0, co_schedule=1, sep_update=2), 0, 0),
     "global atomics (binned=0)": (dict(binned=0, fused=0), -1, 0),
 }
 

@@ -739,6 +739,7 @@ def test_full_size_config2(oracle_lib, accel_mod):
     runs = {}
     for name, opts in (("binned", dict(binned=2, fused=0)), ("atomics", dict(binned=0)), ("binned2", dict(binned=2, fused=0)), ("fused", dict(fused=2)),
                        ("tail_update", dict(binned=2, co_schedule=1)), ("compact", dict(binned=2, bin_compact=2)),
+                       ("sep_update", dict(binned=2, co_schedule=1, sep_update=2)), ("compact_co", dict(binned=2, bin_compact=2, co_schedule=1)),
                        ("dense", dict(binned=2, bin_compact=0))):
         a2 = accel_mod.Accel(max_events=len(sl["t"]), max_rows=s * H + s, max_cols=s * W + s)
         for k, v in opts.items():
@@ -1024,8 +1025,9 @@ def test_event_lists_full_bins_and_second_pass(accel_mod):
         sl = synth.make_slice(n, H, W, 0.05, seed=23)
         ref = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=0)
         got = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=2, bin_compact=2, **opts)
-        tail = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=2, bin_compact=2, co_schedule=1, **opts)
-        for r in (got, tail):
+        tail = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=2, bin_compact=2, co_schedule=1, sep_update=0, **opts)
+        sep = _run_mode(accel_mod, sl, H, W, scale, trace_cap=64, binned=2, bin_compact=2, co_schedule=1, **opts)   # (auto: the update as its own kernel)
+        for r in (got, tail, sep):
             assert r[0] == ref[0] and r[2].iterations == ref[2].iterations and r[2].rebins >= 1, (n, H, W)
             assert r[1].as_dict() == ref[1].as_dict(), (n, H, W)
             for a, b in zip(r[3], ref[3]):
